@@ -1,0 +1,118 @@
+"""CPU: the oracle (oracle/sae_oracle.py) against golden vectors produced by the real
+reference (tests/golden/make_golden.py).  These pins are what the GPU parity tests lean on."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+
+L1_CASES = ["l1_radam_cosine_d16", "l1_adam_linear_d48", "l1_radam_wd_d32", "l1_radam_cosine_d384"]
+TOPK_CASES = ["topk_adam_linear_d16", "topk_adam_linear_d64"]
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+def test_l1_autocast_oracle_matches_reference(golden_dir, name):
+    z, meta = _load(golden_dir, name)
+    W, b, st = torch.tensor(z["W0"]), torch.tensor(z["b0"]), O.OptState()
+    xs = torch.tensor(z["x"])
+    for i in range(meta["steps"]):
+        x = xs[i].reshape(-1, meta["d"])
+        lr = O.lr_at(i, meta["lr"], meta["scheduler"], meta["total_steps"], meta["num_warmup_steps"])
+        assert lr == pytest.approx(float(z["lr_used"][i]), rel=1e-12, abs=1e-18)
+        out = O.l1_train_step(x, W, b, st, recon_alpha=meta["recon_alpha"], lr=lr, clip_thresh=meta["clip_thresh"],
+                              optimizer=meta["optimizer"], weight_decay=meta["weight_decay"], autocast=True)
+        if i == 0:  # raw gradients of the first step: bit-for-bit the reference's .grad
+            assert torch.equal(out["dW"], torch.tensor(z["dW_step1"]))
+            assert torch.equal(out["db"], torch.tensor(z["db_step1"]))
+        assert out["l1_loss"].item() == pytest.approx(float(z["l1"][i]), rel=1e-6)
+        assert out["reconstruction_loss"].item() == pytest.approx(float(z["recon"][i]), rel=1e-6)
+        assert out["mse"].item() == pytest.approx(float(z["mse"][i]), rel=1e-6)
+        assert out["grad_norm"].item() == pytest.approx(float(z["gnorm"][i]), rel=1e-6)
+    torch.testing.assert_close(W, torch.tensor(z["W_final"]), rtol=0, atol=1e-7)
+    torch.testing.assert_close(b, torch.tensor(z["b_final"]), rtol=0, atol=1e-7)
+    torch.testing.assert_close(st.exp_avg["decoder.weight"], torch.tensor(z["m_W"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(st.exp_avg_sq["decoder.weight"], torch.tensor(z["v_W"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(st.exp_avg["encoder_bias"], torch.tensor(z["m_b"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(st.exp_avg_sq["encoder_bias"], torch.tensor(z["v_b"]), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+def test_l1_fp32_eval_matches_reference(golden_dir, name):
+    """validate() on cpu runs without autocast (train_sae.py:162-166): fp32 forward, and the
+    decoder columns are renormalised in place by encode() even in eval."""
+    z, meta = _load(golden_dir, name)
+    W = O.normalize_columns(torch.tensor(z["W_final"]))
+    torch.testing.assert_close(W, torch.tensor(z["W_after_eval"]), rtol=0, atol=1e-7)
+    x = torch.tensor(z["x"])[-1].reshape(-1, meta["d"])
+    f = O.l1_forward(x, W, torch.tensor(z["b_final"]), meta["recon_alpha"], autocast=False)
+    assert f["l1_loss"].item() == pytest.approx(float(z["eval_l1"]), rel=1e-5)
+    assert f["reconstruction_loss"].item() == pytest.approx(float(z["eval_recon"]), rel=1e-5)
+    assert f["mse"].item() == pytest.approx(float(z["eval_mse"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", L1_CASES)
+def test_l1_fp32_mode_close_to_autocast(golden_dir, name):
+    """The fp32-math mode tracks the reference's bf16-autocast numbers (5e-3 on these tiny
+    batches, where few elements average the bf16 rounding; ~2e-5 at M=65 536)."""
+    z, meta = _load(golden_dir, name)
+    W = O.normalize_columns(torch.tensor(z["W0"]))
+    x = torch.tensor(z["x"])[0].reshape(-1, meta["d"])
+    f = O.l1_forward(x, W, torch.tensor(z["b0"]), meta["recon_alpha"], autocast=False)
+    assert f["l1_loss"].item() == pytest.approx(float(z["l1"][0]), rel=5e-3)
+    assert f["reconstruction_loss"].item() == pytest.approx(float(z["recon"][0]), rel=5e-3)
+
+
+@pytest.mark.parametrize("name", TOPK_CASES)
+def test_topk_autocast_oracle_matches_reference(golden_dir, name):
+    z, meta = _load(golden_dir, name)
+    keys = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+    P = {k: torch.tensor(z["init__" + k]) for k in keys}
+    st, xs, n = O.OptState(), torch.tensor(z["x"]), meta["n"]
+    nfsf = torch.zeros(n, dtype=torch.long)
+    for i in range(meta["steps"]):
+        x = xs[i]
+        lr = O.lr_at(i, meta["lr"], "linear", meta["steps"], meta["num_warmup_steps"])
+        assert lr == pytest.approx(float(z["lr_used"][i]), rel=1e-12, abs=1e-18)
+        dead = nfsf > meta["dead_feature_threshold"]          # train_sae.py:436-439
+        assert int(dead.sum()) == int(z["num_dead"][i])
+        out = O.topk_train_step(x, P, st, k=meta["k"], lr=lr, clip_thresh=1.0, dead_mask=dead,
+                                auxk_alpha=meta["auxk_alpha"], optimizer="adam")
+        did = torch.zeros(n, dtype=torch.bool)
+        did[out["top_indices"].flatten()] = True              # train_sae.py:443-446
+        nfsf += x.shape[0] * x.shape[1]
+        nfsf[did] = 0
+        assert out["fvu"].item() == pytest.approx(float(z["fvu"][i]), rel=1e-6)
+        assert out["auxk_loss"].item() == pytest.approx(float(z["auxk"][i]), rel=1e-5, abs=1e-9)
+        assert out["grad_norm"].item() == pytest.approx(float(z["gnorm"][i]), rel=2e-4)
+        for tag, ii in (("first", 0), ("last", meta["steps"] - 1)):
+            if i == ii:
+                ref_idx = torch.tensor(z[f"{tag}__top_indices"]).reshape(-1, meta["k"])
+                got_idx = out["top_indices"].reshape(-1, meta["k"])
+                assert torch.equal(ref_idx.sort(-1).values, got_idx.sort(-1).values)   # compare as sets
+                for k in keys:
+                    ref = torch.tensor(z[f"{tag}__{k}"])
+                    torch.testing.assert_close(out["grads"][k], ref, rtol=0, atol=4e-3 * float(ref.abs().max()))
+    for k in keys:
+        torch.testing.assert_close(P[k], torch.tensor(z["final__" + k]), rtol=0, atol=5e-6)
+    assert torch.equal(nfsf, torch.tensor(z["nfsf_final"]))
+
+
+def test_lr_schedules_match_trainloop_fixture(golden_dir):
+    """train/lr is logged *after* scheduler.step() (train_sae.py:487-489): value at logged
+    step s is lr_at(s)."""
+    for name in ("trainloop_l1", "trainloop_topk"):
+        z, meta = _load(golden_dir, name)
+        cfg = meta["config"]
+        lrs = [(s, v) for (tag, v, s) in meta["scalars"] if tag == "train/lr"]
+        assert len(lrs) == cfg["steps"]
+        for s, v in lrs:
+            want = O.lr_at(s, cfg["lr"], cfg["scheduler"], cfg["steps"], cfg["scheduler_params"].get("num_warmup_steps", 0))
+            assert v == pytest.approx(want, rel=1e-9, abs=1e-15)
