@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the SAE train step (BASELINE.json metric: SAE train activations/sec).
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Whisper-tiny L1 SAE, d=384, dict 8x
+(n=3072), M=65 536 activation rows per GPU per step, RAdam + cosine schedule, recon_alpha=1e4,
+clip 1.0; synthetic low-rank activations resident in HBM as bf16 before the timed region;
+random-init (orthogonal) weights.  One step = renormalise decoder columns, encoder GEMM+ReLU,
+decoder GEMM, masked MSE + L1, full backward, (N>1: RCCL all-reduce of the gradients,) clip,
+RAdam.  One process per GPU; per-GPU work is fixed as N grows (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the tied-weight gradient
+GEMM pair), timed with HIP events on the launch stream inside the timed region; `cpu_baseline` is
+the CPU oracle (oracle/sae_oracle.py, a port of the reference's step) timed on this box's host
+cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_inputs(M, d, n, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.relu(torch.randn(M, 64, generator=g)) * 0.1
+    x = (z @ torch.randn(64, d, generator=g)).to(dtype)
+    torch.manual_seed(0)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W)
+    return x, W, torch.zeros(n)
+
+
+def cpu_baseline(x, W, b, steps, lr):
+    """The oracle's full train step on the host cores (same batch, same hyper-parameters)."""
+    from oracle import sae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Wc, bc, st = W.clone(), b.clone(), O.OptState()
+    xf = x.float()
+    O.l1_train_step(xf, Wc, bc, st, recon_alpha=1e4, lr=lr, clip_thresh=1.0, optimizer="radam")  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.l1_train_step(xf, Wc, bc, st, recon_alpha=1e4, lr=lr, clip_thresh=1.0, optimizer="radam")
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": x.shape[0] / dt, "unit": "activations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full train steps (+1 warm-up) of the same M={x.shape[0]} d={x.shape[1]} n={W.shape[1]} "
+                      f"batch, torch-CPU bf16-autocast restatement of train_sae.py:429-451, {dt:.3f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=65536)
+    ap.add_argument("--d", type=int, default=384)
+    ap.add_argument("--n", type=int, default=3072)
+    ap.add_argument("--x-dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the train step)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from freud_amd.engine import SaeEngine
+
+    M, d, n = args.rows, args.d, args.n
+    dtype = getattr(torch, args.x_dtype)
+    x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype)
+    x = x_cpu.cuda()
+    eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
+                    clip_thresh=1.0, device_id=local_rank)
+    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    grads = eng.grad_tensor() if world > 1 else None
+    total_steps, base_lr = 100000, 4e-4
+    lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
+
+    def one_step(i):
+        if world > 1:
+            eng.forward_backward(x)
+            dist.all_reduce(grads)
+            eng.optimizer_step(lr_of(i), 1.0 / world)
+        else:
+            eng.step(x, lr_of(i))
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    eng.profile(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    times = eng.kernel_times()
+    metrics = eng.metrics()
+    eng.profile(0)
+
+    ms_per_step = dt / args.steps * 1e3
+    value = M * world * args.steps / dt
+    dom = eng.dominant_kernel()
+    dom_ms, dom_cnt = times[dom]
+    dom_avg_ms = dom_ms / max(dom_cnt, 1)
+    dom_flops = 4.0 * M * d * n                      # two of the five 2*M*d*n GEMMs
+    achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
+    step_flops = 10.0 * M * d * n                    # algorithmic FLOPs per activation = 10 d n
+    fb_ms, fb_cnt = times["fwd_bwd_total"]
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        eng.profile(2)
+        for i in range(10):
+            one_step(args.warmup + args.steps + i)
+        breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in eng.kernel_times().items()}
+        eng.profile(0)
+        print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
+
+    out = {
+        "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
+                               f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
+                   "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel": dom,
+                     "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,
+                     "flops_per_launch": dom_flops},
+        "step_mfma_frac": (step_flops * world / (ms_per_step * 1e-3) / 1e12) / (PEAK_BF16_TFLOPS * world),
+        "fwd_bwd_ms": fb_ms / max(fb_cnt, 1),
+        "loss": {"recon": float(metrics[0]), "l1": float(metrics[1]), "grad_norm": float(metrics[3])},
+    }
+    if breakdown:
+        out["kernel_ms"] = breakdown
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(x_cpu, W, b, args.cpu_steps, base_lr)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,519 @@
+// libfreud_sae.so -- context management and the C ABI declared in include/freud_sae.h.
+// Host orchestration of the gfx950 kernels for one SAE optimizer step
+// (reference: src/scripts/train_sae.py:429-451).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/freud_sae.h"
+#include "l1_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// kernel ids for profiling
+// ------------------------------------------------------------------------------------------
+enum KernelId {
+  KID_PREP_W = 0,
+  KID_PREP_X,
+  KID_ENC_FWD,
+  KID_DEC_FWD,
+  KID_DPRE,
+  KID_DW,
+  KID_REDUCE,
+  KID_OPT,
+  KID_STEP_TOTAL,
+  KID_COUNT
+};
+static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x",        "enc_fwd_gemm", "dec_fwd_gemm", "dpre_gemm",
+                                              "dw_gemm", "reduce_grads", "clip_adam",    "fwd_bwd_total"};
+constexpr int EV_RING = 64;
+
+struct EvRing {
+  hipEvent_t beg[EV_RING], end[EV_RING];
+  int n = 0;  // recorded since last read
+};
+
+struct sae_ctx {
+  sae_config cfg;
+  int d, n, d_p, n_p;
+  int64_t max_rows_p;
+  int64_t nW;       // d_p * n_p
+  int64_t nparams;  // nW + n_p
+  // flat parameter / state buffers: [W (d_p*n_p) | b (n_p)]
+  float *P = nullptr, *Mom = nullptr, *Var = nullptr;
+  float* G = nullptr;  // [grads (nparams) | metrics (8)]
+  bf16_t *Wb = nullptr, *Wt = nullptr;
+  bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
+  float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
+  double* gn_part = nullptr;
+  unsigned int* masked = nullptr;
+  int dw_splits = 1;
+  int64_t step = 0;
+  int64_t last_M = 0, last_M_p = 0;
+  int last_dtype = 0;
+  int profile = 0;
+  EvRing ev[KID_COUNT];
+  bool ev_init = false;
+};
+
+static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
+  if (c->profile >= 2 || (c->profile == 1 && (kid == KID_DW || kid == KID_STEP_TOTAL))) {
+    EvRing& r = c->ev[kid];
+    hipEventRecord(r.beg[r.n % EV_RING], s);
+  }
+}
+static void ev_end(sae_ctx* c, int kid, hipStream_t s) {
+  if (c->profile >= 2 || (c->profile == 1 && (kid == KID_DW || kid == KID_STEP_TOTAL))) {
+    EvRing& r = c->ev[kid];
+    hipEventRecord(r.end[r.n % EV_RING], s);
+    r.n++;
+  }
+}
+
+extern "C" const char* sae_last_error(void) { return g_err; }
+extern "C" int sae_version(void) { return 1; }
+extern "C" const char* sae_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : nullptr; }
+extern "C" int sae_dominant_kernel(sae_ctx*) { return KID_DW; }
+
+extern "C" void sae_destroy(sae_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->cfg.device_id);
+  void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
+                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (c->ev_init)
+    for (auto& r : c->ev)
+      for (int i = 0; i < EV_RING; ++i) {
+        hipEventDestroy(r.beg[i]);
+        hipEventDestroy(r.end[i]);
+      }
+  delete c;
+}
+
+extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
+  if (!cfg || !out) return fail(SAE_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->variant != SAE_VARIANT_L1)
+    return fail(SAE_ERR_INVALID, "variant %d not supported by this build (only SAE_VARIANT_L1)", cfg->variant);
+  if (cfg->d_model <= 0 || cfg->n_dict <= 0 || cfg->max_rows <= 0)
+    return fail(SAE_ERR_INVALID, "d_model, n_dict and max_rows must be positive");
+  if (cfg->optimizer != SAE_OPT_RADAM && cfg->optimizer != SAE_OPT_ADAM)
+    return fail(SAE_ERR_INVALID, "Invalid optimizer: %d, must be 'radam' or 'adam'", cfg->optimizer);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(SAE_ERR_INVALID, "device_id %d out of range", cfg->device_id);
+  HIP_TRY(hipSetDevice(cfg->device_id));
+
+  sae_ctx* c = new sae_ctx();
+  c->cfg = *cfg;
+  c->d = cfg->d_model;
+  c->n = cfg->n_dict;
+  c->d_p = (int)round_up(c->d, 128);
+  c->n_p = (int)round_up(c->n, 128);
+  c->max_rows_p = round_up(cfg->max_rows, 128);
+  c->nW = (int64_t)c->d_p * c->n_p;
+  c->nparams = c->nW + c->n_p;
+  const int64_t Mp = c->max_rows_p;
+  const int out_tiles = (c->d_p / 128) * (c->n_p / 128);
+  const int ktiles = (int)(2 * Mp / 64);
+  c->dw_splits = 512 / out_tiles;
+  if (c->dw_splits < 1) c->dw_splits = 1;
+  if (c->dw_splits > ktiles) c->dw_splits = ktiles;
+  if (c->dw_splits > 64) c->dw_splits = 64;
+
+#define ALLOC(ptr, bytes)                                   \
+  do {                                                      \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));     \
+    if (e_ != hipSuccess) {                                 \
+      int rc_ = fail(SAE_ERR_HIP, "hipMalloc(%lld bytes) for %s failed: %s", (long long)(bytes), #ptr, \
+                     hipGetErrorString(e_));                \
+      sae_destroy(c);                                       \
+      return rc_;                                           \
+    }                                                       \
+  } while (0)
+  ALLOC(c->P, c->nparams * 4);
+  ALLOC(c->Mom, c->nparams * 4);
+  ALLOC(c->Var, c->nparams * 4);
+  ALLOC(c->G, (c->nparams + SAE_NUM_METRICS) * 4);
+  ALLOC(c->Wb, c->nW * 2);
+  ALLOC(c->Wt, c->nW * 2);
+  ALLOC(c->xb, Mp * c->d_p * 2);
+  ALLOC(c->c, Mp * c->n_p * 2);
+  ALLOC(c->dxh, Mp * c->d_p * 2);
+  ALLOC(c->dpre, Mp * c->n_p * 2);
+  ALLOC(c->slab, (int64_t)c->dw_splits * c->nW * 4);
+  ALLOC(c->db_part, (Mp / 128) * c->n_p * 4);
+  ALLOC(c->l1_part, (Mp / 128) * (c->n_p / 128) * 4);
+  ALLOC(c->sq_part, (Mp / 128) * (c->d_p / 128) * 2 * 4);
+  ALLOC(c->scal, 16 * 4);
+  ALLOC(c->gn_part, 1024 * 8);
+  ALLOC(c->masked, 16);
+#undef ALLOC
+  hipMemset(c->P, 0, c->nparams * 4);
+  hipMemset(c->Mom, 0, c->nparams * 4);
+  hipMemset(c->Var, 0, c->nparams * 4);
+  hipMemset(c->G, 0, (c->nparams + SAE_NUM_METRICS) * 4);
+  for (auto& r : c->ev)
+    for (int i = 0; i < EV_RING; ++i) {
+      hipEventCreate(&r.beg[i]);
+      hipEventCreate(&r.end[i]);
+    }
+  c->ev_init = true;
+  // opt in to > 64 KiB dynamic LDS for every GEMM instantiation lazily at first launch (see launch_gemm)
+  HIP_TRY(hipDeviceSynchronize());
+  *out = c;
+  return SAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter / optimizer-state transfer (reference layouts <-> padded internal layout)
+// ------------------------------------------------------------------------------------------
+static int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int to_internal,
+                  int is_device) {
+  hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : (to_internal ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+  HIP_TRY(hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind));
+  return SAE_OK;
+}
+
+static int xfer_flat(sae_ctx* c, float* internal, float* w_ext, float* b_ext, int to_internal, int is_device) {
+  int rc;
+  if (w_ext) {
+    if (to_internal)
+      rc = copy2d(internal, (size_t)c->n_p * 4, w_ext, (size_t)c->n * 4, (size_t)c->n * 4, c->d, 1, is_device);
+    else
+      rc = copy2d(w_ext, (size_t)c->n * 4, internal, (size_t)c->n_p * 4, (size_t)c->n * 4, c->d, 0, is_device);
+    if (rc) return rc;
+  }
+  if (b_ext) {
+    hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : (to_internal ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+    if (to_internal)
+      HIP_TRY(hipMemcpy(internal + c->nW, b_ext, (size_t)c->n * 4, kind));
+    else
+      HIP_TRY(hipMemcpy(b_ext, internal + c->nW, (size_t)c->n * 4, kind));
+  }
+  return SAE_OK;
+}
+
+extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, const float*, const float*, int is_device) {
+  if (!c || !p0 || !p1) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
+  return xfer_flat(c, c->P, const_cast<float*>(p0), const_cast<float*>(p1), 1, is_device);
+}
+
+extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float*, float*, int is_device) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  return xfer_flat(c, c->P, p0, p1, 0, is_device);
+}
+
+extern "C" int sae_set_opt_state(sae_ctx* c, int64_t step, const float* const exp_avg[4], const float* const exp_avg_sq[4],
+                                 int is_device) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  c->step = step;
+  int rc = SAE_OK;
+  if (exp_avg) rc = xfer_flat(c, c->Mom, const_cast<float*>(exp_avg[0]), const_cast<float*>(exp_avg[1]), 1, is_device);
+  if (rc) return rc;
+  if (exp_avg_sq) rc = xfer_flat(c, c->Var, const_cast<float*>(exp_avg_sq[0]), const_cast<float*>(exp_avg_sq[1]), 1, is_device);
+  return rc;
+}
+
+extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg[4], float* const exp_avg_sq[4],
+                                 int is_device) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  if (step) *step = c->step;
+  int rc = SAE_OK;
+  if (exp_avg) rc = xfer_flat(c, c->Mom, exp_avg[0], exp_avg[1], 0, is_device);
+  if (rc) return rc;
+  if (exp_avg_sq) rc = xfer_flat(c, c->Var, exp_avg_sq[0], exp_avg_sq[1], 0, is_device);
+  return rc;
+}
+
+extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
+  if (!c || !dev_ptr || !n_floats) return fail(SAE_ERR_INVALID, "null argument");
+  *dev_ptr = c->G;
+  *n_floats = c->nparams + SAE_NUM_METRICS;
+  return SAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------
+template <int AM, int BM_, class Epi>
+static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_bf16_kernel<AM, BM_, Epi>;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  const int grid = g.nbm * g.nbn * g.splits;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, g, epi);
+  HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
+template <typename T>
+static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream_t s, bool need_backward) {
+  const int d = c->d, d_p = c->d_p, n_p = c->n_p;
+  const float alpha = (float)c->cfg.recon_alpha;
+  float* W = c->P;
+  float* b = c->P + c->nW;
+
+  ev_begin(c, KID_PREP_W, s);
+  hipLaunchKernelGGL(prep_w_kernel, dim3(n_p / 64), dim3(256), 0, s, W, c->Wb, c->Wt, d_p, n_p);
+  ev_end(c, KID_PREP_W, s);
+
+  ev_begin(c, KID_PREP_X, s);
+  HIP_TRY(hipMemsetAsync(c->masked, 0, 16, s));
+  {
+    const int64_t chunks = Mp * (d_p / 8);
+    int grid = (int)((chunks + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(prep_x_kernel<T>, dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
+    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c->masked, c->scal, M, d, alpha);
+  }
+  ev_end(c, KID_PREP_X, s);
+
+  int rc;
+  {  // c = relu(x W + b)
+    GemmArgs g{};
+    g.A0 = c->xb; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
+    g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+    EpiEnc e{};
+    e.c = c->c; e.bias = b; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = g.nbn;
+    ev_begin(c, KID_ENC_FWD, s);
+    rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+    ev_end(c, KID_ENC_FWD, s);
+    if (rc) return rc;
+  }
+  {  // x_hat = c W^T, residual, dx_hat
+    GemmArgs g{};
+    g.A0 = c->c; g.B0 = c->Wb; g.lda = n_p; g.ldb = n_p;
+    g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
+    EpiDec<T> e{};
+    e.x = x; e.dxh = c->dxh; e.scal = c->scal; e.sq_part = c->sq_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = g.nbn;
+    ev_begin(c, KID_DEC_FWD, s);
+    rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+    ev_end(c, KID_DEC_FWD, s);
+    if (rc) return rc;
+  }
+  (void)need_backward;
+  return SAE_OK;
+}
+
+template <typename T>
+static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool backward) {
+  const int d = c->d, d_p = c->d_p, n_p = c->n_p;
+  const int64_t Mp = round_up(M, 128);
+  const float alpha = (float)c->cfg.recon_alpha;
+  ev_begin(c, KID_STEP_TOTAL, s);
+  int rc = forward_impl<T>(c, x, M, Mp, s, backward);
+  if (rc) return rc;
+  if (backward) {
+    {  // dpre = (dx_hat W + 1/M) [c > 0]
+      GemmArgs g{};
+      g.A0 = c->dxh; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
+      g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+      EpiDpre e{};
+      e.c = c->c; e.dpre = c->dpre; e.db_part = c->db_part; e.scal = c->scal; e.n_p = n_p;
+      ev_begin(c, KID_DPRE, s);
+      rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+      ev_end(c, KID_DPRE, s);
+      if (rc) return rc;
+    }
+    int splits = c->dw_splits;
+    {  // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs)
+      GemmArgs g{};
+      g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
+      g.nbm = d_p / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
+      if (splits > g.ktiles) splits = g.ktiles;
+      g.splits = splits;
+      EpiSlab e{};
+      e.slab = c->slab; e.slab_stride = c->nW; e.ld = n_p;
+      ev_begin(c, KID_DW, s);
+      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+      ev_end(c, KID_DW, s);
+      if (rc) return rc;
+    }
+    ev_begin(c, KID_REDUCE, s);
+    {
+      const int64_t n4 = c->nW / 4;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
+                         splits);
+      hipLaunchKernelGGL(reduce_db_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->db_part, c->G + c->nW,
+                         (int)(Mp / 128), n_p);
+    }
+    ev_end(c, KID_REDUCE, s);
+  }
+  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
+                     c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha);
+  ev_end(c, KID_STEP_TOTAL, s);
+  HIP_TRY(hipGetLastError());
+  c->last_M = M;
+  c->last_M_p = Mp;
+  return SAE_OK;
+}
+
+static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream, bool backward) {
+  if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
+  if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  hipStream_t s = (hipStream_t)stream;
+  c->last_dtype = x_dtype;
+  switch (x_dtype) {
+    case SAE_DTYPE_F32: return fwd_bwd_impl<float>(c, (const float*)x, M, s, backward);
+    case SAE_DTYPE_F16: return fwd_bwd_impl<_Float16>(c, (const _Float16*)x, M, s, backward);
+    case SAE_DTYPE_BF16: return fwd_bwd_impl<bf16_t>(c, (const bf16_t*)x, M, s, backward);
+    default: return fail(SAE_ERR_INVALID, "unknown x_dtype %d", x_dtype);
+  }
+}
+
+extern "C" int sae_forward_backward(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
+  return dispatch_fwd_bwd(c, x, M, x_dtype, stream, true);
+}
+extern "C" int sae_eval(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
+  return dispatch_fwd_bwd(c, x, M, x_dtype, stream, false);
+}
+
+extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void* stream) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  hipStream_t s = (hipStream_t)stream;
+  c->step += 1;
+  const double t = (double)c->step, b1 = c->cfg.beta1, b2 = c->cfg.beta2;
+  const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+  OptArgs a{};
+  a.lr = (float)lr;
+  a.grad_scale = (float)grad_scale;
+  a.clip_thresh = (float)c->cfg.clip_thresh;
+  a.weight_decay = (float)c->cfg.weight_decay;
+  a.beta1 = (float)b1;
+  a.beta2 = (float)b2;
+  a.eps = (float)c->cfg.eps;
+  a.one_minus_beta1 = (float)(1.0 - b1);
+  a.one_minus_beta2 = (float)(1.0 - b2);
+  a.bc1 = (float)bc1;
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.step_size = (float)(lr / bc1);
+  a.is_radam = c->cfg.optimizer == SAE_OPT_RADAM;
+  if (a.is_radam) {
+    const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * t * pow(b2, t) / bc2;
+    a.rectify = rho_t > 5.0;
+    a.rect = a.rectify ? (float)sqrt((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) : 0.f;
+  }
+  ev_begin(c, KID_OPT, s);
+  const int64_t n4 = c->nparams / 4;  // nW and n_p are multiples of 128
+  int gblocks = (int)((n4 + 255) / 256);
+  if (gblocks > 1024) gblocks = 1024;
+  hipLaunchKernelGGL(gnorm_partial_kernel, dim3(gblocks), dim3(256), 0, s, c->G, n4, a.grad_scale, c->gn_part);
+  int oblocks = (int)((n4 + 255) / 256);
+  if (oblocks > 2048) oblocks = 2048;
+  hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
+                     a, c->G + c->nparams);
+  ev_end(c, KID_OPT, s);
+  HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
+extern "C" int sae_step(sae_ctx* c, const void* x, int64_t M, int x_dtype, double lr, void* stream) {
+  int rc = sae_forward_backward(c, x, M, x_dtype, stream);
+  if (rc) return rc;
+  return sae_optimizer_step(c, lr, 1.0, stream);
+}
+
+extern "C" int sae_read_metrics(sae_ctx* c, float out[SAE_NUM_METRICS], void* stream) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipMemcpyAsync(out, c->G + c->nparams, SAE_NUM_METRICS * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return SAE_OK;
+}
+
+extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t M = c->last_M;
+  if (which == 0 || which == 1) {
+    const int cols = which == 0 ? c->n : c->d, ld = which == 0 ? c->n_p : c->d_p;
+    if (cap < M * cols) return fail(SAE_ERR_INVALID, "capacity too small");
+    std::vector<uint16_t> tmp((size_t)M * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), which == 0 ? (void*)c->c : (void*)c->dxh, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < M; ++r)
+      for (int j = 0; j < cols; ++j) {
+        uint32_t u = (uint32_t)tmp[(size_t)r * ld + j] << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        out[r * cols + j] = f;
+      }
+    return SAE_OK;
+  }
+  if (which == 2) {
+    if (cap < (int64_t)c->d * c->n + c->n) return fail(SAE_ERR_INVALID, "capacity too small");
+    int rc = xfer_flat(c, c->G, out, out + (int64_t)c->d * c->n, 0, 0);
+    return rc;
+  }
+  return fail(SAE_ERR_INVALID, "unknown debug tensor %d", which);
+}
+
+extern "C" int sae_profile(sae_ctx* c, int level) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  c->profile = level;
+  for (auto& r : c->ev) r.n = 0;
+  return SAE_OK;
+}
+
+extern "C" int sae_kernel_times(sae_ctx* c, float* ms_sum, int32_t* launches, int n) {
+  if (!c || !ms_sum || !launches) return fail(SAE_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  for (int k = 0; k < n; ++k) {
+    ms_sum[k] = 0.f;
+    launches[k] = 0;
+    if (k >= KID_COUNT) continue;
+    EvRing& r = c->ev[k];
+    const int cnt = r.n < EV_RING ? r.n : EV_RING;
+    for (int i = 0; i < cnt; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.beg[i], r.end[i]) == hipSuccess) {
+        ms_sum[k] += ms;
+        launches[k]++;
+      }
+    }
+    r.n = 0;
+  }
+  return SAE_OK;
+}

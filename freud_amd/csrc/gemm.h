@@ -1,0 +1,203 @@
+// 128x128x64 bf16 MFMA GEMM for gfx950 with LDS-staged tiles and a row-major epilogue functor.
+//
+//   C[128*bm .. , 128*bn ..] = sum_k A(m,k) * B(n,k)            (fp32 accumulate)
+//
+// Operand storage modes (per operand):
+//   OP_ROW    : K-contiguous, P[(row)*ld + k]      -> fragments by ds_read_b128 from an XOR-swizzled
+//               [128][64] image (conflict-free for the 4x16-lane groups of ds_read_b128);
+//   OP_KMAJOR : K is the slow dimension, P[(k)*ld + row] -> fragments by ds_read_b64_tr_b16 (hardware
+//               transposing read) from a [64][128] image with 256-B rows, chunk-XOR swizzled.
+// The K range may be the concatenation of two (A,B) pairs (used for the tied-weight gradient
+// dW = dx_hat^T c + x^T dpre, one accumulator) and may be split over blockIdx ranges (split-K).
+//
+// 256 threads = 4 waves in a 2x2 arrangement, each wave a 64x64 output (2x2 v_mfma_f32_32x32x16_bf16
+// tiles, 64 accumulator registers); two LDS stages of 32 KiB; register-staged global loads issued one
+// K-tile ahead (loads for tile t+1 are in flight while tile t is multiplied).
+#pragma once
+#include "common.h"
+
+enum { OP_ROW = 0, OP_KMAJOR = 1 };
+
+struct GemmArgs {
+  const bf16_t* A0;
+  const bf16_t* B0;
+  const bf16_t* A1;  // second K segment (may be null)
+  const bf16_t* B1;
+  int64_t lda, ldb;  // elements
+  int nbm, nbn;      // output tiles
+  int ktiles0;       // 64-wide K tiles in segment 0
+  int ktiles;        // total K tiles (segment 0 + segment 1)
+  int splits;        // split-K factor (grid = nbm*nbn*splits)
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
+constexpr int GEMM_STAGE_BYTES = 32768;              // A 16 KiB + B 16 KiB
+constexpr int GEMM_EPI_PITCH = 132;                  // floats
+constexpr int GEMM_LDS_BYTES = 128 * GEMM_EPI_PITCH * 4;  // 67584 >= 2 stages
+
+// Bijective XCD-aware remap (blocks b and b+8 share an XCD's L2: give each XCD a contiguous id range).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, xcd = id & 7, idx = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int MODE>
+__device__ __forceinline__ void tile_load(uint4 (&regs)[4], const bf16_t* base, int64_t ld, int t) {
+  if constexpr (MODE == OP_ROW) {
+    // [128 rows][64 k]: thread -> row t/8 + 32 i, 16-B chunk t%8
+    const bf16_t* p = base + (int64_t)(t >> 3) * ld + (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(32 * i) * ld);
+  } else {
+    // [64 k][128 cols]: thread -> k row t/16 + 16 i, 16-B chunk t%16
+    const bf16_t* p = base + (int64_t)(t >> 4) * ld + (t & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(16 * i) * ld);
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void tile_store(const uint4 (&regs)[4], char* lds, int t) {
+  if constexpr (MODE == OP_ROW) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (t >> 3) + 32 * i, c = t & 7;
+      *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = regs[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (t >> 4) + 16 * i, c = t & 15;
+      *reinterpret_cast<uint4*>(lds + r * 256 + ((c ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4)) = regs[i];
+    }
+  }
+}
+
+// Fragment of the 32x32x16 MFMA for the 32 output rows/cols starting at `base32` of the tile, k-step kk.
+template <int MODE>
+__device__ __forceinline__ bf16x8 frag_read(const char* lds, int base32, int kk, int lane) {
+  if constexpr (MODE == OP_ROW) {
+    const int r = base32 + (lane & 31), c = 2 * kk + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+  } else {
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int col = base32 + 16 * g + 4 * p;
+    const int r0 = 16 * kk + 8 * h + q, r1 = r0 + 4;
+    const int o0 = r0 * 256 + (((col >> 3) ^ (((r0 & 3) << 2) | ((r0 >> 2) & 3))) << 4) + (col & 7) * 2;
+    const int o1 = r1 * 256 + (((col >> 3) ^ (((r1 & 3) << 2) | ((r1 >> 2) & 3))) << 4) + (col & 7) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + o0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + o1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// Epi requirements:
+//   __device__ void tile_begin(int row0, int col0, int split);
+//   __device__ void apply(int row, int col, f32x4 v);   // 4 consecutive columns
+//   __device__ void tile_end(float* lds_scratch);        // block-wide reductions (all 256 threads call)
+template <int AMODE, int BMODE, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+
+  const int nblk = g.nbm * g.nbn * g.splits;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int split = id / (g.nbm * g.nbn);
+  id -= split * (g.nbm * g.nbn);
+  const int bm = id / g.nbn, bn = id - bm * g.nbn;
+  const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
+  const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto a_ptr = [&](int kt) -> const bf16_t* {
+    const bool s1 = kt >= g.ktiles0;
+    const bf16_t* base = s1 ? g.A1 : g.A0;
+    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    if constexpr (AMODE == OP_ROW) return base + (int64_t)(bm * GEMM_BM) * g.lda + k;
+    else return base + (int64_t)k * g.lda + bm * GEMM_BM;
+  };
+  auto b_ptr = [&](int kt) -> const bf16_t* {
+    const bool s1 = kt >= g.ktiles0;
+    const bf16_t* base = s1 ? g.B1 : g.B0;
+    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    if constexpr (BMODE == OP_ROW) return base + (int64_t)(bn * GEMM_BN) * g.ldb + k;
+    else return base + (int64_t)k * g.ldb + bn * GEMM_BN;
+  };
+
+  uint4 ra[4], rb[4];
+  if (kt_begin < kt_end) {
+    tile_load<AMODE>(ra, a_ptr(kt_begin), g.lda, t);
+    tile_load<BMODE>(rb, b_ptr(kt_begin), g.ldb, t);
+    tile_store<AMODE>(ra, smem, t);
+    tile_store<BMODE>(rb, smem + 16384, t);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
+    if (more) {
+      tile_load<AMODE>(ra, a_ptr(kt + 1), g.lda, t);
+      tile_load<BMODE>(rb, b_ptr(kt + 1), g.ldb, t);
+    }
+    const char* sa = smem + cur * GEMM_STAGE_BYTES;
+    const char* sb = sa + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = frag_read<AMODE>(sa, 64 * wm + 32 * i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = frag_read<BMODE>(sb, 64 * wn + 32 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* na = smem + (cur ^ 1) * GEMM_STAGE_BYTES;
+      tile_store<AMODE>(ra, na, t);
+      tile_store<BMODE>(rb, na + 16384, t);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: accumulators -> fp32 LDS tile -> row-major functor (coalesced global access) ----
+  float* tile = reinterpret_cast<float*>(smem);
+  {
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+          tile[row * GEMM_EPI_PITCH + 64 * wn + 32 * j + c] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  epi.tile_begin(bm * GEMM_BM, bn * GEMM_BN, split);
+  {
+    const int c4 = (t & 31) * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = (t >> 5) + 8 * it;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * GEMM_EPI_PITCH + c4]);
+      epi.apply(bm * GEMM_BM + row, bn * GEMM_BN + c4, v);
+    }
+  }
+  __syncthreads();
+  epi.tile_end(tile);
+}

@@ -1,0 +1,350 @@
+// Kernels of the L1 (tied-weight) SAE train step around the MFMA GEMMs: weight/activation
+// preparation, GEMM epilogues, gradient reduction, clip + Adam/RAdam.
+// Reference arithmetic: src/models/l1autoencoder.py:29-36,69-95; src/scripts/train_sae.py:429-451.
+#pragma once
+#include "gemm.h"
+
+// ------------------------------------------------------------------------------------------
+// prep_w: W <- W / max(||W[:,j]||_2, 1e-12) in place (l1autoencoder.py:71-73), and the two bf16
+// GEMM operand copies: Wb[d_p][n_p] (K = n contiguous, decoder) and Wt[n_p][d_p] (K = d contiguous,
+// encoder / dc).  One block = 64 dictionary columns x all rows.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_w_kernel(float* __restrict__ W, bf16_t* __restrict__ Wb,
+                                                      bf16_t* __restrict__ Wt, int d_p, int n_p) {
+  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) bf16_t tT[64][136];
+  const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  float ss = 0.f;
+  for (int i = ty; i < d_p; i += 4) {
+    const float v = W[(int64_t)i * n_p + col];
+    ss += v * v;
+  }
+  red[ty][tx] = ss;
+  __syncthreads();
+  const float denom = fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
+  for (int i0 = 0; i0 < d_p; i0 += 128) {
+    __syncthreads();
+    for (int i = ty; i < 128; i += 4) {
+      const int64_t o = (int64_t)(i0 + i) * n_p + col;
+      const float v = W[o] / denom;
+      W[o] = v;
+      const bf16_t b = (bf16_t)v;
+      Wb[o] = b;
+      tT[tx][i] = b;
+    }
+    __syncthreads();
+    // 64 columns x 128 rows -> Wt[col][i0 .. i0+128): 16 pieces of 16 B per column
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = t + 256 * it, c = piece >> 4, s = piece & 15;
+      *reinterpret_cast<uint4*>(Wt + (int64_t)(blockIdx.x * 64 + c) * d_p + i0 + s * 8) =
+          *reinterpret_cast<const uint4*>(&tT[c][s * 8]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// prep_x: activation rows (fp32 / fp16 / bf16, [M][d]) -> zero-padded bf16 GEMM operand
+// xb[M_p][d_p]; counts the entries equal to -1 (mse_loss's ignored_index, l1autoencoder.py:31).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float load_as_float(const T* p) { return (float)*p; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_x_kernel(const T* __restrict__ x, bf16_t* __restrict__ xb,
+                                                      unsigned int* __restrict__ masked_count, int64_t M, int d,
+                                                      int64_t M_p, int d_p) {
+  const int chunks_per_row = d_p >> 3;
+  const int64_t total = M_p * chunks_per_row;
+  unsigned int masked = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / chunks_per_row;
+    const int c0 = (int)(i - row * chunks_per_row) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (row < M && c0 + j < d) {
+        v = load_as_float(x + row * d + c0 + j);
+        masked += (v == -1.0f);
+      }
+      o[j] = (bf16_t)v;
+    }
+    *reinterpret_cast<bf16x8*>(xb + row * d_p + c0) = o;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) masked += (unsigned int)__shfl_xor((int)masked, o, 64);
+  if ((threadIdx.x & 63) == 0 && masked) atomicAdd(masked_count, masked);
+}
+
+// scal[0] = count of unmasked entries, scal[1] = alpha/count (d loss / d squared-error term), scal[2] = 1/M
+__global__ void finalize_count_kernel(const unsigned int* masked_count, float* scal, int64_t M, int d, float alpha) {
+  const double count = (double)M * d - (double)*masked_count;
+  scal[0] = (float)count;
+  scal[1] = alpha / (float)count;
+  scal[2] = 1.0f / (float)M;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM epilogues (row-major over the fp32 tile, 4 consecutive columns per call)
+// ------------------------------------------------------------------------------------------
+// c = relu(bf16(x W) + b)  (l1autoencoder.py:74), rows >= M forced to 0; L1 partial sum per tile.
+struct EpiEnc {
+  bf16_t* c;            // [M_p][n_p]
+  const float* bias;    // [n_p]
+  float* l1_part;       // [tiles]
+  int64_t M;
+  int n_p, nbn;
+  float l1;
+  int tile_id;
+  __device__ void tile_begin(int row0, int col0, int) {
+    l1 = 0.f;
+    tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
+  }
+  __device__ void apply(int row, int col, f32x4 v) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float cv = fmaxf(bf16_round(v[j]) + b[j], 0.f);
+      if (row >= M) cv = 0.f;
+      l1 += cv;
+      o[j] = (bf16_t)cv;
+    }
+    *reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col) = o;
+  }
+  __device__ void tile_end(float* scratch) {
+    const float s = block_sum_256(l1, scratch);
+    if (threadIdx.x == 0) l1_part[tile_id] = s;
+  }
+};
+
+// x_hat = bf16(c W^T); masked residual; dx_hat = bf16(2 alpha (x_hat - x) [x != -1] / count)
+// (l1autoencoder.py:84,86,29-36 and its backward).  Partial sums: masked sq-err, unmasked sq-err.
+template <typename T>
+struct EpiDec {
+  const T* x;           // original activations [M][d]
+  bf16_t* dxh;          // [M_p][d_p]
+  const float* scal;    // scal[1] = alpha / count
+  float* sq_part;       // [tiles][2]
+  int64_t M;
+  int d, d_p, nbn;
+  float sq, plain, scale;
+  int tile_id;
+  __device__ void tile_begin(int row0, int col0, int) {
+    sq = plain = 0.f;
+    scale = scal[1];
+    tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
+  }
+  __device__ void apply(int row, int col, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = 0.f;
+      if (row < M && col + j < d) {
+        const float xv = load_as_float(x + (int64_t)row * d + col + j);
+        const float e = bf16_round(v[j]) - xv;
+        plain += e * e;
+        if (xv != -1.0f) {
+          sq += e * e;
+          g = (e * 2.0f) * scale;
+        }
+      }
+      o[j] = (bf16_t)g;
+    }
+    *reinterpret_cast<bf16x4*>(dxh + (int64_t)row * d_p + col) = o;
+  }
+  __device__ void tile_end(float* scratch) {
+    const float a = block_sum_256(sq, scratch);
+    const float b = block_sum_256(plain, scratch + 8);
+    if (threadIdx.x == 0) {
+      sq_part[2 * tile_id] = a;
+      sq_part[2 * tile_id + 1] = b;
+    }
+  }
+};
+
+// dpre = (bf16(dx_hat W) + sign(c)/M) * [c > 0]; db partial column sums per row-tile.
+struct EpiDpre {
+  const bf16_t* c;      // [M_p][n_p]
+  bf16_t* dpre;         // [M_p][n_p]
+  float* db_part;       // [nbm][n_p]
+  const float* scal;    // scal[2] = 1/M
+  int n_p;
+  float colsum[4];
+  float inv_m;
+  int row_tile, col0_;
+  __device__ void tile_begin(int row0, int col0, int) {
+    colsum[0] = colsum[1] = colsum[2] = colsum[3] = 0.f;
+    inv_m = scal[2];
+    row_tile = row0 / GEMM_BM;
+    col0_ = col0;
+  }
+  __device__ void apply(int row, int col, f32x4 v) {
+    const bf16x4 cv = *reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = ((float)cv[j] > 0.f) ? (bf16_round(v[j]) + inv_m) : 0.f;
+      colsum[j] += g;
+      o[j] = (bf16_t)g;
+    }
+    *reinterpret_cast<bf16x4*>(dpre + (int64_t)row * n_p + col) = o;
+  }
+  __device__ void tile_end(float* scratch) {
+    // thread t owns columns 4*(t&31).. of row group t>>5: reduce the 8 row groups through LDS
+    const int t = threadIdx.x;
+    f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
+    *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
+    __syncthreads();
+    if (t < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int gidx = 0; gidx < 8; ++gidx) s += scratch[gidx * 128 + t];
+      db_part[(int64_t)row_tile * n_p + col0_ + t] = s;
+    }
+  }
+};
+
+// split-K partial slab store for dW
+struct EpiSlab {
+  float* slab;          // [splits][rows][ld]
+  int64_t slab_stride;  // rows*ld
+  int ld;
+  float* base;
+  __device__ void tile_begin(int, int, int split) { base = slab + slab_stride * split; }
+  __device__ void apply(int row, int col, f32x4 v) { *reinterpret_cast<f32x4*>(base + (int64_t)row * ld + col) = v; }
+  __device__ void tile_end(float*) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// gradient reduction, loss finalisation, clip + optimizer
+// ------------------------------------------------------------------------------------------
+// grad[i] = sum_s slab[s][i] (float4 per thread)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ grad,
+                                                            int64_t n4, int64_t stride4, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* s = reinterpret_cast<const f32x4*>(slab);
+  f32x4 a = s[i];
+  for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+  reinterpret_cast<f32x4*>(grad)[i] = a;
+}
+
+// db[j] = sum over row tiles of db_part[tile][j]
+__global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict__ part, float* __restrict__ db, int nbm,
+                                                         int n_p) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_p) return;
+  float s = 0.f;
+  for (int i = 0; i < nbm; ++i) s += part[(int64_t)i * n_p + j];
+  db[j] = s;
+}
+
+// One block: loss scalars from the per-tile partials (double accumulation, fixed order -> deterministic).
+// metrics: [0]=alpha*sq/count  [1]=l1_sum/M  [2]=plain_sq/(M*d)  [4]=count
+__global__ __launch_bounds__(256) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
+                                                               int n_sq, const float* scal, float* metrics, int64_t M,
+                                                               int d, float alpha) {
+  __shared__ double red[3][4];
+  double a = 0, b = 0, c = 0;
+  for (int i = threadIdx.x; i < n_l1; i += 256) a += (double)l1_part[i];
+  for (int i = threadIdx.x; i < n_sq; i += 256) {
+    b += (double)sq_part[2 * i];
+    c += (double)sq_part[2 * i + 1];
+  }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+    red[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double l1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double pl = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const double count = (double)scal[0];
+    metrics[0] = (float)((double)alpha * (sq / count));
+    metrics[1] = (float)(l1 / (double)M);
+    metrics[2] = (float)(pl / ((double)M * d));
+    metrics[3] = 0.f;
+    metrics[4] = scal[0];
+    metrics[5] = metrics[6] = metrics[7] = 0.f;
+  }
+}
+
+// per-block sum of (scale*g)^2 over the flat gradient
+__global__ __launch_bounds__(256) void gnorm_partial_kernel(const float* __restrict__ grad, int64_t n4, float scale,
+                                                             double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(grad)[i] * scale;
+    s += (double)(g[0] * g[0]) + (double)(g[1] * g[1]) + (double)(g[2] * g[2]) + (double)(g[3] * g[3]);
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct OptArgs {
+  float lr, grad_scale, clip_thresh, weight_decay;
+  float beta1, beta2, eps;
+  float one_minus_beta1, one_minus_beta2;
+  float bc1, bc2_sqrt;      // 1 - beta1^t, sqrt(1 - beta2^t)
+  float step_size;          // Adam: lr / bc1
+  float rect;               // RAdam rectification term (valid if rectify)
+  int rectify;              // RAdam: rho_t > 5
+  int is_radam;
+};
+
+// clip_grad_norm_ (coef = min(1, thresh/(norm+1e-6))) fused with the torch single-tensor
+// Adam / RAdam update (op order of torch/optim/{adam,radam}.py kept for fp32 agreement).
+__global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, const float* __restrict__ grad,
+                                                         int64_t n4, const double* __restrict__ gn_part, int n_part,
+                                                         OptArgs a, float* __restrict__ metrics) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float total = sqrtf((float)(red[0] + red[1] + red[2] + red[3]));
+  const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) metrics[3] = total;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 g = reinterpret_cast<const f32x4*>(grad)[i];
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = (g[j] * a.grad_scale) * coef;
+      if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
+      mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
+      vv[j] = vv[j] * a.beta2;
+      vv[j] = vv[j] + (a.one_minus_beta2 * gj) * gj;
+      if (a.is_radam) {
+        const float mh = mv[j] / a.bc1;
+        if (a.rectify) {
+          const float adaptive = (1.0f / (sqrtf(vv[j]) + a.eps)) * a.bc2_sqrt;
+          pv[j] = pv[j] - ((mh * a.lr) * adaptive) * a.rect;
+        } else {
+          pv[j] = pv[j] - mh * a.lr;
+        }
+      } else {
+        const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+        pv[j] = pv[j] + (-a.step_size * mv[j]) / denom;
+      }
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}

@@ -1,0 +1,265 @@
+"""ctypes binding of libfreud_sae.so (C ABI: include/freud_sae.h).
+
+This is the only door between the Python host (orchestration, torch for device memory,
+streams and torch.distributed) and the HIP engine that runs the SAE train step
+(reference hot path: src/scripts/train_sae.py:421-453).  There is no CPU fallback: if the
+shared library is missing the import of this module's `load()` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfreud_sae.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+VARIANT = {"l1": 0, "topk": 1}
+OPTIMIZER = {"radam": 0, "adam": 1}
+DTYPE = {"float32": 0, "float16": 1, "bfloat16": 2}
+NUM_METRICS = 8
+M_LOSS_RECON, M_LOSS_L1, M_MSE, M_GRAD_NORM, M_COUNT = 0, 1, 2, 3, 4
+
+
+class SaeConfig(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("d_model", C.c_int32), ("n_dict", C.c_int32), ("k", C.c_int32),
+        ("optimizer", C.c_int32), ("device_id", C.c_int32), ("max_rows", C.c_int64),
+        ("recon_alpha", C.c_double), ("auxk_alpha", C.c_double), ("clip_thresh", C.c_double),
+        ("weight_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", CSRC_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"build did not produce {LIB_PATH}")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the engine and declare every symbol of include/freud_sae.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built "
+            f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC_DIR}`). "
+            "There is no CPU fallback for the train step.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    fptr = C.POINTER(C.c_float)
+    sig = {
+        "sae_last_error": (C.c_char_p, []),
+        "sae_version": (C.c_int, []),
+        "sae_create": (C.c_int, [C.POINTER(SaeConfig), C.POINTER(vp)]),
+        "sae_destroy": (None, [vp]),
+        "sae_set_params": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+        "sae_get_params": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
+        "sae_set_opt_state": (C.c_int, [vp, i64, C.POINTER(vp), C.POINTER(vp), C.c_int]),
+        "sae_get_opt_state": (C.c_int, [vp, C.POINTER(i64), C.POINTER(vp), C.POINTER(vp), C.c_int]),
+        "sae_forward_backward": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+        "sae_grad_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
+        "sae_optimizer_step": (C.c_int, [vp, dbl, dbl, vp]),
+        "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
+        "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+        "sae_read_metrics": (C.c_int, [vp, fptr, vp]),
+        "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
+        "sae_profile": (C.c_int, [vp, C.c_int]),
+        "sae_kernel_times": (C.c_int, [vp, fptr, C.POINTER(i32), C.c_int]),
+        "sae_kernel_name": (C.c_char_p, [C.c_int]),
+        "sae_dominant_kernel": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
+    "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
+    "sae_step", "sae_eval", "sae_read_metrics", "sae_debug_read", "sae_profile", "sae_kernel_times",
+    "sae_kernel_name", "sae_dominant_kernel",
+]
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise EngineError(f"libfreud_sae error {rc}: {load().sae_last_error().decode()}")
+
+
+def _np_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class SaeEngine:
+    """One engine context = one SAE on one GPU.  Thin, typed wrapper over the C ABI."""
+
+    def __init__(self, variant: str, d_model: int, n_dict: int, max_rows: int, *, optimizer: str = "radam",
+                 recon_alpha: float = 1.0, k: int = 0, auxk_alpha: float = 0.0, clip_thresh: float = 1.0,
+                 weight_decay: float = 0.0, betas=(0.9, 0.999), eps: Optional[float] = None, device_id: int = 0):
+        if variant not in VARIANT:
+            raise AssertionError(f"Invalid autoencoder variant: {variant}, must be 'l1' or 'topk'")
+        if optimizer not in OPTIMIZER:
+            raise ValueError(f"Invalid optimizer: {optimizer}, must be 'radam' or 'adam'")
+        self._lib = load()
+        if eps is None:  # train_sae.py:374-379: RAdam(eps=1e-5), Adam default 1e-8
+            eps = 1e-5 if optimizer == "radam" else 1e-8
+        cfg = SaeConfig()
+        cfg.variant, cfg.d_model, cfg.n_dict, cfg.k = VARIANT[variant], d_model, n_dict, k
+        cfg.optimizer, cfg.device_id, cfg.max_rows = OPTIMIZER[optimizer], device_id, max_rows
+        cfg.recon_alpha, cfg.auxk_alpha, cfg.clip_thresh = recon_alpha, auxk_alpha, clip_thresh
+        cfg.weight_decay, cfg.beta1, cfg.beta2, cfg.eps = weight_decay, betas[0], betas[1], eps
+        self.variant, self.d, self.n, self.max_rows, self.device_id = variant, d_model, n_dict, max_rows, device_id
+        self._ctx = C.c_void_p()
+        _check(self._lib.sae_create(C.byref(cfg), C.byref(self._ctx)))
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.sae_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters ---------------------------------------------------------------------------
+    def param_shapes(self) -> Dict[str, tuple]:
+        """Reference state_dict keys and shapes, in the engine's parameter order."""
+        if self.variant == "l1":   # l1autoencoder.py:56-60
+            return {"decoder.weight": (self.d, self.n), "encoder_bias": (self.n,)}
+        return {"encoder.weight": (self.n, self.d), "encoder.bias": (self.n,),
+                "W_dec": (self.n, self.d), "b_dec": (self.d,)}   # topkautoencoder.py:62-70
+
+    def set_params(self, params: Dict[str, np.ndarray]) -> None:
+        arrs = [_np_f32(params[k]).reshape(shape) for k, shape in self.param_shapes().items()]
+        ptrs = [a.ctypes.data_as(C.c_void_p) for a in arrs] + [None] * (4 - len(arrs))
+        _check(self._lib.sae_set_params(self._ctx, *ptrs, 0))
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        out = {k: np.empty(shape, dtype=np.float32) for k, shape in self.param_shapes().items()}
+        ptrs = [a.ctypes.data_as(C.c_void_p) for a in out.values()] + [None] * (4 - len(out))
+        _check(self._lib.sae_get_params(self._ctx, *ptrs, 0))
+        return out
+
+    def set_opt_state(self, step: int, exp_avg: Dict[str, np.ndarray], exp_avg_sq: Dict[str, np.ndarray]) -> None:
+        keys = list(self.param_shapes())
+        a = [_np_f32(exp_avg[k]) for k in keys]
+        b = [_np_f32(exp_avg_sq[k]) for k in keys]
+        pa = (C.c_void_p * 4)(*([x.ctypes.data for x in a] + [None] * (4 - len(a))))
+        pb = (C.c_void_p * 4)(*([x.ctypes.data for x in b] + [None] * (4 - len(b))))
+        _check(self._lib.sae_set_opt_state(self._ctx, int(step), pa, pb, 0))
+
+    def get_opt_state(self):
+        shapes = self.param_shapes()
+        a = {k: np.empty(s, dtype=np.float32) for k, s in shapes.items()}
+        b = {k: np.empty(s, dtype=np.float32) for k, s in shapes.items()}
+        pa = (C.c_void_p * 4)(*([x.ctypes.data for x in a.values()] + [None] * (4 - len(a))))
+        pb = (C.c_void_p * 4)(*([x.ctypes.data for x in b.values()] + [None] * (4 - len(b))))
+        step = C.c_int64(0)
+        _check(self._lib.sae_get_opt_state(self._ctx, C.byref(step), pa, pb, 0))
+        return int(step.value), a, b
+
+    # -- the hot path -------------------------------------------------------------------------
+    @staticmethod
+    def _x_args(x):
+        """x: a torch CUDA tensor [M, d] (or [B, T, d]) fp32/fp16/bf16, contiguous."""
+        import torch
+        if not x.is_cuda:
+            raise EngineError("activations must live in HBM (torch CUDA tensor); there is no CPU path")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        name = {torch.float32: "float32", torch.float16: "float16", torch.bfloat16: "bfloat16"}.get(x.dtype)
+        if name is None:
+            raise EngineError(f"unsupported activation dtype {x.dtype}")
+        rows = x.numel() // x.shape[-1]
+        return x, x.data_ptr(), rows, DTYPE[name]
+
+    @staticmethod
+    def _stream(stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(s.cuda_stream)
+
+    def forward_backward(self, x, stream=None) -> None:
+        x, ptr, rows, dt = self._x_args(x)
+        _check(self._lib.sae_forward_backward(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
+        _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))
+
+    def step(self, x, lr: float, stream=None) -> None:
+        x, ptr, rows, dt = self._x_args(x)
+        _check(self._lib.sae_step(self._ctx, C.c_void_p(ptr), rows, dt, float(lr), self._stream(stream)))
+
+    def eval(self, x, stream=None) -> None:
+        x, ptr, rows, dt = self._x_args(x)
+        _check(self._lib.sae_eval(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    def metrics(self, stream=None) -> np.ndarray:
+        out = np.zeros(NUM_METRICS, dtype=np.float32)
+        _check(self._lib.sae_read_metrics(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), self._stream(stream)))
+        return out
+
+    def grad_buffer(self):
+        """(device pointer, number of floats) of the flat gradient + metrics buffer (for all-reduce)."""
+        p, n = C.c_void_p(), C.c_int64()
+        _check(self._lib.sae_grad_buffer(self._ctx, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def grad_tensor(self):
+        """The gradient buffer as a torch CUDA tensor aliasing the engine's HBM (no copy)."""
+        import torch
+        ptr, n = self.grad_buffer()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Alias(), device=f"cuda:{self.device_id}")
+
+    # -- inspection -----------------------------------------------------------------------------
+    def debug_read(self, which: int, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.float32)
+        _check(self._lib.sae_debug_read(self._ctx, which, out.ctypes.data_as(C.POINTER(C.c_float)), count))
+        return out
+
+    def profile(self, level: int) -> None:
+        _check(self._lib.sae_profile(self._ctx, level))
+
+    def kernel_times(self) -> Dict[str, tuple]:
+        n = 16
+        ms = (C.c_float * n)()
+        cnt = (C.c_int32 * n)()
+        _check(self._lib.sae_kernel_times(self._ctx, ms, cnt, n))
+        out = {}
+        for i in range(n):
+            name = self._lib.sae_kernel_name(i)
+            if name is None:
+                break
+            out[name.decode()] = (float(ms[i]), int(cnt[i]))
+        return out
+
+    def dominant_kernel(self) -> str:
+        return self._lib.sae_kernel_name(self._lib.sae_dominant_kernel(self._ctx)).decode()

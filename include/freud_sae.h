@@ -1,0 +1,146 @@
+/*
+ * freud_sae.h -- C ABI of libfreud_sae.so, the MI355X (gfx950) SAE training engine.
+ *
+ * This is the drop-in boundary for the one hot path of ksadov/FREUD that this repository
+ * replaces: the body of the training loop in src/scripts/train_sae.py:421-453
+ * (forward under autocast -> backward -> clip_grad_norm_ -> optimizer.step) together with
+ * the model arithmetic it calls (src/models/l1autoencoder.py:69-95, mse_loss :29-36;
+ * src/models/topkautoencoder.py:72-151).  The reference has no FFI of its own (it is pure
+ * PyTorch); the entry points below are what a ctypes/cffi binding added to the reference's
+ * train() would call instead of `dist_model(activations)`, `loss.backward()`,
+ * `clip_grad_norm_` and `optimizer.step()` -- see INTEGRATION.md for that stub.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "dev" is a device (HBM) pointer owned by the
+ *     caller, every pointer marked "host" is ordinary host memory;
+ *   - all calls return 0 on success, a negative code on failure; sae_last_error() then
+ *     returns a description (thread-local).  No exceptions cross the boundary;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued on it; only the calls documented as synchronising wait for the device;
+ *   - one host thread drives one context; a context is bound to one GPU;
+ *   - parameter layouts are the reference's own (row-major fp32), so checkpoints written from
+ *     sae_get_params are bit-layout compatible with the reference's state_dict:
+ *       L1   : decoder.weight W[d][n], encoder_bias b[n]            (l1autoencoder.py:56-60)
+ *       TopK : encoder.weight We[n][d], encoder.bias be[n], W_dec Wd[n][d], b_dec bd[d]
+ *                                                                  (topkautoencoder.py:62-70)
+ */
+#ifndef FREUD_SAE_H
+#define FREUD_SAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sae_ctx sae_ctx;
+
+enum { SAE_VARIANT_L1 = 0, SAE_VARIANT_TOPK = 1 };          /* train_sae.py:352-361 autoencoder_variant */
+enum { SAE_OPT_RADAM = 0, SAE_OPT_ADAM = 1 };               /* train_sae.py:374-381 optimizer           */
+enum { SAE_DTYPE_F32 = 0, SAE_DTYPE_F16 = 1, SAE_DTYPE_BF16 = 2 }; /* dtype of the activation rows x     */
+
+enum {
+  SAE_OK = 0,
+  SAE_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  SAE_ERR_HIP = -2,       /* a HIP runtime call failed                */
+  SAE_ERR_STATE = -3      /* call sequence error                      */
+};
+
+/* Mirrors the knobs of train() that reach the step (train_sae.py:297-320, 356-381) and the
+ * autoencoder_config dataclasses (src/models/config.py:5-28). */
+typedef struct sae_config {
+  int32_t variant;        /* SAE_VARIANT_*                                               */
+  int32_t d_model;        /* activation_size (feat_dim, train_sae.py:65)                 */
+  int32_t n_dict;         /* get_n_dict_components(...) (src/utils/models.py:1-6)         */
+  int32_t k;              /* TopK only: cfg.k                                            */
+  int32_t optimizer;      /* SAE_OPT_*                                                   */
+  int32_t device_id;      /* HIP device ordinal                                          */
+  int64_t max_rows;       /* largest M = batch_size*T this context will be asked to step */
+  /* hyper-parameters are doubles because the reference holds them as Python floats */
+  double recon_alpha;     /* L1 only: cfg.recon_alpha                                    */
+  double auxk_alpha;      /* TopK only: cfg.auxk_alpha                                   */
+  double clip_thresh;     /* clip_grad_norm_ max_norm (train_sae.py:449)                 */
+  double weight_decay;    /* RAdam only (train_sae.py:375-377)                           */
+  double beta1, beta2;    /* 0.9 / 0.999 (torch defaults the reference relies on)        */
+  double eps;             /* 1e-5 RAdam (train_sae.py:376), 1e-8 Adam (torch default)    */
+  int32_t reserved[8];    /* must be zero                                                */
+} sae_config;
+
+/* Metrics of the most recent sae_forward_backward / sae_eval (all fp32). */
+enum {
+  SAE_M_LOSS_RECON = 0,   /* L1: out.reconstruction_loss  (l1autoencoder.py:86)  | TopK: fvu            */
+  SAE_M_LOSS_L1 = 1,      /* L1: out.l1_loss              (l1autoencoder.py:85)  | TopK: auxk_loss      */
+  SAE_M_MSE = 2,          /* the return_mse value         (l1autoencoder.py:93-94, topk :149-150)       */
+  SAE_M_GRAD_NORM = 3,    /* total_norm returned by clip_grad_norm_ (valid after sae_optimizer_step)    */
+  SAE_M_COUNT = 4,        /* number of unmasked elements (x != -1) entering the masked MSE             */
+  SAE_M_RESERVED5 = 5,
+  SAE_M_RESERVED6 = 6,
+  SAE_M_RESERVED7 = 7,
+  SAE_NUM_METRICS = 8
+};
+
+const char* sae_last_error(void);
+int sae_version(void);
+
+/* Create / destroy.  Allocates every HBM buffer the context will ever need (no allocation
+ * happens inside the step calls, so they can be captured into a hipGraph). */
+int sae_create(const sae_config* cfg, sae_ctx** out);
+void sae_destroy(sae_ctx* ctx);
+
+/* Parameters, reference layouts (see top).  `is_device` selects host or device pointers.
+ * For L1 pass (W, b, NULL, NULL); for TopK pass (We, be, Wd, bd).  Synchronising.
+ * Replaces model.load_state_dict / model.state_dict (train_sae.py:232-251, 265-294). */
+int sae_set_params(sae_ctx* ctx, const float* p0, const float* p1, const float* p2, const float* p3, int is_device);
+int sae_get_params(sae_ctx* ctx, float* p0, float* p1, float* p2, float* p3, int is_device);
+
+/* Optimizer moments (exp_avg / exp_avg_sq per parameter, same order and layouts as the
+ * parameters) and the step counter.  Replaces optimizer.state_dict()/load_state_dict().
+ * Pointers may be NULL to skip a tensor.  Synchronising. */
+int sae_set_opt_state(sae_ctx* ctx, int64_t step, const float* const exp_avg[4], const float* const exp_avg_sq[4], int is_device);
+int sae_get_opt_state(sae_ctx* ctx, int64_t* step, float* const exp_avg[4], float* const exp_avg_sq[4], int is_device);
+
+/* Forward + backward of one batch of M activation rows x[M][d_model] (dev pointer, row-major,
+ * dtype SAE_DTYPE_*).  For L1 this is: renormalise decoder columns in place, encoder GEMM +
+ * bias + ReLU, decoder GEMM, masked MSE + L1, and the full backward into the gradient buffer
+ * (train_sae.py:429-448).  Asynchronous on `stream`. */
+int sae_forward_backward(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stream);
+
+/* The flat fp32 gradient buffer the backward fills and the optimizer consumes:
+ * [ grads of every parameter, padded | SAE_NUM_METRICS loss scalars ].  A data-parallel host
+ * all-reduces (sum) exactly this buffer between sae_forward_backward and sae_optimizer_step and
+ * passes grad_scale = 1/world_size.  Pointer is stable for the life of the context. */
+int sae_grad_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+
+/* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
+ * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
+int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream);
+
+/* Convenience: sae_forward_backward + sae_optimizer_step(lr, 1). */
+int sae_step(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, double lr, void* stream);
+
+/* Forward only (no parameter update except the in-place column renormalisation the reference's
+ * encode() also performs in eval).  Fills the metrics.  Asynchronous. */
+int sae_eval(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stream);
+
+/* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
+int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);
+
+/* Test / inspection hook: copy an internal tensor of the last step to host as fp32, un-padded.
+ * which: 0 = latent c [M][n]; 1 = x_hat-derived dx_hat [M][d]; 2 = raw gradients in reference
+ * layouts, concatenated in parameter order.  Synchronising.  Not part of the hot path. */
+int sae_debug_read(sae_ctx* ctx, int which, float* out_host, int64_t capacity_floats);
+
+/* Timing hooks for bench.py / profiling.  level 0 = off, 1 = bracket only the dominant kernel of
+ * every step with HIP events on the launch stream, 2 = bracket every kernel (diagnostic).
+ * sae_kernel_times synchronises, adds up the events recorded since the last call (at most the last
+ * 64 launches per kernel are kept) and returns per-kernel total milliseconds and launch counts for
+ * kernel ids 0..n-1 (ids: sae_kernel_name).  */
+int sae_profile(sae_ctx* ctx, int level);
+int sae_kernel_times(sae_ctx* ctx, float* ms_sum, int32_t* launches, int n);
+const char* sae_kernel_name(int id);        /* NULL past the last id */
+int sae_dominant_kernel(sae_ctx* ctx);      /* id bracketed at level 1 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREUD_SAE_H */
