@@ -46,7 +46,7 @@ def make_inputs(M, d, n, seed, dtype):
 def cpu_baseline(x, W, b, steps, lr):
     """The oracle's full train step on the host cores (same batch, same hyper-parameters)."""
     from oracle import sae_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)     # more threads than this only adds barrier overhead at these sizes
     torch.set_num_threads(cores)
     Wc, bc, st = W.clone(), b.clone(), O.OptState()
     xf = x.float()

@@ -42,33 +42,33 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }
 
 template <int MODE>
-__device__ __forceinline__ void tile_load(uint4 (&regs)[4], const bf16_t* base, int64_t ld, int t) {
+__device__ __forceinline__ void tile_load(u32x4 (&regs)[4], const bf16_t* base, int64_t ld, int t) {
   if constexpr (MODE == OP_ROW) {
     // [128 rows][64 k]: thread -> row t/8 + 32 i, 16-B chunk t%8
     const bf16_t* p = base + (int64_t)(t >> 3) * ld + (t & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(32 * i) * ld);
+    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const u32x4*>(p + (int64_t)(32 * i) * ld);
   } else {
     // [64 k][128 cols]: thread -> k row t/16 + 16 i, 16-B chunk t%16
     const bf16_t* p = base + (int64_t)(t >> 4) * ld + (t & 15) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(16 * i) * ld);
+    for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const u32x4*>(p + (int64_t)(16 * i) * ld);
   }
 }
 
 template <int MODE>
-__device__ __forceinline__ void tile_store(const uint4 (&regs)[4], char* lds, int t) {
+__device__ __forceinline__ void tile_store(const u32x4 (&regs)[4], char* lds, int t) {
   if constexpr (MODE == OP_ROW) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (t >> 3) + 32 * i, c = t & 7;
-      *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = regs[i];
+      *reinterpret_cast<u32x4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = regs[i];
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (t >> 4) + 16 * i, c = t & 15;
-      *reinterpret_cast<uint4*>(lds + r * 256 + ((c ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4)) = regs[i];
+      *reinterpret_cast<u32x4*>(lds + r * 256 + ((c ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4)) = regs[i];
     }
   }
 }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
     else return base + (int64_t)k * g.ldb + bn * GEMM_BN;
   };
 
-  uint4 ra[4], rb[4];
+  u32x4 ra[4], rb[4];
   if (kt_begin < kt_end) {
     tile_load<AMODE>(ra, a_ptr(kt_begin), g.lda, t);
     tile_load<BMODE>(rb, b_ptr(kt_begin), g.ldb, t);

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void prep_w_kernel(float* __restrict__ W, bf16
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int piece = t + 256 * it, c = piece >> 4, s = piece & 15;
-      *reinterpret_cast<uint4*>(Wt + (int64_t)(blockIdx.x * 64 + c) * d_p + i0 + s * 8) =
-          *reinterpret_cast<const uint4*>(&tT[c][s * 8]);
+      *reinterpret_cast<u32x4*>(Wt + (int64_t)(blockIdx.x * 64 + c) * d_p + i0 + s * 8) =
+          *reinterpret_cast<const u32x4*>(&tT[c][s * 8]);
     }
   }
 }

@@ -45,7 +45,8 @@ def test_l1_steps_match_reference_golden(golden_dir, name):
             assert _rel(g[d * n:], z["db_step1"]) < 5e-3
             c = eng.debug_read(0, M * n).reshape(M, n)
             # latent: engine stores bf16(c); reference c is fp32 relu(bf16(xW)+b)
-            np.testing.assert_allclose(c, z["c_step1"], rtol=1e-2, atol=2e-2 * np.abs(z["c_step1"]).max())
+            cref = z["c_step1"].reshape(M, n)
+            np.testing.assert_allclose(c, cref, rtol=1e-2, atol=2e-2 * np.abs(cref).max())
         eng.optimizer_step(lr)
         m = eng.metrics()
         tol = 1e-3 if i == 0 else 1e-2
@@ -144,7 +145,7 @@ def test_full_size_properties():
     first = eng.metrics().copy()
     assert half[4] == pytest.approx(first[4], rel=1e-6)                 # same unmasked count
     assert half[0] == pytest.approx(first[0], rel=1e-4)                 # same masked MSE
-    assert full[4] == pytest.approx(M * d, rel=1e-6)
+    assert full[4] == pytest.approx(float((x != -1.0).sum().item()), rel=1e-6)   # bf16 data does hit -1.0 exactly
     losses = []
     for _ in range(20):
         eng.step(x, 4e-4)
