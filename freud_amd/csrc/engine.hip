@@ -67,6 +67,7 @@ struct sae_ctx {
   bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
+  float* cn_part = nullptr;
   unsigned int* masked = nullptr;
   int dw_splits = 1;
   int64_t step = 0;
@@ -100,7 +101,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device_id);
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
-                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked};
+                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->ev_init)
@@ -169,7 +170,8 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->sq_part, (Mp / 128) * (c->d_p / 128) * 2 * 4);
   ALLOC(c->scal, 16 * 4);
   ALLOC(c->gn_part, 1024 * 8);
-  ALLOC(c->masked, 16);
+  ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
+  ALLOC(c->masked, 2048 * 4);
 #undef ALLOC
   hipMemset(c->P, 0, c->nparams * 4);
   hipMemset(c->Mom, 0, c->nparams * 4);
@@ -290,17 +292,21 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   float* b = c->P + c->nW;
 
   ev_begin(c, KID_PREP_W, s);
-  hipLaunchKernelGGL(prep_w_kernel, dim3(n_p / 64), dim3(256), 0, s, W, c->Wb, c->Wt, d_p, n_p);
+  hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 64, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
+  hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
+                     c->Wt, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
   ev_begin(c, KID_PREP_X, s);
-  HIP_TRY(hipMemsetAsync(c->masked, 0, 16, s));
   {
     const int64_t chunks = Mp * (d_p / 8);
     int grid = (int)((chunks + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(prep_x_kernel<T>, dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
-    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c->masked, c->scal, M, d, alpha);
+    if (grid > 2048) grid = 2048;
+    if (d % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+      hipLaunchKernelGGL((prep_x_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
+    else
+      hipLaunchKernelGGL((prep_x_kernel<T, false>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
+    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha);
   }
   ev_end(c, KID_PREP_X, s);
 
@@ -370,12 +376,12 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       const int64_t n4 = c->nW / 4;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
                          splits);
-      hipLaunchKernelGGL(reduce_db_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->db_part, c->G + c->nW,
+      hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, c->G + c->nW,
                          (int)(Mp / 128), n_p);
     }
     ev_end(c, KID_REDUCE, s);
   }
-  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
+  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
                      c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha);
   ev_end(c, KID_STEP_TOTAL, s);
   HIP_TRY(hipGetLastError());

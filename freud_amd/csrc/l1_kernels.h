@@ -7,40 +7,58 @@
 // ------------------------------------------------------------------------------------------
 // prep_w: W <- W / max(||W[:,j]||_2, 1e-12) in place (l1autoencoder.py:71-73), and the two bf16
 // GEMM operand copies: Wb[d_p][n_p] (K = n contiguous, decoder) and Wt[n_p][d_p] (K = d contiguous,
-// encoder / dc).  One block = 64 dictionary columns x all rows.
+// encoder / dc).  Phase 1: per-column sums of squares over 32-row slabs (fixed order ->
+// deterministic); phase 2: 64x64 tiles normalise, cast and transpose through LDS.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_w_kernel(float* __restrict__ W, bf16_t* __restrict__ Wb,
-                                                      bf16_t* __restrict__ Wt, int d_p, int n_p) {
+__global__ __launch_bounds__(256) void colnorm_partial_kernel(const float* __restrict__ W, float* __restrict__ part,
+                                                               int n_p) {
+  // grid (n_p/64, d_p/32); thread -> column tx, rows ty, ty+4, ... of the 32-row slab
   __shared__ float red[4][64];
-  __shared__ __attribute__((aligned(16))) bf16_t tT[64][136];
   const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-  const int col = blockIdx.x * 64 + tx;
+  const int col = blockIdx.x * 64 + tx, r0 = blockIdx.y * 32;
   float ss = 0.f;
-  for (int i = ty; i < d_p; i += 4) {
-    const float v = W[(int64_t)i * n_p + col];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = W[(int64_t)(r0 + ty + 4 * i) * n_p + col];
     ss += v * v;
   }
   red[ty][tx] = ss;
   __syncthreads();
-  const float denom = fmaxf(sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]), 1e-12f);
-  for (int i0 = 0; i0 < d_p; i0 += 128) {
-    __syncthreads();
-    for (int i = ty; i < 128; i += 4) {
-      const int64_t o = (int64_t)(i0 + i) * n_p + col;
-      const float v = W[o] / denom;
-      W[o] = v;
-      const bf16_t b = (bf16_t)v;
-      Wb[o] = b;
-      tT[tx][i] = b;
-    }
-    __syncthreads();
-    // 64 columns x 128 rows -> Wt[col][i0 .. i0+128): 16 pieces of 16 B per column
+  if (ty == 0) part[(int64_t)blockIdx.y * n_p + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void normalize_cast_kernel(float* __restrict__ W, const float* __restrict__ part,
+                                                              int nslab, bf16_t* __restrict__ Wb,
+                                                              bf16_t* __restrict__ Wt, int d_p, int n_p) {
+  // grid (n_p/64, d_p/64): one 64x64 tile
+  __shared__ float denom_s[64];
+  __shared__ __attribute__((aligned(16))) bf16_t tT[64][72];
+  const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+  const int col = blockIdx.x * 64 + tx, r0 = blockIdx.y * 64;
+  if (ty == 0) {
+    float ss = 0.f;
+    for (int i = 0; i < nslab; ++i) ss += part[(int64_t)i * n_p + col];
+    denom_s[tx] = fmaxf(sqrtf(ss), 1e-12f);
+  }
+  __syncthreads();
+  const float denom = denom_s[tx];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int piece = t + 256 * it, c = piece >> 4, s = piece & 15;
-      *reinterpret_cast<u32x4*>(Wt + (int64_t)(blockIdx.x * 64 + c) * d_p + i0 + s * 8) =
-          *reinterpret_cast<const u32x4*>(&tT[c][s * 8]);
-    }
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    const int64_t o = (int64_t)(r0 + r) * n_p + col;
+    const float v = W[o] / denom;
+    W[o] = v;
+    const bf16_t b = (bf16_t)v;
+    Wb[o] = b;
+    tT[tx][r] = b;
+  }
+  __syncthreads();
+  // 64 columns x 64 rows -> Wt[col][r0 .. r0+64): 8 pieces of 16 B per column, 512 pieces
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int piece = t + 256 * it, c = piece >> 3, sgm = piece & 7;
+    *reinterpret_cast<u32x4*>(Wt + (int64_t)(blockIdx.x * 64 + c) * d_p + r0 + sgm * 8) =
+        *reinterpret_cast<const u32x4*>(&tT[c][sgm * 8]);
   }
 }
 
@@ -51,39 +69,68 @@ __global__ __launch_bounds__(256) void prep_w_kernel(float* __restrict__ W, bf16
 template <typename T>
 __device__ __forceinline__ float load_as_float(const T* p) { return (float)*p; }
 
-template <typename T>
+template <typename T> struct Vec8;
+template <> struct Vec8<float> { typedef __attribute__((ext_vector_type(8))) float type; };
+template <> struct Vec8<_Float16> { typedef __attribute__((ext_vector_type(8))) _Float16 type; };
+template <> struct Vec8<bf16_t> { typedef bf16x8 type; };
+
+// VEC: d % 8 == 0 and x 16-B aligned -> one vector load per 8 elements.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void prep_x_kernel(const T* __restrict__ x, bf16_t* __restrict__ xb,
                                                       unsigned int* __restrict__ masked_count, int64_t M, int d,
                                                       int64_t M_p, int d_p) {
-  const int chunks_per_row = d_p >> 3;
-  const int64_t total = M_p * chunks_per_row;
+  const unsigned int chunks_per_row = (unsigned int)d_p >> 3;
+  const unsigned int total = (unsigned int)(M_p * chunks_per_row);   // host guarantees < 2^32
   unsigned int masked = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  __shared__ unsigned int red[4];
+  for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int64_t row = i / chunks_per_row;
-    const int c0 = (int)(i - row * chunks_per_row) * 8;
+    const int c0 = (int)(i - (unsigned int)row * chunks_per_row) * 8;
     bf16x8 o;
+    if (VEC && row < M && c0 + 8 <= d) {
+      const typename Vec8<T>::type v = *reinterpret_cast<const typename Vec8<T>::type*>(x + row * d + c0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = 0.f;
-      if (row < M && c0 + j < d) {
-        v = load_as_float(x + row * d + c0 + j);
-        masked += (v == -1.0f);
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        masked += (f == -1.0f);
+        o[j] = (bf16_t)f;
       }
-      o[j] = (bf16_t)v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (row < M && c0 + j < d) {
+          v = load_as_float(x + row * d + c0 + j);
+          masked += (v == -1.0f);
+        }
+        o[j] = (bf16_t)v;
+      }
     }
     *reinterpret_cast<bf16x8*>(xb + row * d_p + c0) = o;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) masked += (unsigned int)__shfl_xor((int)masked, o, 64);
-  if ((threadIdx.x & 63) == 0 && masked) atomicAdd(masked_count, masked);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = masked;
+  __syncthreads();
+  if (threadIdx.x == 0) masked_count[blockIdx.x] = red[0] + red[1] + red[2] + red[3];   // per-block partial, no atomics
 }
 
 // scal[0] = count of unmasked entries, scal[1] = alpha/count (d loss / d squared-error term), scal[2] = 1/M
-__global__ void finalize_count_kernel(const unsigned int* masked_count, float* scal, int64_t M, int d, float alpha) {
-  const double count = (double)M * d - (double)*masked_count;
-  scal[0] = (float)count;
-  scal[1] = alpha / (float)count;
-  scal[2] = 1.0f / (float)M;
+__global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int* masked_part, int nparts, float* scal,
+                                                              int64_t M, int d, float alpha) {
+  __shared__ unsigned int red[4];
+  unsigned int m = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) m += masked_part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m += (unsigned int)__shfl_xor((int)m, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double count = (double)M * d - (double)(red[0] + red[1] + red[2] + red[3]);
+    scal[0] = (float)count;
+    scal[1] = alpha / (float)count;
+    scal[2] = 1.0f / (float)M;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -232,25 +279,38 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   reinterpret_cast<f32x4*>(grad)[i] = a;
 }
 
-// db[j] = sum over row tiles of db_part[tile][j]
+// db[j] = sum over row tiles of db_part[tile][j]; block = 32 columns x 8 row lanes (fixed order)
 __global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict__ part, float* __restrict__ db, int nbm,
                                                          int n_p) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_p) return;
-  float s = 0.f;
-  for (int i = 0; i < nbm; ++i) s += part[(int64_t)i * n_p + j];
-  db[j] = s;
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  int i = ty;
+  for (; i + 8 < nbm; i += 16) {
+    s0 += part[(int64_t)i * n_p + j];
+    s1 += part[(int64_t)(i + 8) * n_p + j];
+  }
+  if (i < nbm) s0 += part[(int64_t)i * n_p + j];
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][tx];
+    db[j] = s;
+  }
 }
 
 // One block: loss scalars from the per-tile partials (double accumulation, fixed order -> deterministic).
 // metrics: [0]=alpha*sq/count  [1]=l1_sum/M  [2]=plain_sq/(M*d)  [4]=count
-__global__ __launch_bounds__(256) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
-                                                               int n_sq, const float* scal, float* metrics, int64_t M,
-                                                               int d, float alpha) {
-  __shared__ double red[3][4];
+__global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
+                                                                int n_sq, const float* scal, float* metrics, int64_t M,
+                                                                int d, float alpha) {
+  __shared__ double red[3][16];
   double a = 0, b = 0, c = 0;
-  for (int i = threadIdx.x; i < n_l1; i += 256) a += (double)l1_part[i];
-  for (int i = threadIdx.x; i < n_sq; i += 256) {
+  for (int i = threadIdx.x; i < n_l1; i += 1024) a += (double)l1_part[i];
+  for (int i = threadIdx.x; i < n_sq; i += 1024) {
     b += (double)sq_part[2 * i];
     c += (double)sq_part[2 * i + 1];
   }
@@ -264,9 +324,12 @@ __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* l1_pa
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double l1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const double sq = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const double pl = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    double l1 = 0, sq = 0, pl = 0;
+    for (int k = 0; k < 16; ++k) {
+      l1 += red[0][k];
+      sq += red[1][k];
+      pl += red[2][k];
+    }
     const double count = (double)scal[0];
     metrics[0] = (float)((double)alpha * (sq / count));
     metrics[1] = (float)(l1 / (double)M);
