@@ -493,6 +493,26 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
   return fail(SAE_ERR_INVALID, "unknown debug tensor %d", which);
 }
 
+extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, void* stream) {
+  if (!c || !out_host) return fail(SAE_ERR_INVALID, "null argument");
+  if (capacity < c->n) return fail(SAE_ERR_INVALID, "capacity too small");
+  if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  hipStream_t s = (hipStream_t)stream;
+  int* bits = reinterpret_cast<int*>(c->db_part);   // scratch, free outside of a backward pass
+  HIP_TRY(hipMemsetAsync(bits, 0, (size_t)c->n_p * 4, s));
+  const int rows_per_block = 256;
+  dim3 grid(c->n_p / 128 / 2 > 0 ? c->n_p / 256 : 1, (unsigned)((c->last_M + rows_per_block - 1) / rows_per_block));
+  if (c->n_p % 256 != 0) grid.x = (c->n_p + 255) / 256;
+  hipLaunchKernelGGL(latent_colmax_kernel, grid, dim3(256), 0, s, c->c, bits, c->last_M, c->n_p, rows_per_block);
+  HIP_TRY(hipGetLastError());
+  std::vector<float> tmp(c->n_p);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), bits, (size_t)c->n_p * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  memcpy(out_host, tmp.data(), (size_t)c->n * 4);
+  return SAE_OK;
+}
+
 extern "C" int sae_profile(sae_ctx* c, int level) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device_id));

@@ -355,6 +355,18 @@ __global__ __launch_bounds__(256) void gnorm_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// per-feature max over rows of the (non-negative) latent c[M_p][n_p]  (validate(): train_sae.py:176-178)
+__global__ __launch_bounds__(256) void latent_colmax_kernel(const bf16_t* __restrict__ c, int* __restrict__ out_bits,
+                                                             int64_t M, int n_p, int rows_per_block) {
+  // grid (n_p/256, ceil(M/rows_per_block)); thread -> one column; non-negative floats order like ints
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float m = 0.f;
+  for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, (float)c[r * n_p + col]);
+  atomicMax(out_bits + col, __float_as_int(m));
+}
+
 struct OptArgs {
   float lr, grad_scale, clip_thresh, weight_decay;
   float beta1, beta2, eps;
@@ -380,7 +392,14 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
   __syncthreads();
   const float total = sqrtf((float)(red[0] + red[1] + red[2] + red[3]));
   const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
-  if (blockIdx.x == 0 && threadIdx.x == 0) metrics[3] = total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    metrics[3] = total;
+    if (a.grad_scale != 1.0f) {   // after a data-parallel sum the loss scalars become means over ranks
+      metrics[0] *= a.grad_scale;
+      metrics[1] *= a.grad_scale;
+      metrics[2] *= a.grad_scale;
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 g = reinterpret_cast<const f32x4*>(grad)[i];
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];

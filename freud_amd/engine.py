@@ -80,6 +80,7 @@ def load() -> C.CDLL:
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_read_metrics": (C.c_int, [vp, fptr, vp]),
+        "sae_latent_colmax": (C.c_int, [vp, fptr, i64, vp]),
         "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
         "sae_profile": (C.c_int, [vp, C.c_int]),
         "sae_kernel_times": (C.c_int, [vp, fptr, C.POINTER(i32), C.c_int]),
@@ -97,7 +98,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
-    "sae_step", "sae_eval", "sae_read_metrics", "sae_debug_read", "sae_profile", "sae_kernel_times",
+    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
 
@@ -221,6 +222,12 @@ class SaeEngine:
     def metrics(self, stream=None) -> np.ndarray:
         out = np.zeros(NUM_METRICS, dtype=np.float32)
         _check(self._lib.sae_read_metrics(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), self._stream(stream)))
+        return out
+
+    def latent_colmax(self, stream=None) -> np.ndarray:
+        """max over rows of |latent| per dictionary feature for the last forward (validate())."""
+        out = np.empty(self.n, dtype=np.float32)
+        _check(self._lib.sae_latent_colmax(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), self.n, self._stream(stream)))
         return out
 
     def grad_buffer(self):

@@ -1,0 +1,187 @@
+"""Activation-shard loader: the from_disk=true path of the reference
+(src/dataset/activations.py:116-206, MemoryMappedActivationsDataset / MemoryMappedActivationDataLoader)
+rebuilt as a host -> pinned -> HBM double-buffered streamer.
+
+On-disk format (written by the reference's collector, src/scripts/collect_activations.py:12-63):
+  <dir>/<layer>_tensors.npy     NPY, C-order, shape [n_files, T*d], fp32 or fp16
+  <dir>/<layer>_metadata.json   {"tensor_shape": [T, d], "activation_shape": [T, d], "filenames": [...]}
+
+Batch order: identical to torch's DataLoader(shuffle=True, drop_last=True) under the same global
+RNG state (train_sae.py:321-334): one int64 draw for the iterator's base seed, one for the
+RandomSampler seed, then randperm -- pinned by tests/golden/sampler_order.json.
+Data-parallel: every rank draws the same epoch permutation and takes perm[rank::world]
+(SURVEY.md section 8e); per-rank batch_size stays the config value.
+
+Pipeline per rank: a worker thread gathers the next batch's rows from the memory map into one of
+`depth` pinned host buffers; the consumer issues the H2D copy on a dedicated copy stream into the
+matching HBM buffer and makes the compute stream wait on its event, so the copy of batch i+1
+overlaps the train step of batch i.
+"""
+from __future__ import annotations
+
+import json
+import os
+import queue
+import threading
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+class MemoryMappedActivationsDataset:
+    """dataset/activations.py:116-174 (tensor-type shards only; 'indexed' SAE-feature shards are
+    not consumed by training)."""
+
+    def __init__(self, data_path: str, layer_name: str, subset_size: Optional[int] = None):
+        self.data_path, self.layer_name = data_path, layer_name
+        self.metadata_file = os.path.join(data_path, f"{layer_name}_metadata.json")
+        with open(self.metadata_file, "r") as f:
+            self.metadata = json.load(f)
+        self.tensor_file = os.path.join(data_path, f"{layer_name}_tensors.npy")
+        if not os.path.exists(self.tensor_file):
+            raise FileNotFoundError(
+                f"{self.tensor_file} not found (SAE-encoded 'indexed' shards cannot be trained on)")
+        self.activation_type = "tensor"
+        self.mmap = np.load(self.tensor_file, mmap_mode="r")
+        if subset_size is not None:
+            self.metadata["filenames"] = self.metadata["filenames"][:subset_size]
+            self.mmap = self.mmap[:subset_size]
+        self.activation_shape = self.metadata["activation_shape"]
+        self.tensor_shape = list(self.metadata["tensor_shape"])
+        if self.mmap.shape[0] < len(self.metadata["filenames"]):
+            raise ValueError("metadata lists more files than the tensor file holds")
+
+    def __len__(self) -> int:
+        return len(self.metadata["filenames"])
+
+    def __getitem__(self, idx: int):
+        return torch.from_numpy(np.array(self.mmap[idx]).reshape(self.tensor_shape)), self.metadata["filenames"][idx]
+
+
+class MemoryMappedActivationDataLoader:
+    """dataset/activations.py:177-206 with the same constructor arguments, plus device / rank / world."""
+
+    def __init__(self, data_path: str, layer_name: str, batch_size: int, dl_max_workers: int = 0,
+                 subset_size: Optional[int] = None, dl_kwargs: Optional[dict] = None, *,
+                 device: torch.device | str = "cpu", rank: int = 0, world_size: int = 1, depth: int = 2):
+        dl_kwargs = dict(dl_kwargs or {})
+        self._dataset = MemoryMappedActivationsDataset(data_path, layer_name, subset_size)
+        self.dataset = self._dataset
+        self.batch_size = batch_size
+        self.shuffle = bool(dl_kwargs.get("shuffle", False))
+        self.drop_last = bool(dl_kwargs.get("drop_last", False))
+        self.activation_shape = self._dataset.activation_shape
+        self.activation_type = self._dataset.activation_type
+        self.dataset_length = len(self._dataset)
+        self.device = torch.device(device)
+        self.rank, self.world_size, self.depth = rank, world_size, max(2, depth)
+        self.dl_max_workers = dl_max_workers
+
+    def __len__(self) -> int:   # reference quirk kept: floor division even without drop_last (:205-206)
+        return (len(self._dataset) // self.world_size) // self.batch_size
+
+    # -- batch order ---------------------------------------------------------------------------
+    def epoch_batches(self) -> List[List[int]]:
+        """File indices of every batch of one epoch for this rank (consumes the global torch RNG
+        exactly as a fresh DataLoader iterator does)."""
+        n = len(self._dataset)
+        _base_seed = torch.empty((), dtype=torch.int64).random_().item()  # DataLoader iterator's base seed draw
+        if self.shuffle:
+            order = list(torch.utils.data.RandomSampler(range(n)))
+        else:
+            order = list(range(n))
+        if self.world_size > 1:
+            order = order[self.rank::self.world_size][: n // self.world_size]
+        batches = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if batches and len(batches[-1]) < self.batch_size and self.drop_last:
+            batches.pop()
+        return batches
+
+    # -- iteration -------------------------------------------------------------------------------
+    def _gather(self, idxs: Sequence[int], out: np.ndarray) -> None:
+        mm = self._dataset.mmap
+        for j, i in enumerate(idxs):
+            out[j] = mm[i]
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, List[str]]]:
+        batches = self.epoch_batches()
+        T, d = self._dataset.tensor_shape[-2], self._dataset.tensor_shape[-1]
+        names = self._dataset.metadata["filenames"]
+        np_dtype = self._dataset.mmap.dtype
+        if self.device.type != "cuda":
+            for idxs in batches:
+                buf = np.empty((len(idxs), T * d), dtype=np_dtype)
+                self._gather(idxs, buf)
+                yield torch.from_numpy(buf).reshape(len(idxs), T, d), [names[i] for i in idxs]
+            return
+        yield from self._iter_cuda(batches, T, d, names, np_dtype)
+
+    def _iter_cuda(self, batches, T, d, names, np_dtype):
+        B, depth, dev = self.batch_size, self.depth, self.device
+        tdtype = torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+        pinned = [torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)]
+        hbm = [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)]
+        free = [threading.Semaphore(1) for _ in range(depth)]
+        ready: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
+
+        def worker():
+            try:
+                for bi, idxs in enumerate(batches):
+                    slot = bi % depth
+                    while not free[slot].acquire(timeout=0.1):
+                        if stop.is_set():
+                            return
+                    self._gather(idxs, pinned[slot].numpy()[: len(idxs)])
+                    ready.put((slot, idxs))
+                ready.put(None)
+            except BaseException as e:  # surface loader errors in the training thread
+                ready.put(e)
+
+        th = threading.Thread(target=worker, name="shard-gather", daemon=True)
+        th.start()
+        copy_stream = torch.cuda.Stream(device=dev)
+        consumed = [None] * depth   # compute-stream event: batch in hbm[slot] fully enqueued
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                slot, idxs = item
+                compute = torch.cuda.current_stream(dev)
+                with torch.cuda.stream(copy_stream):
+                    if consumed[slot] is not None:
+                        copy_stream.wait_event(consumed[slot])
+                    hbm[slot][: len(idxs)].copy_(pinned[slot][: len(idxs)], non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record(copy_stream)
+                compute.wait_event(landed)
+                landed.synchronize()          # pinned[slot] may be refilled once the DMA has read it
+                free[slot].release()
+                yield hbm[slot][: len(idxs)].view(len(idxs), T, d), [names[i] for i in idxs]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                consumed[slot] = ev
+        finally:
+            stop.set()
+            th.join(timeout=5)
+
+
+def write_shards(folder: str, layer_name: str, rows: np.ndarray, tensor_shape: Sequence[int],
+                 filenames: Optional[Sequence[str]] = None) -> None:
+    """Write a shard directory byte-compatible with what collect_activations.py:12-63 produces
+    (one [1, T*d] row per file, standard NPY header, C order) -- SURVEY.md section 8f row f2."""
+    os.makedirs(folder, exist_ok=True)
+    rows = np.ascontiguousarray(rows)
+    n_files = rows.shape[0]
+    T, d = int(tensor_shape[-2]), int(tensor_shape[-1])
+    if rows.reshape(n_files, -1).shape[1] != T * d:
+        raise ValueError(f"All tensors must have the same shape as the first tensor. Expected {[T, d]}")
+    np.save(os.path.join(folder, f"{layer_name}_tensors.npy"), rows.reshape(n_files, T * d))
+    meta = {"tensor_shape": [T, d], "activation_shape": [T, d],
+            "filenames": list(filenames) if filenames is not None else [f"file_{i:06d}.flac" for i in range(n_files)]}
+    with open(os.path.join(folder, f"{layer_name}_metadata.json"), "w") as f:
+        json.dump(meta, f)

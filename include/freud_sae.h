@@ -125,6 +125,11 @@ int sae_eval(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stre
 /* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
 int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);
 
+/* Per-dictionary-feature maximum of |latent| over the M rows of the last forward
+ * (torch.max(torch.abs(latent), dim=0) in validate(), train_sae.py:176-178) -> out_host[n_dict].
+ * Synchronises `stream`. */
+int sae_latent_colmax(sae_ctx* ctx, float* out_host, int64_t capacity_floats, void* stream);
+
 /* Test / inspection hook: copy an internal tensor of the last step to host as fp32, un-padded.
  * which: 0 = latent c [M][n]; 1 = x_hat-derived dx_hat [M][d]; 2 = raw gradients in reference
  * layouts, concatenated in parameter order.  Synchronising.  Not part of the hot path. */

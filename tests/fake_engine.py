@@ -1,0 +1,126 @@
+"""Oracle-backed stand-in for freud_amd.engine.SaeEngine, for CPU tests of the HOST logic only
+(train loop sequencing, checkpoints, loader order, data-parallel all-reduce).  Lives under tests/:
+the product never imports it, and it is never the thing measured."""
+import numpy as np
+import torch
+
+from oracle import sae_oracle as O
+
+
+class OracleEngine:
+    def __init__(self, variant, d_model, n_dict, max_rows, *, optimizer="radam", recon_alpha=1.0, k=0, auxk_alpha=0.0,
+                 clip_thresh=1.0, weight_decay=0.0, device_id=0, **_):
+        self.variant, self.d, self.n, self.max_rows = variant, d_model, n_dict, max_rows
+        self.optimizer, self.recon_alpha, self.k, self.auxk_alpha = optimizer, recon_alpha, k, auxk_alpha
+        self.clip_thresh, self.weight_decay = clip_thresh, weight_decay
+        self.st = O.OptState()
+        self.P = {}
+        self.dead_threshold = None
+        self.nfsf = torch.zeros(n_dict, dtype=torch.long)
+        nflat = sum(int(np.prod(s)) for s in self.param_shapes().values())
+        self.flat = torch.zeros(nflat + 8)
+        self._latent = None
+
+    def param_shapes(self):
+        if self.variant == "l1":
+            return {"decoder.weight": (self.d, self.n), "encoder_bias": (self.n,)}
+        return {"encoder.weight": (self.n, self.d), "encoder.bias": (self.n,), "W_dec": (self.n, self.d), "b_dec": (self.d,)}
+
+    def set_dead_feature_threshold(self, v):
+        self.dead_threshold = v
+
+    def set_params(self, params):
+        self.P = {k: torch.tensor(np.asarray(params[k], dtype=np.float32)).reshape(s).clone()
+                  for k, s in self.param_shapes().items()}
+
+    def get_params(self):
+        return {k: v.numpy().copy() for k, v in self.P.items()}
+
+    def set_opt_state(self, step, exp_avg, exp_avg_sq):
+        self.st.step = int(step)
+        self.st.exp_avg = {k: torch.tensor(np.asarray(exp_avg[k])).clone() for k in self.param_shapes()}
+        self.st.exp_avg_sq = {k: torch.tensor(np.asarray(exp_avg_sq[k])).clone() for k in self.param_shapes()}
+
+    def get_opt_state(self):
+        z = {k: np.zeros(s, np.float32) for k, s in self.param_shapes().items()}
+        m1 = {k: self.st.exp_avg[k].numpy().copy() if k in self.st.exp_avg else z[k] for k in z}
+        m2 = {k: self.st.exp_avg_sq[k].numpy().copy() if k in self.st.exp_avg_sq else z[k] for k in z}
+        return self.st.step, m1, m2
+
+    def grad_tensor(self):
+        return self.flat
+
+    def _pack(self, grads, metrics):
+        off = 0
+        for k in self.param_shapes():
+            g = grads[k].reshape(-1)
+            self.flat[off:off + g.numel()] = g
+            off += g.numel()
+        self.flat[off:off + 8] = torch.tensor(metrics + [0.0] * (8 - len(metrics)))
+
+    def forward_backward(self, x, stream=None):
+        x = x.detach().cpu()
+        if self.variant == "l1":
+            W, b = self.P["decoder.weight"], self.P["encoder_bias"]
+            W.copy_(O.normalize_columns(W))
+            xf = x.reshape(-1, self.d).float()
+            f = O.l1_forward(xf, W, b, self.recon_alpha, True)
+            dW, db = O.l1_backward(xf, W, b, f, self.recon_alpha, True)
+            self._latent = f["c"]
+            self._pack({"decoder.weight": dW, "encoder_bias": db},
+                       [f["reconstruction_loss"].item(), f["l1_loss"].item(), f["mse"].item(), 0.0, float(f["count"])])
+        else:
+            P = self.P
+            dead = self.nfsf > self.dead_threshold
+            f = O.topk_forward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], self.k, dead,
+                               self.auxk_alpha, True)
+            g = O.topk_backward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], f,
+                                self.auxk_alpha, True)
+            did = torch.zeros(self.n, dtype=torch.bool)
+            did[f["top_indices"].flatten()] = True
+            self.nfsf += x.shape[0] * x.shape[1]
+            self.nfsf[did] = 0
+            self._latent = f["dense"].float()
+            self._pack({"encoder.weight": g["W_enc"], "encoder.bias": g["b_enc"], "W_dec": g["W_dec"], "b_dec": g["b_dec"]},
+                       [f["fvu"].item(), f["auxk_loss"].item(), f["mse"].item(), 0.0, 0.0, float(dead.float().mean())])
+
+    def optimizer_step(self, lr, grad_scale=1.0, stream=None):
+        off, grads = 0, {}
+        for k, s in self.param_shapes().items():
+            n = int(np.prod(s))
+            grads[k] = (self.flat[off:off + n] * grad_scale).reshape(s).clone()
+            off += n
+        order = ["encoder_bias", "decoder.weight"] if self.variant == "l1" else ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]
+        gn, clipped = O.clip_grad_norm([grads[k] for k in order], self.clip_thresh)
+        cg = dict(zip(order, clipped))
+        params = {k: self.P[k] for k in order}
+        if self.optimizer == "radam":
+            O.radam_step(params, cg, self.st, lr, eps=1e-5, weight_decay=self.weight_decay)
+        else:
+            O.adam_step(params, cg, self.st, lr)
+        self.flat[off + 3] = gn
+        if grad_scale != 1.0:
+            self.flat[off:off + 3] *= grad_scale
+
+    def step(self, x, lr, stream=None):
+        self.forward_backward(x)
+        self.optimizer_step(lr, 1.0)
+
+    def eval(self, x, stream=None):
+        x = x.detach().cpu()
+        W, b = self.P["decoder.weight"], self.P["encoder_bias"]
+        W.copy_(O.normalize_columns(W))
+        f = O.l1_forward(x.reshape(-1, self.d).float(), W, b, self.recon_alpha, True)
+        self._latent = f["c"]
+        off = self.flat.numel() - 8
+        self.flat[off:off + 5] = torch.tensor([f["reconstruction_loss"].item(), f["l1_loss"].item(), f["mse"].item(), 0.0,
+                                               float(f["count"])])
+
+    def metrics(self, stream=None):
+        return self.flat[-8:].numpy().copy()
+
+    def latent_colmax(self, stream=None):
+        return self._latent.abs().reshape(-1, self.n).max(0).values.numpy()
+
+    def close(self):
+        pass

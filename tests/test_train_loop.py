@@ -1,0 +1,137 @@
+"""CPU: host orchestration of freud_amd.train_sae.train() against the reference's own train()
+(golden fixture trainloop_*.npz produced by tests/golden/make_golden.py), with the oracle-backed
+engine stand-in from tests/fake_engine.py in place of the HIP engine.  Pins: RNG consumption /
+batch order, LR schedule timing, logging tags, checkpoint file names, keys and contents, resume."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from freud_amd.loader import write_shards
+from freud_amd.train_sae import train, lr_at
+from tests.fake_engine import OracleEngine
+
+
+def _setup(tmp_path, golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    meta = json.loads(str(z["meta"]))
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, meta["layer"], z["shard"], [meta["T"], meta["d"]],
+                 [f"/data/audio/file_{i:04d}.flac" for i in range(meta["n_files"])])
+    cfg = copy.deepcopy(meta["config"])
+    cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run"), device="cpu")
+    return z, meta, cfg
+
+
+def _scalars(run_dir):
+    return [json.loads(l) for l in open(os.path.join(run_dir, "metrics.jsonl"))]
+
+
+def test_l1_train_loop_matches_reference(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
+    train(**cfg, engine_factory=OracleEngine)
+    ck_dir = os.path.join(cfg["run_dir"], "checkpoints")
+    assert sorted(os.listdir(ck_dir)) == meta["checkpoint_files"]        # step{save_every}, epoch ends, final
+    got = {(s["tag"], s["step"]): s["value"] for s in _scalars(cfg["run_dir"])}
+    for tag, val, step in meta["scalars"]:
+        assert (tag, step) in got, (tag, step)
+        assert got[(tag, step)] == pytest.approx(val, rel=2e-6, abs=1e-12), (tag, step)
+    ck = torch.load(os.path.join(ck_dir, "step7.pth"), map_location="cpu", weights_only=True)   # plain containers only
+    assert sorted(ck.keys()) == meta["checkpoint_keys"]
+    assert list(ck["model"].keys()) == meta["model_keys"]
+    assert ck["step"] == meta["step"] and ck["best_val_loss"] == meta["best_val_loss"]
+    hp = dict(meta["hparams"])
+    hp.update(train_folder=cfg["train_folder"], val_folder=cfg["val_folder"])
+    assert ck["hparams"] == hp
+    for k in meta["model_keys"]:
+        torch.testing.assert_close(ck["model"][k], torch.tensor(z[f"model__{k}"]), rtol=0, atol=2e-7)
+    assert sorted(ck["scheduler"].keys()) == meta["scheduler_keys"]
+    ref_groups = meta["opt_param_groups"][0]
+    assert set(ck["optimizer"]["param_groups"][0].keys()) == set(ref_groups.keys())
+    for k, v in ref_groups.items():
+        got_v = ck["optimizer"]["param_groups"][0][k]
+        if isinstance(v, float):
+            assert got_v == pytest.approx(v, rel=1e-9, abs=1e-15), k
+        else:
+            assert got_v == v or list(got_v) == list(v), k
+    for pid in (0, 1):
+        st = ck["optimizer"]["state"][pid]
+        assert float(st["step"]) == float(z[f"opt__{pid}__step"])
+        np.testing.assert_allclose(st["exp_avg"].numpy(), z[f"opt__{pid}__exp_avg"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(st["exp_avg_sq"].numpy(), z[f"opt__{pid}__exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+def test_checkpoint_consumed_by_reference_key_logic(tmp_path, golden_dir):
+    """init_sae_from_checkpoint (src/dataset/activations.py:16-31) reads hparams.activation_size,
+    hparams.autoencoder_variant, hparams.autoencoder_config and model: restate that key logic."""
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
+    train(**cfg, engine_factory=OracleEngine)
+    ck = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step4.pth"), map_location="cpu")
+    d = ck["hparams"]["activation_size"]
+    assert ck["hparams"]["autoencoder_variant"] == "l1"
+    n = ck["hparams"]["autoencoder_config"]["n_dict_components"]
+    lin = torch.nn.Linear(n, d, bias=False)
+    lin.load_state_dict({"weight": ck["model"]["decoder.weight"]})
+    assert ck["model"]["encoder_bias"].shape == (n,)
+
+
+def test_resume_from_checkpoint_continues_identically(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
+    train(**cfg, engine_factory=OracleEngine)
+    full = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    cfg2 = dict(cfg, run_dir=os.path.join(str(tmp_path), "run2"),
+                start_checkpoint=os.path.join(cfg["run_dir"], "checkpoints", "step4.pth"))
+    st = train(**cfg2, engine_factory=OracleEngine)
+    assert st["step"] == 7
+    # like the reference, resume restores model/optimizer/step but not the loader position or RNG,
+    # so the continued run sees different batches: parameters stay finite and the step counter,
+    # optimizer step and LR schedule line up.
+    ck = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    assert float(ck["optimizer"]["state"][0]["step"]) == 7.0
+    assert ck["scheduler"]["last_epoch"] == 7 == full["scheduler"]["last_epoch"]
+    assert ck["scheduler"]["_last_lr"][0] == pytest.approx(full["scheduler"]["_last_lr"][0], rel=1e-12)
+    assert all(torch.isfinite(v).all() for v in ck["model"].values())
+
+
+def test_error_conventions(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
+    with pytest.raises(TypeError):
+        train(**{k: v for k, v in cfg.items() if k != "clip_thresh"}, engine_factory=OracleEngine)
+    with pytest.raises(TypeError):
+        train(**cfg, not_a_key=1, engine_factory=OracleEngine)
+    with pytest.raises(AssertionError, match="Invalid autoencoder variant"):
+        train(**dict(cfg, autoencoder_variant="vae"), engine_factory=OracleEngine)
+    with pytest.raises(ValueError, match="Invalid optimizer"):
+        train(**dict(cfg, optimizer="sgd"), engine_factory=OracleEngine)
+    with pytest.raises(ValueError, match="Invalid scheduler"):
+        train(**dict(cfg, scheduler="step"), engine_factory=OracleEngine)
+    with pytest.raises(KeyError):
+        train(**dict(cfg, scheduler="linear", scheduler_params={}), engine_factory=OracleEngine)
+    with pytest.raises(NotImplementedError):
+        train(**dict(cfg, from_disk=False), engine_factory=OracleEngine)
+
+
+def test_validation_and_bestval(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
+    cfg = dict(cfg, val_every=3)
+    st = train(**cfg, engine_factory=OracleEngine)
+    assert os.path.exists(os.path.join(cfg["run_dir"], "checkpoints", "bestval.pth"))
+    assert os.path.exists(os.path.join(cfg["run_dir"], "mo.bestval"))      # the reference's quirk path
+    tags = {s["tag"] for s in _scalars(cfg["run_dir"])}
+    assert {"val/loss_recon", "val/loss_l1", "val/mse", "val/encoded/num_dead", "val/encoded/percent_dead"} <= tags
+    assert np.isfinite(st["best_val_loss"])
+
+
+def test_topk_train_loop_matches_reference(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_topk")
+    train(**cfg, engine_factory=OracleEngine)
+    got = {(s["tag"], s["step"]): s["value"] for s in _scalars(cfg["run_dir"])}
+    for tag, val, step in meta["scalars"]:
+        assert got[(tag, step)] == pytest.approx(val, rel=2e-5, abs=1e-7), (tag, step)
+    ck = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step7.pth"), map_location="cpu", weights_only=True)
+    assert list(ck["model"].keys()) == meta["model_keys"]
+    for k in meta["model_keys"]:
+        torch.testing.assert_close(ck["model"][k], torch.tensor(z[f"model__{k}"]), rtol=0, atol=5e-6)
