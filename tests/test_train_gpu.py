@@ -22,13 +22,12 @@ def test_train_cli_path_matches_reference(tmp_path, golden_dir):
     write_shards(folder, meta["layer"], z["shard"], [meta["T"], meta["d"]],
                  [f"/data/audio/file_{i:04d}.flac" for i in range(meta["n_files"])])
     cfg = copy.deepcopy(meta["config"])
-    cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run"), device="cuda",
-               val_every=5)
+    cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run"), device="cuda")
     cfg_path = os.path.join(str(tmp_path), "cfg.json")
     json.dump(cfg, open(cfg_path, "w"))
     main(["--config", cfg_path])
     ck_dir = os.path.join(cfg["run_dir"], "checkpoints")
-    assert sorted(os.listdir(ck_dir)) == sorted(meta["checkpoint_files"] + ["bestval.pth"])
+    assert sorted(os.listdir(ck_dir)) == sorted(meta["checkpoint_files"])
     got = {}
     for line in open(os.path.join(cfg["run_dir"], "metrics.jsonl")):
         s = json.loads(line)
@@ -39,7 +38,14 @@ def test_train_cli_path_matches_reference(tmp_path, golden_dir):
     assert sorted(ck.keys()) == meta["checkpoint_keys"]
     W, Wref = ck["model"]["decoder.weight"].numpy(), z["model__decoder.weight"]
     assert np.linalg.norm(W - Wref) / np.linalg.norm(Wref) < 1e-3
-    assert ("val/loss_recon", 5) in got and ("val/encoded/num_dead", 5) in got
+    # second run with validation switched on (it draws from the global RNG like the reference's val
+    # DataLoader does, so later batches differ from the fixture: only check what it produces)
+    cfg.update(run_dir=os.path.join(str(tmp_path), "run_val"), val_every=5)
+    json.dump(cfg, open(cfg_path, "w"))
+    main(["--config", cfg_path])
+    tags = {(json.loads(l)["tag"], json.loads(l)["step"]) for l in open(os.path.join(cfg["run_dir"], "metrics.jsonl"))}
+    assert ("val/loss_recon", 5) in tags and ("val/encoded/num_dead", 5) in tags and ("val/mse", 5) in tags
+    assert os.path.exists(os.path.join(cfg["run_dir"], "checkpoints", "bestval.pth"))
 
 
 def test_cuda_streamer_delivers_exact_rows(tmp_path):
