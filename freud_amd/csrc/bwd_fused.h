@@ -1,0 +1,271 @@
+// Fused backward of the tied-weight L1 SAE for d_model (padded) == 384 on gfx950.
+//
+// Per (row r, dictionary column j):   dc = dx_hat[r,:] . W[:,j]
+//                                     dpre = (bf16(dc) + 1/M) * [c > 0]
+// and the single tied weight gradient dW[:, j] += dx_hat[r,:]^T c[r,j] + x[r,:]^T dpre[r,j],  db[j] += dpre[r,j]
+// (reference: autograd of src/models/l1autoencoder.py:69-95).
+//
+// One workgroup (4 waves, one per SIMD, whole 512-register file per wave) owns 128 dictionary columns
+// and a contiguous range of activation rows; wave w owns columns 32w..32w+31:
+//   - its slice of W^T (32 columns x K=384, 24 MFMA B-fragments) stays in registers for the whole kernel;
+//   - its dW slab [384 x 32] fp32 stays in 192 accumulator registers (12 MFMA tiles) across all rows;
+//   - per 32-row step the dx_hat / x / c tiles are staged global -> registers -> LDS (double buffered);
+//     dc is one 32x32 MFMA tile (24 MFMAs, A = dx_hat rows by ds_read_b128); its accumulator registers are
+//     gated by c and turned into the bf16 B-operand of the x^T dpre product without leaving the register
+//     file (accumulator-as-operand: rows of the 32x32 tile are the next product's K index);
+//     the A-operands dx_hat^T and x^T are read from the SAME row-major LDS images with the hardware
+//     transposing read ds_read_b64_tr_b16, in the permuted k order the accumulator layout dictates.
+// dpre never exists in HBM; c is read exactly once.  Partial dW slabs / db vectors (one per row range)
+// are summed by reduce_slabs_kernel / reduce_db_kernel in a fixed order (deterministic).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+constexpr int BF_D = 384;                 // padded d_model this kernel is specialised for
+constexpr int BF_BM = 32;                 // rows per step
+constexpr int BF_BN = 128;                // dictionary columns per workgroup
+constexpr int BF_DXH_BYTES = BF_BM * BF_D * 2;   // 24576
+constexpr int BF_C_BYTES = BF_BM * BF_BN * 2;    // 8192
+constexpr int BF_STAGE_BYTES = 2 * BF_DXH_BYTES + BF_C_BYTES;   // 57344
+constexpr int BF_LDS_BYTES = 2 * BF_STAGE_BYTES;                // 114688
+
+// byte offset of 16-B chunk `ch` (0..15) of row `row` in a [rows][128 x bf16] image (256-B rows) that serves
+// both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads without bank conflicts
+__device__ __forceinline__ int dual_off(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+struct BwdFusedArgs {
+  const bf16_t* dxh;   // [M_p][384]
+  const bf16_t* xb;    // [M_p][384]
+  const bf16_t* c;     // [M_p][n_p]
+  const bf16_t* Wt;    // [n_p][384]
+  const float* scal;   // scal[2] = 1/M
+  float* slab;         // [splits][384][n_p]
+  float* db_part;      // [splits][n_p]
+  int n_p;
+  int ntiles;          // n_p / 128
+  int splits;
+  int steps_total;     // M_p / 32
+};
+
+// transposed-read fragment (A or B operand of v_mfma_f32_32x32x16_bf16) from a dual-use image, 32 columns
+// starting at col0 (multiple of 32) of a 128-column sub-tile, for k-step s (16 rows), in the PERMUTED k order
+// that matches an accumulator tile used as the other operand: element j of lane half h <-> row
+// 16 s + 8 (j >> 2) + 4 h + (j & 3).
+__device__ __forceinline__ bf16x8 tr_frag_perm(const char* img, int col0, int s, int lane) {
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int col = col0 + 16 * g + 4 * p;
+  const int r0 = 16 * s + 4 * h + q, r1 = r0 + 8;
+  const int o0 = dual_off(r0, col >> 3) + (col & 7) * 2;
+  const int o1 = dual_off(r1, col >> 3) + (col & 7) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + o0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + o1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// LDS-DMA issued from inline asm so that hipcc does not track it: with the builtin it waits vmcnt(0) before the
+// next LDS read and the copy of step i+1 cannot overlap the MFMAs of step i.  We wait ourselves
+// (s_waitcnt vmcnt(0) + barrier at the end of the step).  M0 carries the wave-uniform LDS byte address.
+// Two pieces per statement (one M0 save/restore): piece k copies 64 x 16 B from sbase_k + voff (per lane) to
+// LDS [dst_k, dst_k + 1024).
+__device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
+                                          unsigned dst0, unsigned dst1) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
+      : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int nblk = a.ntiles * a.splits;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int split = id / a.ntiles, ntile = id - split * a.ntiles;
+  const int step_begin = (int)((int64_t)a.steps_total * split / a.splits);
+  const int step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
+  const int n0 = ntile * BF_BN;           // first dictionary column of the workgroup
+  const int nw = n0 + 32 * w;             // first column of this wave
+  const float inv_m = a.scal[2];
+
+  // W^T fragments of this wave: B[k = d][col = n] -> lane (n = lane & 31, h) holds Wt[nw + n][16 kk + 8 h ..+8]
+  bf16x8 wfrag[24];
+  {
+    const bf16_t* wp = a.Wt + (int64_t)(nw + (lane & 31)) * BF_D + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wp + 16 * kk);
+  }
+
+  f32x16 acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float db_acc = 0.f;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land contiguously at a wave-uniform LDS
+  // address).  One instruction fills 4 rows x 256 B of a [32][256 B] sub-tile image; the dual-use swizzle is
+  // applied to the per-lane SOURCE chunk (linear destination + swizzled source + swizzled reads).
+  // Per step: dx_hat 24 + x 24 + c 8 instructions, 6 + 6 + 2 per wave, issued as 7 two-piece statements.
+  const int srow = lane >> 4;                         // row within the 4-row group
+  const int pc = lane & 15;                           // physical 16-B chunk the lane's data lands in
+  unsigned voff_d[6], voff_c[2];                      // per-lane source byte offsets relative to the step's first row
+  unsigned loff_d[6], loff_c[2];                      // wave-uniform LDS byte offsets inside a stage
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int inst = w + 4 * i, sub = inst >> 3, row = 4 * (inst & 7) + srow;
+    const int ch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    voff_d[i] = (unsigned)(row * (BF_D * 2) + (sub * 16 + ch) * 16);
+    loff_d[i] = (unsigned)__builtin_amdgcn_readfirstlane(sub * 8192 + (inst & 7) * 1024);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = w + 4 * i, row = 4 * inst + srow;
+    const int ch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    voff_c[i] = (unsigned)(row * (a.n_p * 2) + ch * 16);
+    loff_c[i] = (unsigned)__builtin_amdgcn_readfirstlane(2 * BF_DXH_BYTES + inst * 1024);
+  }
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  // piece pair p (0..6) of the step whose first row is row0, into stage `stage`
+  auto dma_pair = [&](int p, int64_t row0, int stage) {
+    const unsigned buf = smem_base + stage * BF_STAGE_BYTES;
+    if (p < 6) {
+      glds16_x2(a.dxh + row0 * BF_D, a.xb + row0 * BF_D, voff_d[p], voff_d[p], buf + loff_d[p],
+                buf + BF_DXH_BYTES + loff_d[p]);
+    } else {
+      const bf16_t* gc = a.c + row0 * a.n_p + n0;
+      glds16_x2(gc, gc, voff_c[0], voff_c[1], buf + loff_c[0], buf + loff_c[1]);
+    }
+  };
+
+  if (step_begin < step_end) {
+#pragma unroll
+    for (int p = 0; p < 7; ++p) dma_pair(p, (int64_t)step_begin * BF_BM, 0);
+  }
+  // make hipcc retire the W^T fragment loads HERE: otherwise it places its vmcnt waits for them inside the loop,
+  // where they would also wait for the (untracked) LDS-DMA of the next step and serialise copy and compute
+#pragma unroll
+  for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(wfrag[kk]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- loop-invariant per-lane LDS read offsets (everything else folds into instruction immediates)
+  //   row read of chunk 2*(kk&7)+h of row (lane&31):         roff[kk & 7]
+  //   transposed read, column group dt&3, first/second half: toff[2 * (dt & 3) + second]   (k-step adds 4096)
+  const int arow = lane & 31, ah = lane >> 5;
+  int roff[8], toff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) roff[i] = dual_off(arow, 2 * i + ah);
+  {
+    const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 32 * (i >> 1) + 16 * g + 4 * p;
+      const int r = 4 * ah + q + 8 * (i & 1);
+      toff[i] = dual_off(r, col >> 3) + (col & 7) * 2;
+    }
+  }
+  const int coff0 = [&] {   // c fragments: this wave's 32 columns of the [32][128] c image
+    const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int col = 32 * w + 16 * g + 4 * p;
+    return dual_off(4 * ah + q, col >> 3) + (col & 7) * 2;
+  }();
+  const int coff1 = [&] {
+    const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int col = 32 * w + 16 * g + 4 * p;
+    return dual_off(4 * ah + q + 8, col >> 3) + (col & 7) * 2;
+  }();
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr_pair = [&](const char* p0, const char* p1) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  int cur = 0;
+  for (int step = step_begin; step < step_end; ++step) {
+    // the last step re-copies its own rows into the idle stage instead of branching around the DMA
+    const int64_t next_row0 = (int64_t)(step + 1 < step_end ? step + 1 : step) * BF_BM;
+    const char* img_d = smem + cur * BF_STAGE_BYTES;
+    const char* img_x = img_d + BF_DXH_BYTES;
+    const char* img_c = img_d + 2 * BF_DXH_BYTES;
+
+    // A-operand fragment of MFMA i (0..71):
+    //   i in [ 0,24): dc += dx_hat(rows; ds_read_b128)      . W^T fragment i (registers)
+    //   i in [24,48): dW[dt] += dx_hat^T (transposed reads) . c fragment s      (dt = (i-24)/2, s = i&1)
+    //   i in [48,72): dW[dt] += x^T (transposed reads)      . dpre fragment s   (dpre made from dc in gaps 30..45)
+    auto load_frag = [&](int i) -> bf16x8 {
+      if (i < 24) {
+        return *reinterpret_cast<const bf16x8*>(img_d + (i >> 3) * 8192 + roff[i & 7]);
+      } else {
+        const char* img = i < 48 ? img_d : img_x;
+        const int tt = i < 48 ? i - 24 : i - 48, dt = tt >> 1, sk = tt & 1;
+        const char* b = img + (dt >> 2) * 8192 + sk * 4096;
+        return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
+      }
+    };
+
+    bf16x8 cf[2], pf[2];
+    cf[0] = tr_pair(img_c + coff0, img_c + coff1);
+    cf[1] = tr_pair(img_c + 4096 + coff0, img_c + 4096 + coff1);
+    f32x16 dc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dc[r] = 0.f;
+    constexpr int DIST = 8;          // fragments are requested DIST MFMAs ahead of their use
+    bf16x8 ring[DIST + 1];
+#pragma unroll
+    for (int i = 0; i < DIST; ++i) ring[i] = load_frag(i);
+
+#pragma unroll
+    for (int i = 0; i < 72; ++i) {
+      // ---- gap work (issues while the previous MFMA occupies the matrix pipe)
+      if (i + DIST < 72) ring[(i + DIST) % (DIST + 1)] = load_frag(i + DIST);
+      if (i % 3 == 1 && i / 3 < 7) dma_pair(i / 3, next_row0, cur ^ 1);
+      if (i >= 30 && i < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
+        const int e = i - 30, s2 = e >> 3, j = e & 7;
+        const float gv = ((float)cf[s2][j] > 0.f) ? (bf16_round(dc[e]) + inv_m) : 0.f;
+        db_acc += gv;
+        pf[s2][j] = (bf16_t)gv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 fa = ring[i % (DIST + 1)];
+      if (i < 24) {
+        dc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, wfrag[i], dc, 0, 0, 0);
+      } else if (i < 48) {
+        acc[(i - 24) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cf[i & 1], acc[(i - 24) >> 1], 0, 0, 0);
+      } else {
+        acc[(i - 48) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[i & 1], acc[(i - 48) >> 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next step have landed
+    __syncthreads();                                    // ... and everybody's; all reads of this stage are done
+    cur ^= 1;
+  }
+
+  // ---- epilogue: dW slab of this row range (rows d = 32 dt + (r&3) + 8 (r>>2) + 4 h, column nw + lane&31)
+  {
+    float* out = a.slab + (int64_t)split * BF_D * a.n_p + nw + (lane & 31);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 12; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int drow = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(int64_t)drow * a.n_p] = acc[dt][r];
+      }
+    db_acc += __shfl_xor(db_acc, 32, 64);
+    if (lane < 32) a.db_part[(int64_t)split * a.n_p + nw + lane] = db_acc;
+  }
+}

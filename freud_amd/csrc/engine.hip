@@ -11,6 +11,7 @@
 
 #include "../../include/freud_sae.h"
 #include "l1_kernels.h"
+#include "bwd_fused.h"
 
 // ------------------------------------------------------------------------------------------
 // error handling
@@ -40,13 +41,14 @@ enum KernelId {
   KID_DEC_FWD,
   KID_DPRE,
   KID_DW,
+  KID_BWD_FUSED,
   KID_REDUCE,
   KID_OPT,
   KID_STEP_TOTAL,
   KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x",        "enc_fwd_gemm", "dec_fwd_gemm", "dpre_gemm",
-                                              "dw_gemm", "reduce_grads", "clip_adam",    "fwd_bwd_total"};
+                                              "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
 struct EvRing {
@@ -70,6 +72,8 @@ struct sae_ctx {
   float* cn_part = nullptr;
   unsigned int* masked = nullptr;
   int dw_splits = 1;
+  int bwd_splits = 1;       // row ranges of the fused backward
+  bool use_fused_bwd = false;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
@@ -78,14 +82,15 @@ struct sae_ctx {
   bool ev_init = false;
 };
 
+static int dominant_kid(const sae_ctx* c) { return c->use_fused_bwd ? KID_BWD_FUSED : KID_DW; }
 static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
-  if (c->profile >= 2 || (c->profile == 1 && (kid == KID_DW || kid == KID_STEP_TOTAL))) {
+  if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
     EvRing& r = c->ev[kid];
     hipEventRecord(r.beg[r.n % EV_RING], s);
   }
 }
 static void ev_end(sae_ctx* c, int kid, hipStream_t s) {
-  if (c->profile >= 2 || (c->profile == 1 && (kid == KID_DW || kid == KID_STEP_TOTAL))) {
+  if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
     EvRing& r = c->ev[kid];
     hipEventRecord(r.end[r.n % EV_RING], s);
     r.n++;
@@ -95,7 +100,7 @@ static void ev_end(sae_ctx* c, int kid, hipStream_t s) {
 extern "C" const char* sae_last_error(void) { return g_err; }
 extern "C" int sae_version(void) { return 1; }
 extern "C" const char* sae_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : nullptr; }
-extern "C" int sae_dominant_kernel(sae_ctx*) { return KID_DW; }
+extern "C" int sae_dominant_kernel(sae_ctx* c) { return c ? dominant_kid(c) : KID_DW; }
 
 extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
@@ -143,6 +148,19 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   if (c->dw_splits < 1) c->dw_splits = 1;
   if (c->dw_splits > ktiles) c->dw_splits = ktiles;
   if (c->dw_splits > 64) c->dw_splits = 64;
+  // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
+  // generic three-GEMM path (used by the tests to cover both)
+  c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
+  {
+    const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
+    int sp = 256 / ntiles;
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    if (sp > steps) sp = steps;
+    c->bwd_splits = sp;
+  }
+  const int slab_splits = c->use_fused_bwd ? (c->bwd_splits > c->dw_splits ? c->bwd_splits : c->dw_splits) : c->dw_splits;
+  const int64_t db_rows = (Mp / 128) > 64 ? (Mp / 128) : 64;
 
 #define ALLOC(ptr, bytes)                                   \
   do {                                                      \
@@ -164,8 +182,8 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->c, Mp * c->n_p * 2);
   ALLOC(c->dxh, Mp * c->d_p * 2);
   ALLOC(c->dpre, Mp * c->n_p * 2);
-  ALLOC(c->slab, (int64_t)c->dw_splits * c->nW * 4);
-  ALLOC(c->db_part, (Mp / 128) * c->n_p * 4);
+  ALLOC(c->slab, (int64_t)slab_splits * c->nW * 4);
+  ALLOC(c->db_part, db_rows * c->n_p * 4);
   ALLOC(c->l1_part, (Mp / 128) * (c->n_p / 128) * 4);
   ALLOC(c->sq_part, (Mp / 128) * (c->d_p / 128) * 2 * 4);
   ALLOC(c->scal, 16 * 4);
@@ -346,38 +364,58 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
   if (rc) return rc;
   if (backward) {
-    {  // dpre = (dx_hat W + 1/M) [c > 0]
-      GemmArgs g{};
-      g.A0 = c->dxh; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
-      g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
-      EpiDpre e{};
-      e.c = c->c; e.dpre = c->dpre; e.db_part = c->db_part; e.scal = c->scal; e.n_p = n_p;
-      ev_begin(c, KID_DPRE, s);
-      rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
-      ev_end(c, KID_DPRE, s);
-      if (rc) return rc;
-    }
     int splits = c->dw_splits;
-    {  // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs)
-      GemmArgs g{};
-      g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
-      g.nbm = d_p / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
-      if (splits > g.ktiles) splits = g.ktiles;
-      g.splits = splits;
-      EpiSlab e{};
-      e.slab = c->slab; e.slab_stride = c->nW; e.ld = n_p;
-      ev_begin(c, KID_DW, s);
-      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
-      ev_end(c, KID_DW, s);
-      if (rc) return rc;
+    int db_rows = (int)(Mp / 128);
+    if (c->use_fused_bwd) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_d384_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES));
+        attr_set = true;
+      }
+      BwdFusedArgs a{};
+      a.dxh = c->dxh; a.xb = c->xb; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
+      a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
+      splits = c->bwd_splits;
+      if (splits > a.steps_total) splits = a.steps_total;
+      a.splits = splits;
+      db_rows = splits;
+      ev_begin(c, KID_BWD_FUSED, s);
+      hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+      ev_end(c, KID_BWD_FUSED, s);
+      HIP_TRY(hipGetLastError());
+    } else {
+      {  // dpre = (dx_hat W + 1/M) [c > 0]
+        GemmArgs g{};
+        g.A0 = c->dxh; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
+        g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+        EpiDpre e{};
+        e.c = c->c; e.dpre = c->dpre; e.db_part = c->db_part; e.scal = c->scal; e.n_p = n_p;
+        ev_begin(c, KID_DPRE, s);
+        rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+        ev_end(c, KID_DPRE, s);
+        if (rc) return rc;
+      }
+      {  // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs)
+        GemmArgs g{};
+        g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
+        g.nbm = d_p / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
+        if (splits > g.ktiles) splits = g.ktiles;
+        g.splits = splits;
+        EpiSlab e{};
+        e.slab = c->slab; e.slab_stride = c->nW; e.ld = n_p;
+        ev_begin(c, KID_DW, s);
+        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+        ev_end(c, KID_DW, s);
+        if (rc) return rc;
+      }
     }
     ev_begin(c, KID_REDUCE, s);
     {
       const int64_t n4 = c->nW / 4;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
                          splits);
-      hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, c->G + c->nW,
-                         (int)(Mp / 128), n_p);
+      hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, c->G + c->nW, db_rows, n_p);
     }
     ev_end(c, KID_REDUCE, s);
   }

@@ -64,14 +64,17 @@ def test_l1_steps_match_reference_golden(golden_dir, name):
     eng.close()
 
 
-@pytest.mark.parametrize("d,n,M,dtype,opt", [
-    (384, 3072, 1024, torch.float32, "radam"),
-    (384, 3072, 1000, torch.bfloat16, "radam"),     # ragged M (not a tile multiple)
-    (384, 200, 1500, torch.float16, "adam"),        # the stock tiny_l1.json dictionary size
-    (768, 1536, 512, torch.float32, "adam"),
-    (1280, 2560, 384, torch.bfloat16, "radam"),
+@pytest.mark.parametrize("d,n,M,dtype,opt,generic", [
+    (384, 3072, 1024, torch.float32, "radam", False),
+    (384, 3072, 1024, torch.float32, "radam", True),       # generic three-GEMM backward on the same case
+    (384, 3072, 1000, torch.bfloat16, "radam", False),     # ragged M (not a tile multiple)
+    (384, 200, 1500, torch.float16, "adam", False),        # the stock tiny_l1.json dictionary size
+    (384, 200, 1500, torch.float16, "adam", True),
+    (384, 3072, 8192 + 96, torch.bfloat16, "adam", False), # several 32-row steps per row range, uneven split
+    (768, 1536, 512, torch.float32, "adam", False),
+    (1280, 2560, 384, torch.bfloat16, "radam", False),
 ])
-def test_l1_step_matches_oracle(d, n, M, dtype, opt):
+def test_l1_step_matches_oracle(d, n, M, dtype, opt, generic):
     g = torch.Generator().manual_seed(d + n + M)
     W = torch.empty(d, n)
     torch.nn.init.orthogonal_(W, generator=g)
@@ -80,7 +83,7 @@ def test_l1_step_matches_oracle(d, n, M, dtype, opt):
     x = (z @ torch.randn(64, d, generator=g)).to(dtype)
     x.view(-1)[torch.randint(0, x.numel(), (50,), generator=g)] = -1.0
     alpha, lr = 1e4, 4e-4
-    eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer=opt, recon_alpha=alpha)
+    eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer=opt, recon_alpha=alpha, force_generic=generic)
     eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     Wo, bo, st = W.clone(), b.clone(), O.OptState()
     xd = x.cuda()
