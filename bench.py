@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--x-dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
 
@@ -94,7 +95,7 @@ def main():
     x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype)
     x = x_cpu.cuda()
     eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
-                    clip_thresh=1.0, device_id=local_rank)
+                    clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg)
     eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     grads = eng.grad_tensor() if world > 1 else None
     total_steps, base_lr = 100000, 4e-4

@@ -47,6 +47,7 @@ struct BwdFusedArgs {
   int ntiles;          // n_p / 128
   int splits;
   int steps_total;     // M_p / 32
+  int dbg;             // timing experiments only: 4 = skip in-loop DMA
 };
 
 // transposed-read fragment (A or B operand of v_mfma_f32_32x32x16_bf16) from a dual-use image, 32 columns
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     for (int i = 0; i < 72; ++i) {
       // ---- gap work (issues while the previous MFMA occupies the matrix pipe)
       if (i + DIST < 72) ring[(i + DIST) % (DIST + 1)] = load_frag(i + DIST);
-      if (i % 3 == 1 && i / 3 < 7) dma_pair(i / 3, next_row0, cur ^ 1);
+      if (i % 3 == 1 && i / 3 < 7 && !(a.dbg & 4)) dma_pair(i / 3, next_row0, cur ^ 1);
       if (i >= 30 && i < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = i - 30, s2 = e >> 3, j = e & 7;
         const float gv = ((float)cf[s2][j] > 0.f) ? (bf16_round(dc[e]) + inv_m) : 0.f;

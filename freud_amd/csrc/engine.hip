@@ -12,6 +12,7 @@
 #include "../../include/freud_sae.h"
 #include "l1_kernels.h"
 #include "bwd_fused.h"
+#include "fwd_fused.h"
 
 // ------------------------------------------------------------------------------------------
 // error handling
@@ -39,6 +40,7 @@ enum KernelId {
   KID_PREP_X,
   KID_ENC_FWD,
   KID_DEC_FWD,
+  KID_FWD_FUSED,
   KID_DPRE,
   KID_DW,
   KID_BWD_FUSED,
@@ -47,7 +49,7 @@ enum KernelId {
   KID_STEP_TOTAL,
   KID_COUNT
 };
-static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x",        "enc_fwd_gemm", "dec_fwd_gemm", "dpre_gemm",
+static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x", "enc_fwd_gemm", "dec_fwd_gemm", "fwd_fused_gemm", "dpre_gemm",
                                               "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
@@ -65,7 +67,8 @@ struct sae_ctx {
   // flat parameter / state buffers: [W (d_p*n_p) | b (n_p)]
   float *P = nullptr, *Mom = nullptr, *Var = nullptr;
   float* G = nullptr;  // [grads (nparams) | metrics (8)]
-  bf16_t *Wb = nullptr, *Wt = nullptr;
+  bf16_t *Wb = nullptr, *Wt = nullptr, *Wp = nullptr;
+  bool use_fused_fwd = false;
   bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
@@ -106,7 +109,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device_id);
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
-                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part};
+                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->Wp};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->ev_init)
@@ -151,6 +154,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
+  c->use_fused_fwd = (c->d_p == FF_D) && cfg->reserved[0] != 1 && (FF_RING_BYTES + (int64_t)c->n_p * 4 <= 160 * 1024)  /* n_p <= 4096 */;
   {
     const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
     int sp = 256 / ntiles;
@@ -178,6 +182,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->G, (c->nparams + SAE_NUM_METRICS) * 4);
   ALLOC(c->Wb, c->nW * 2);
   ALLOC(c->Wt, c->nW * 2);
+  ALLOC(c->Wp, c->nW * 2);
   ALLOC(c->xb, Mp * c->d_p * 2);
   ALLOC(c->c, Mp * c->n_p * 2);
   ALLOC(c->dxh, Mp * c->d_p * 2);
@@ -312,7 +317,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   ev_begin(c, KID_PREP_W, s);
   hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 64, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
   hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
-                     c->Wt, d_p, n_p);
+                     c->Wt, c->use_fused_fwd ? c->Wp : nullptr, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
   ev_begin(c, KID_PREP_X, s);
@@ -329,6 +334,25 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   ev_end(c, KID_PREP_X, s);
 
   int rc;
+  if (c->use_fused_fwd) {
+    static bool attr_set = false;
+    const int lds = FF_RING_BYTES + n_p * 4;
+    auto kern = fwd_fused_d384_kernel<T>;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+      attr_set = true;
+    }
+    FwdFusedArgs a{};
+    a.xb = c->xb; a.x = x; a.Wt = c->Wt; a.Wp = c->Wp; a.bias = b; a.scal = c->scal; a.c = c->c; a.dxh = c->dxh;
+    a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
+    a.dbg = c->cfg.reserved[1];
+    ev_begin(c, KID_FWD_FUSED, s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Mp / FF_BM)), dim3(256), lds, s, a);
+    ev_end(c, KID_FWD_FUSED, s);
+    HIP_TRY(hipGetLastError());
+    return SAE_OK;
+  }
   {  // c = relu(x W + b)
     GemmArgs g{};
     g.A0 = c->xb; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
@@ -376,6 +400,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       BwdFusedArgs a{};
       a.dxh = c->dxh; a.xb = c->xb; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
       a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
+      a.dbg = c->cfg.reserved[1];
       splits = c->bwd_splits;
       if (splits > a.steps_total) splits = a.steps_total;
       a.splits = splits;
@@ -419,8 +444,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     }
     ev_end(c, KID_REDUCE, s);
   }
-  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
-                     c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha);
+  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part,
+                     c->use_fused_fwd ? (int)(Mp / 128) : (int)((Mp / 128) * (n_p / 128)), c->sq_part,
+                     c->use_fused_fwd ? (int)(Mp / 128) : (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d,
+                     alpha);
   ev_end(c, KID_STEP_TOTAL, s);
   HIP_TRY(hipGetLastError());
   c->last_M = M;
