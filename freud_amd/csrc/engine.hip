@@ -154,7 +154,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
-  c->use_fused_fwd = (c->d_p == FF_D) && cfg->reserved[0] != 1 && (FF_RING_BYTES + (int64_t)c->n_p * 4 <= 160 * 1024)  /* n_p <= 4096 */;
+  c->use_fused_fwd = (c->d_p == FF_D) && cfg->reserved[0] != 1 && (FF_FIXED_LDS + (int64_t)c->n_p * 4 <= 160 * 1024);
   {
     const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
     int sp = 256 / ntiles;
@@ -317,7 +317,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   ev_begin(c, KID_PREP_W, s);
   hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 64, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
   hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
-                     c->Wt, c->use_fused_fwd ? c->Wp : nullptr, d_p, n_p);
+                     c->Wt, nullptr, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
   ev_begin(c, KID_PREP_X, s);
@@ -335,18 +335,29 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
 
   int rc;
   if (c->use_fused_fwd) {
-    static bool attr_set = false;
-    const int lds = FF_RING_BYTES + n_p * 4;
-    auto kern = fwd_fused_d384_kernel<T>;
-    if (!attr_set) {
+    const int lds = FF_FIXED_LDS + n_p * 4;
+    FwdFusedArgs a{};
+    a.xb = c->xb; a.x = x; a.Wt = c->Wt; a.bias = b; a.scal = c->scal; a.c = c->c; a.dxh = c->dxh;
+    a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
+    void (*kern)(FwdFusedArgs) = fwd_fused_d384_kernel<T, 0>;
+    switch (c->cfg.reserved[1]) {   // timing experiments (bench.py --dbg); 0 in production
+      case 1: kern = fwd_fused_d384_kernel<T, 1>; break;
+      case 2: kern = fwd_fused_d384_kernel<T, 2>; break;
+      case 3: kern = fwd_fused_d384_kernel<T, 3>; break;
+      case 8: kern = fwd_fused_d384_kernel<T, 8>; break;
+      case 16: kern = fwd_fused_d384_kernel<T, 16>; break;
+      case 19: kern = fwd_fused_d384_kernel<T, 19>; break;
+      case 27: kern = fwd_fused_d384_kernel<T, 27>; break;
+      case 32: kern = fwd_fused_d384_kernel<T, 32>; break;
+      case 59: kern = fwd_fused_d384_kernel<T, 59>; break;
+      default: break;
+    }
+    static const void* attr_done = nullptr;   // one opt-in per kernel variant (> 64 KiB dynamic LDS)
+    if (attr_done != reinterpret_cast<const void*>(kern)) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
-      attr_set = true;
+      attr_done = reinterpret_cast<const void*>(kern);
     }
-    FwdFusedArgs a{};
-    a.xb = c->xb; a.x = x; a.Wt = c->Wt; a.Wp = c->Wp; a.bias = b; a.scal = c->scal; a.c = c->c; a.dxh = c->dxh;
-    a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
-    a.dbg = c->cfg.reserved[1];
     ev_begin(c, KID_FWD_FUSED, s);
     hipLaunchKernelGGL(kern, dim3((unsigned)(Mp / FF_BM)), dim3(256), lds, s, a);
     ev_end(c, KID_FWD_FUSED, s);

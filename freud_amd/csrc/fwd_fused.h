@@ -21,16 +21,16 @@
 constexpr int FF_D = 384;
 constexpr int FF_BM = 128;                        // rows per workgroup
 constexpr int FF_BN = 32;                         // dictionary columns per tile
-constexpr int FF_WT_BYTES = FF_BN * FF_D * 2;     // 24576: W^T tile [32 n][384 d]
-constexpr int FF_WP_BYTES = FF_D * FF_BN * 2;     // 24576: W tile   [384 d][32 n (permuted)]
-constexpr int FF_DEPTH = 3;                        // LDS ring slots per operand: one being read, two landing
-constexpr int FF_RING_BYTES = FF_DEPTH * (FF_WT_BYTES + FF_WP_BYTES);   // 147456
+constexpr int FF_WT_BYTES = FF_BN * FF_D * 2;     // 24576: W^T tile [32 n][384 d] (3 dual-use sub-tiles)
+constexpr int FF_DEPTH = 4;                       // W^T ring: tile j (decoder), j+1 (encoder), j+2 / j+3 landing
+constexpr int FF_RING_BYTES = FF_DEPTH * FF_WT_BYTES;          // 98304
+constexpr int FF_CST_BYTES = 4 * 2 * 4096;        // per wave two [32 rows][64 cols] bf16 latent staging buffers
+constexpr int FF_FIXED_LDS = FF_RING_BYTES + FF_CST_BYTES;     // + 4 * n_p bytes of bias
 
 struct FwdFusedArgs {
   const bf16_t* xb;      // [M_p][384]  bf16 GEMM operand
   const void* x;         // original activations [M][d] (dtype T) for the residual
   const bf16_t* Wt;      // [n_p][384]
-  const bf16_t* Wp;      // [n_p/32][384][32 permuted]
   const float* bias;     // [n_p]
   const float* scal;     // scal[1] = alpha / count
   bf16_t* c;             // [M_p][n_p]
@@ -38,11 +38,13 @@ struct FwdFusedArgs {
   float* l1_part;        // [M_p/128]
   float* sq_part;        // [M_p/128][2]
   int64_t M;
-  int d, n_p, ntiles;    // ntiles = n_p / 32
+  int d, n_p, ntiles;    // ntiles = n_p / 32 (even)
   int dbg;               // timing experiments only: 1 = skip latent stores, 2 = skip in-loop DMA
 };
 
-template <typename T>
+// DBG (compile time, timing experiments only; results become wrong): 1 = no latent stores, 2 = no in-loop DMA,
+// 8 = no end-of-iteration wait/barrier, 16 = no bias/ReLU/staging work, 32 = no decoder MFMAs
+template <typename T, int DBG>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -50,7 +52,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const int64_t m0 = (int64_t)blockIdx.x * FF_BM + 32 * w;     // first row of this wave
   const int64_t mrow = m0 + arow;                               // the row this lane's accumulator column is
   const bool row_ok = mrow < a.M;
-  float* bias_s = reinterpret_cast<float*>(smem + FF_RING_BYTES);
+  const bool wave_has_pad = __builtin_amdgcn_readfirstlane((int)(m0 + 32 > a.M)) != 0;
+  char* cst = smem + FF_RING_BYTES + w * 8192;                  // this wave's latent staging (2 x 4 KB)
+  float* bias_s = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
 
   // x fragments: B[k = d][col = m] -> lane (m = lane&31, h) holds xb[m0 + m][16 kk + 8 h ..+8]
   bf16x8 xfrag[24];
@@ -67,88 +71,92 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // ---- LDS-DMA plan.  W^T tile: 3 sub-tiles [32][256 B] (dual_off swizzle on the source chunk), 24 pieces of
-  // 1 KB (4 rows each).  W tile: 384 rows x 64 B, chunk XOR ((d>>2)&3), 24 pieces (16 rows each).  6 + 6 per wave.
-  unsigned voff_t[6], loff_t[6], voff_p[6], loff_p[6];
+  // ---- LDS-DMA plan: a W^T tile is 3 sub-tiles [32 rows][256 B] with the dual-use swizzle applied to the source
+  // chunk; 24 pieces of 1 KB (4 rows each), 6 per wave, issued as 3 two-piece statements per iteration.
+  unsigned voff_t[6], loff_t[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int inst = w + 4 * i;
-    {
-      const int sub = inst >> 3, row = 4 * (inst & 7) + (lane >> 4), pc = lane & 15;
-      const int ch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
-      voff_t[i] = (unsigned)(row * (FF_D * 2) + (sub * 16 + ch) * 16);
-      loff_t[i] = (unsigned)__builtin_amdgcn_readfirstlane(sub * 8192 + (inst & 7) * 1024);
-    }
-    {
-      const int row = 16 * inst + (lane >> 2), pc = lane & 3;
-      const int ch = pc ^ ((row >> 2) & 3);
-      voff_p[i] = (unsigned)(row * 64 + ch * 16);
-      loff_p[i] = (unsigned)__builtin_amdgcn_readfirstlane(inst * 1024);
-    }
+    const int inst = w + 4 * i, sub = inst >> 3, row = 4 * (inst & 7) + (lane >> 4), pc = lane & 15;
+    const int ch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    voff_t[i] = (unsigned)(row * (FF_D * 2) + (sub * 16 + ch) * 16);
+    loff_t[i] = (unsigned)__builtin_amdgcn_readfirstlane(sub * 8192 + (inst & 7) * 1024);
   }
   typedef __attribute__((address_space(3))) char* lptr_t;
   const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
-  // pair p (0..5): one piece of W^T tile `jt` into Wt slot `st`, one piece of W tile `jp` into Wp slot `sp`
-  auto dma_pair = [&](int p, int jt, int st, int jp, int sp) {
-    const unsigned dst_t = smem_base + st * FF_WT_BYTES + loff_t[p];
-    const unsigned dst_p = smem_base + FF_DEPTH * FF_WT_BYTES + sp * FF_WP_BYTES + loff_p[p];
-    glds16_x2(a.Wt + (int64_t)jt * FF_BN * FF_D, a.Wp + (int64_t)jp * FF_BN * FF_D, voff_t[p], voff_p[p], dst_t, dst_p);
+  // pieces 2p, 2p+1 of W^T tile `jt` into ring slot `st`
+  auto dma_pair = [&](int p, int jt, int st) {
+    const bf16_t* src = a.Wt + (int64_t)jt * FF_BN * FF_D;
+    const unsigned dst = smem_base + st * FF_WT_BYTES;
+    glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], dst + loff_t[2 * p], dst + loff_t[2 * p + 1]);
   };
   const int last = a.ntiles - 1;
-  // prologue: W^T tiles 0, 1, 2 and W tiles 0, 1
+  // prologue: W^T tiles 0, 1, 2 into slots 0, 1, 2
 #pragma unroll
-  for (int p = 0; p < 6; ++p) dma_pair(p, 0, 0, 0, 0);
+  for (int q = 0; q < 3; ++q)
 #pragma unroll
-  for (int p = 0; p < 6; ++p) dma_pair(p, last < 1 ? last : 1, 1, last < 1 ? last : 1, 1);
-#pragma unroll
-  for (int p = 0; p < 6; ++p) dma_pair(p, last < 2 ? last : 2, 2, last < 1 ? last : 1, 1);
+    for (int p = 0; p < 3; ++p) dma_pair(p, q <= last ? q : last, q);
 #pragma unroll
   for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(xfrag[kk]));   // retire hipcc-tracked loads before the loop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // loop-invariant per-lane LDS read offsets
-  int roff[8];
+  // ---- loop-invariant per-lane LDS offsets
+  int roff[8], toff[8];      // row reads (encoder A operand) / transposed reads (decoder A operand) of a W^T tile
 #pragma unroll
   for (int i = 0; i < 8; ++i) roff[i] = dual_off(arow, 2 * i + ah);
-  int poff[2];
+  {
+    const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) poff[s] = arow * 64 + (((2 * s + ah) ^ ((arow >> 2) & 3)) << 4);
+    for (int i = 0; i < 8; ++i) {
+      const int col = 32 * (i >> 1) + 16 * g + 4 * p;
+      const int r = 4 * ah + q + 8 * (i & 1);
+      toff[i] = dual_off(r, col >> 3) + (col & 7) * 2;
+    }
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr_pair = [&](const char* p0, const char* p1) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  // latent staging [32 rows][64 cols] bf16, 128-B rows, 16-B chunk index XORed with (row & 7):
+  //   write: this lane's row `arow`, 8 bytes at column 32 (j&1) + 8 k + 4 h
+  //   drain: piece p (0..3) = rows 8p..8p+7, lane -> row 8p + lane/8, chunk lane%8 (16 B) -> full 128-B lines
+  const int drow_l = lane >> 3, dch = lane & 7;
+  bf16_t* cdrain = a.c + (m0 + drow_l) * a.n_p + dch * 8;     // + 8 p rows, + 64 * pair columns
 
-  // per-lane output pointer for c: row mrow, columns 4 h + 8 k (k = 0..3) of the current tile
-  bf16_t* cptr = a.c + mrow * a.n_p + 4 * ah;
   float l1_acc = 0.f;
 
   // ---- S for tile 0 (no overlap partner yet)
   f32x16 S;
 #pragma unroll
   for (int r = 0; r < 16; ++r) S[r] = 0.f;
-  {
-    const char* img_t = smem;   // slot 0
 #pragma unroll
-    for (int kk = 0; kk < 24; ++kk) {
-      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(img_t + (kk >> 3) * 8192 + roff[kk & 7]);
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], S, 0, 0, 0);
-    }
+  for (int kk = 0; kk < 24; ++kk) {
+    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(smem + (kk >> 3) * 8192 + roff[kk & 7]);
+    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], S, 0, 0, 0);
   }
 
   constexpr int DIST = 8;
-  int s0 = 0, s1 = 1, s2 = 2;                               // j % 3, (j+1) % 3, (j+2) % 3
   for (int j = 0; j < a.ntiles; ++j) {
-    // iteration j: encoder MFMAs of tile j+1 (S_next) with the epilogue of tile j in their gaps, then decoder
-    // MFMAs of tile j.  Reads W^T slot (j+1)%3 and W slot j%3.  DMA issued now: W^T tile j+3 -> slot j%3 (its
-    // tile j was consumed in iteration j-1) and W tile j+2 -> slot (j+2)%3; they are only required to have
-    // landed by the END of iteration j+1 (counted vmcnt), so a copy has more than one iteration to arrive.
-    const int jn = j + 2 <= last ? j + 2 : last;           // clamped sources: the tail re-copies valid tiles
+    // iteration j: encoder MFMAs of tile j+1 (rows of ring slot (j+1)%4) with the bias/ReLU/staging work of tile
+    // j in their gaps, then decoder MFMAs of tile j (transposed reads of ring slot j%4).  DMA issued now: tile
+    // j+3 -> slot (j+3)%4 (its previous tile j-1 was last read in iteration j-1); it has to have landed only
+    // by the END of iteration j+1 (counted vmcnt), i.e. it has more than one whole iteration to arrive.
     const int jt = j + 3 <= last ? j + 3 : last;
-    const char* img_t = smem + s1 * FF_WT_BYTES;
-    const char* img_p = smem + FF_DEPTH * FF_WT_BYTES + s0 * FF_WP_BYTES;
+    const char* img_e = smem + ((j + 1) & 3) * FF_WT_BYTES;
+    const char* img_d = smem + (j & 3) * FF_WT_BYTES;
     const float* bj = bias_s + j * FF_BN;
+    char* cst_w = cst + ((j >> 1) & 1) * 4096;               // staging buffer being filled by tiles 2t, 2t+1
+    const char* cst_r = cst + (((j >> 1) & 1) ^ 1) * 4096;   // staging buffer being drained (tiles 2t-2, 2t-1)
+    const bool drain = j >= 2;
 
     auto load_frag = [&](int i) -> bf16x8 {
-      if (i < 24) return *reinterpret_cast<const bf16x8*>(img_t + (i >> 3) * 8192 + roff[i & 7]);
-      const int tt = i - 24, dt = tt >> 1, s = tt & 1;
-      return *reinterpret_cast<const bf16x8*>(img_p + dt * 2048 + poff[s]);
+      if (i < 24) return *reinterpret_cast<const bf16x8*>(img_e + (i >> 3) * 8192 + roff[i & 7]);
+      const int tt = i - 24, dt = tt >> 1, sk = tt & 1;
+      const char* b = img_d + (dt >> 2) * 8192 + sk * 4096;
+      return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
     };
     bf16x8 ring[DIST + 1];
 #pragma unroll
@@ -158,43 +166,71 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
     bf16x8 cf[2];
+    if (DBG & 16) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { cf[0][q] = (bf16_t)S[q]; cf[1][q] = (bf16_t)S[8 + q]; }
+    }
     f32x4 bq[4];
+    u32x4 dr[2];
 
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
       if (i + DIST < 48) ring[(i + DIST) % (DIST + 1)] = load_frag(i + DIST);
-      if (i % 4 == 1 && i / 4 < 6 && !(a.dbg & 2)) dma_pair(i / 4, jt, s0, jn, s2);   // slots idle in this iteration
+      if (i % 4 == 1 && i / 4 < 3 && !(DBG & 2)) dma_pair(i / 4, jt, (j + 3) & 3);
       if (i < 4) bq[i] = *reinterpret_cast<const f32x4*>(bj + 8 * i + 4 * ah);    // bias of S rows 8 i + 4 h + (0..3)
-      if (i >= 4 && i < 20) {     // one latent element per gap: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+      if (i >= 4 && i < 20 && !(DBG & 16)) {     // one latent element per gap: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
         const int e = i - 4;
         float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
-        cv = row_ok ? cv : 0.f;
+        if (wave_has_pad) cv = row_ok ? cv : 0.f;
         l1_acc += cv;
         cf[e >> 3][e & 7] = (bf16_t)cv;
-        if ((e & 3) == 3) {       // 4 consecutive columns ready: 8-B store straight from registers
+        if ((e & 3) == 3) {       // 4 consecutive columns ready: 8 bytes into the staging image
           const int k = e >> 2;
-          bf16x4 o = {cf[e >> 3][(e & 7) - 3], cf[e >> 3][(e & 7) - 2], cf[e >> 3][(e & 7) - 1], cf[e >> 3][e & 7]};
-          if (!(a.dbg & 1)) *reinterpret_cast<bf16x4*>(cptr + 8 * k) = o;
+          const bf16x4 o = {cf[e >> 3][(e & 7) - 3], cf[e >> 3][(e & 7) - 2], cf[e >> 3][(e & 7) - 1], cf[e >> 3][e & 7]};
+          const int chunk = 4 * (j & 1) + k;                 // 16-B chunk of the 128-B row; +8 bytes for h = 1
+          *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
         }
+      }
+      // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 10 gaps later
+      if ((i == 24 || i == 28) && drain && !(DBG & 1)) {
+        const int r = 8 * (2 * (j & 1) + (i == 28)) + drow_l;
+        dr[i == 28] = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
+      }
+      if ((i == 34 || i == 38) && drain && !(DBG & 1)) {
+        const int p = 2 * (j & 1) + (i == 38);
+        *reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((j >> 1) - 1)) = dr[i == 38];
       }
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8 fa = ring[i % (DIST + 1)];
       if (i < 24) {
         Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i], Sn, 0, 0, 0);
-      } else {
+      } else if (!(DBG & 32)) {
         acc[(i - 24) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cf[i & 1], acc[(i - 24) >> 1], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(fa));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     S = Sn;
-    cptr += FF_BN;
-    { const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp; }
-    // this iteration issued 12 LDS-DMA pieces + 4 latent stores per wave: everything older has completed once at
-    // most 16 operations are outstanding.  Raw barrier (no fence): __syncthreads() would drain vmcnt to 0.
+    // this iteration issued 6 LDS-DMA pieces (+ 2 latent stores when draining) per wave: everything older has
+    // completed once at most that many operations are outstanding.  Raw barrier: __syncthreads() would drain to 0.
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 8)) {
+      if (drain) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // drain the last pair of latent tiles
+  if (!(DBG & 1)) {
+    const char* cst_r = cst + (((a.ntiles >> 1) - 1) & 1) * 4096;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = 8 * p + drow_l;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
+      *reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)) = v;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -203,49 +239,61 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   // acc[dt][r] <-> d = 32 dt + (r&3) + 8 (r>>2) + 4 h, row mrow.
   const float scale = a.scal[1];
   float sq = 0.f, plain = 0.f;
-  // rows past M read row M-1 (valid memory) and are masked; with d == 384 every 4-column group is whole, so the
-  // original activations come in as vector loads issued back to back (no per-element branches / waits)
+  // every value of this lane belongs to ONE activation row (mrow): rows past M read row M-1 (valid memory) and the
+  // row mask is applied once at the end.  With d == 384 every 4-column group is whole -> vector loads, no branches.
   const int64_t lrow = row_ok ? mrow : a.M - 1;
   const T* xrow = reinterpret_cast<const T*>(a.x) + lrow * a.d;
   bf16_t* drow = a.dxh + mrow * FF_D;
   typedef __attribute__((ext_vector_type(4))) T Tx4;
   const bool vec_ok = (a.d == FF_D) && ((reinterpret_cast<uintptr_t>(a.x) & (sizeof(T) * 4 - 1)) == 0);
+  const float rmask = row_ok ? 1.f : 0.f;
+  if (vec_ok) {
 #pragma unroll
-  for (int dt = 0; dt < 12; ++dt) {
-    float xv[4][4];
-    if (vec_ok) {
+    for (int dt = 0; dt < 12; ++dt) {
+      Tx4 xv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const Tx4*>(xrow + 32 * dt + 8 * k + 4 * ah);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const Tx4 v = *reinterpret_cast<const Tx4*>(xrow + 32 * dt + 8 * k + 4 * ah);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[k][q] = (float)v[q];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
+        bf16x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int dd = 32 * dt + 8 * k + 4 * ah + q;
-          xv[k][q] = (float)xrow[dd < a.d ? dd : a.d - 1];
+          const float xf = (float)xv[k][q];
+          const float e = bf16_round(acc[dt][4 * k + q]) - xf;
+          const float e2 = e * e;
+          plain += e2;
+          const float keep = (xf != -1.0f) ? rmask : 0.f;
+          sq += keep * e2;
+          o[q] = (bf16_t)((keep * (e * 2.0f)) * scale);
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int d0 = 32 * dt + 8 * k + 4 * ah;
-      bf16x4 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool valid = row_ok && (d0 + q < a.d);
-        const float e = bf16_round(acc[dt][4 * k + q]) - xv[k][q];
-        const float e2 = valid ? e * e : 0.f;
-        plain += e2;
-        const bool keep = valid && (xv[k][q] != -1.0f);
-        sq += keep ? e2 : 0.f;
-        o[q] = (bf16_t)(keep ? (e * 2.0f) * scale : 0.f);
+        *reinterpret_cast<bf16x4*>(drow + 32 * dt + 8 * k + 4 * ah) = o;
       }
-      *reinterpret_cast<bf16x4*>(drow + d0) = o;
     }
+  } else {
+    for (int dt = 0; dt < 12; ++dt)
+      for (int k = 0; k < 4; ++k) {
+        const int d0 = 32 * dt + 8 * k + 4 * ah;
+        bf16x4 o;
+        for (int q = 0; q < 4; ++q) {
+          const bool valid = d0 + q < a.d;
+          const float xf = (float)xrow[valid ? d0 + q : a.d - 1];
+          float accv = 0.f;
+#pragma unroll
+          for (int dd = 0; dd < 12; ++dd)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr)
+              if (dd == dt && rr == 4 * k + q) accv = acc[dd][rr];
+          const float e = bf16_round(accv) - xf;
+          const float e2 = valid ? e * e : 0.f;
+          plain += e2;
+          const float keep = (valid && xf != -1.0f) ? rmask : 0.f;
+          sq += keep * e2;
+          o[q] = (bf16_t)((keep * (e * 2.0f)) * scale);
+        }
+        *reinterpret_cast<bf16x4*>(drow + d0) = o;
+      }
   }
+  plain *= rmask;
   float* red = reinterpret_cast<float*>(smem);      // the W rings are idle now
   const float l1s = block_sum_256(l1_acc, red);
   const float sqs = block_sum_256(sq, red + 8);
