@@ -137,7 +137,9 @@ def main():
     dom = eng.dominant_kernel()
     dom_ms, dom_cnt = times[dom]
     dom_avg_ms = dom_ms / max(dom_cnt, 1)
-    dom_flops = 4.0 * M * d * n                      # two of the five 2*M*d*n GEMMs
+    # algorithmic FLOPs of the dominant kernel: fused backward = dc, dW(dec), dW(enc) GEMMs = 3 x 2*M*d*n;
+    # generic path's dw_gemm = the two weight-gradient GEMMs = 2 x 2*M*d*n
+    dom_flops = (6.0 if dom == "bwd_fused_gemm" else 4.0) * M * d * n
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
     step_flops = 10.0 * M * d * n                    # algorithmic FLOPs per activation = 10 d n
     fb_ms, fb_cnt = times["fwd_bwd_total"]

@@ -13,6 +13,7 @@
 #include "l1_kernels.h"
 #include "bwd_fused.h"
 #include "fwd_fused.h"
+#include "topk_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // error handling
@@ -46,11 +47,20 @@ enum KernelId {
   KID_BWD_FUSED,
   KID_REDUCE,
   KID_OPT,
+  KID_TK_ENC,
+  KID_TK_SELECT,
+  KID_TK_DECODE,
+  KID_TK_DDENSE,
+  KID_TK_DWD,
+  KID_TK_DWE,
+  KID_TK_DSAE,
   KID_STEP_TOTAL,
   KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x", "enc_fwd_gemm", "dec_fwd_gemm", "fwd_fused_gemm", "dpre_gemm",
-                                              "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "fwd_bwd_total"};
+                                              "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "topk_enc_gemm", "topk_select",
+                                              "topk_decode", "topk_ddense_gemm", "topk_dwdec_gemm", "topk_dwenc_gemm",
+                                              "topk_dsaein_gemm", "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
 struct EvRing {
@@ -77,6 +87,18 @@ struct sae_ctx {
   int dw_splits = 1;
   int bwd_splits = 1;       // row ranges of the fused backward
   bool use_fused_bwd = false;
+  // ---- TopK variant (topkautoencoder.py): flat params [We (n_p*d_p) | be (n_p) | Wd (n_p*d_p) | bd (d_p)]
+  bool topk = false;
+  int k = 0, k_aux_cap = 0;
+  int64_t rows_per_file = 0;          // T: x is [B][T][d] for x.mean(0); 0 = the whole batch is one file
+  double dead_threshold = 1e300;
+  bf16_t *We_b = nullptr, *Wd_b = nullptr, *xs = nullptr, *pre = nullptr, *dense = nullptr, *aux_dense = nullptr;
+  bf16_t *de_b = nullptr, *dh_b = nullptr;
+  float *e = nullptr, *dh = nullptr, *e2_part = nullptr, *a2_part = nullptr, *dbd_part = nullptr, *ds_part = nullptr, *tkf = nullptr;
+  int *top_idx = nullptr, *aux_idx = nullptr, *tk = nullptr;
+  double* tv_part = nullptr;
+  long long* nfsf = nullptr;
+  unsigned char* dead = nullptr;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
@@ -85,7 +107,7 @@ struct sae_ctx {
   bool ev_init = false;
 };
 
-static int dominant_kid(const sae_ctx* c) { return c->use_fused_bwd ? KID_BWD_FUSED : KID_DW; }
+static int dominant_kid(const sae_ctx* c) { return c->topk ? KID_TK_ENC : (c->use_fused_bwd ? KID_BWD_FUSED : KID_DW); }
 static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
   if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
     EvRing& r = c->ev[kid];
@@ -105,11 +127,77 @@ extern "C" int sae_version(void) { return 1; }
 extern "C" const char* sae_kernel_name(int id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : nullptr; }
 extern "C" int sae_dominant_kernel(sae_ctx* c) { return c ? dominant_kid(c) : KID_DW; }
 
+// ------------------------------------------------------------------------------------------
+// TopK variant: buffers
+// ------------------------------------------------------------------------------------------
+static int topk_create(sae_ctx* c, int64_t Mp) {
+  c->k = c->cfg.k;
+  c->k_aux_cap = c->d / 2 > 0 ? c->d / 2 : 1;           // k_aux = x.shape[-1] // 2 (topkautoencoder.py:110)
+  if (c->k_aux_cap > 1024) return fail(SAE_ERR_INVALID, "topk: d_model/2 = %d aux latents exceed the 1024 supported", c->k_aux_cap);
+  c->nparams = 2 * c->nW + c->n_p + c->d_p;
+  const int64_t ntail = SAE_NUM_METRICS + c->n_p;       // metrics + did_fire flags ride in the all-reduced buffer
+  const int tiles = (c->n_p / 128) * (c->d_p / 128);
+  int splits = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
+  if (splits > 64) splits = 64;
+  c->dw_splits = splits;
+#define TALLOC(ptr, bytes)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                                              \
+    if (e_ != hipSuccess)                                                                                    \
+      return fail(SAE_ERR_HIP, "hipMalloc(%lld bytes) for %s failed: %s", (long long)(bytes), #ptr, hipGetErrorString(e_)); \
+  } while (0)
+  TALLOC(c->P, c->nparams * 4);
+  TALLOC(c->Mom, c->nparams * 4);
+  TALLOC(c->Var, c->nparams * 4);
+  TALLOC(c->G, (c->nparams + ntail) * 4);
+  TALLOC(c->We_b, c->nW * 2);
+  TALLOC(c->Wd_b, c->nW * 2);
+  TALLOC(c->xs, Mp * c->d_p * 2);
+  TALLOC(c->pre, Mp * c->n_p * 2);
+  TALLOC(c->dense, Mp * c->n_p * 2);
+  TALLOC(c->aux_dense, Mp * c->n_p * 2);
+  TALLOC(c->dpre, Mp * c->n_p * 2);
+  TALLOC(c->de_b, Mp * c->d_p * 2);
+  TALLOC(c->dh_b, Mp * c->d_p * 2);
+  TALLOC(c->e, Mp * c->d_p * 4);
+  TALLOC(c->dh, Mp * c->d_p * 4);
+  TALLOC(c->e2_part, Mp * 4);
+  TALLOC(c->a2_part, Mp * 4);
+  TALLOC(c->dbd_part, (Mp / 128 + 1) * c->d_p * 4);
+  TALLOC(c->ds_part, (Mp / 128) * c->d_p * 4);
+  TALLOC(c->db_part, (Mp / 128) * c->n_p * 4);
+  TALLOC(c->tkf, 64);
+  TALLOC(c->tk, 64);
+  TALLOC(c->top_idx, Mp * c->k * 4);
+  TALLOC(c->aux_idx, Mp * c->k_aux_cap * 4);
+  TALLOC(c->tv_part, ((Mp * c->d + 255) / 256 + 1) * 8);
+  TALLOC(c->nfsf, (size_t)c->n_p * 8);
+  TALLOC(c->dead, c->n_p);
+  TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * c->nW * 4);
+  TALLOC(c->gn_part, 1024 * 8);
+#undef TALLOC
+  HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
+  HIP_TRY(hipMemset(c->Mom, 0, c->nparams * 4));
+  HIP_TRY(hipMemset(c->Var, 0, c->nparams * 4));
+  HIP_TRY(hipMemset(c->G, 0, (c->nparams + ntail) * 4));
+  HIP_TRY(hipMemset(c->nfsf, 0, (size_t)c->n_p * 8));
+  for (auto& r : c->ev)
+    for (int i = 0; i < EV_RING; ++i) {
+      hipEventCreate(&r.beg[i]);
+      hipEventCreate(&r.end[i]);
+    }
+  c->ev_init = true;
+  HIP_TRY(hipDeviceSynchronize());
+  return SAE_OK;
+}
+
 extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device_id);
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
-                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->Wp};
+                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->Wp,
+                  c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
+                  c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->ev_init)
@@ -124,8 +212,10 @@ extern "C" void sae_destroy(sae_ctx* c) {
 extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   if (!cfg || !out) return fail(SAE_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (cfg->variant != SAE_VARIANT_L1)
-    return fail(SAE_ERR_INVALID, "variant %d not supported by this build (only SAE_VARIANT_L1)", cfg->variant);
+  if (cfg->variant != SAE_VARIANT_L1 && cfg->variant != SAE_VARIANT_TOPK)
+    return fail(SAE_ERR_INVALID, "Invalid autoencoder variant: %d, must be 'l1' or 'topk'", cfg->variant);
+  if (cfg->variant == SAE_VARIANT_TOPK && (cfg->k <= 0 || cfg->k > cfg->n_dict || cfg->k > 1024))
+    return fail(SAE_ERR_INVALID, "topk: k=%d must be in [1, min(n_dict, 1024)]", cfg->k);
   if (cfg->d_model <= 0 || cfg->n_dict <= 0 || cfg->max_rows <= 0)
     return fail(SAE_ERR_INVALID, "d_model, n_dict and max_rows must be positive");
   if (cfg->optimizer != SAE_OPT_RADAM && cfg->optimizer != SAE_OPT_ADAM)
@@ -144,7 +234,17 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   c->max_rows_p = round_up(cfg->max_rows, 128);
   c->nW = (int64_t)c->d_p * c->n_p;
   c->nparams = c->nW + c->n_p;
+  c->topk = cfg->variant == SAE_VARIANT_TOPK;
   const int64_t Mp = c->max_rows_p;
+  if (c->topk) {
+    int rc_tk = topk_create(c, Mp);
+    if (rc_tk) {
+      sae_destroy(c);
+      return rc_tk;
+    }
+    *out = c;
+    return SAE_OK;
+  }
   const int out_tiles = (c->d_p / 128) * (c->n_p / 128);
   const int ktiles = (int)(2 * Mp / 64);
   c->dw_splits = 512 / out_tiles;
@@ -241,18 +341,47 @@ static int xfer_flat(sae_ctx* c, float* internal, float* w_ext, float* b_ext, in
   return SAE_OK;
 }
 
-extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, const float*, const float*, int is_device) {
+// TopK flat layout: [We [n_p][d_p] | be [n_p] | Wd [n_p][d_p] | bd [d_p]]; reference tensors We[n][d], be[n], Wd[n][d], bd[d]
+static int xfer_flat_topk(sae_ctx* c, float* internal, float* const ext[4], int to_internal, int is_device) {
+  const int64_t off[4] = {0, c->nW, c->nW + c->n_p, 2 * c->nW + c->n_p};
+  hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : (to_internal ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+  for (int i = 0; i < 4; ++i) {
+    if (!ext[i]) continue;
+    float* in = internal + off[i];
+    if (i == 0 || i == 2) {
+      int rc = to_internal ? copy2d(in, (size_t)c->d_p * 4, ext[i], (size_t)c->d * 4, (size_t)c->d * 4, c->n, 1, is_device)
+                           : copy2d(ext[i], (size_t)c->d * 4, in, (size_t)c->d_p * 4, (size_t)c->d * 4, c->n, 0, is_device);
+      if (rc) return rc;
+    } else {
+      const size_t bytes = (size_t)(i == 1 ? c->n : c->d) * 4;
+      if (to_internal) HIP_TRY(hipMemcpy(in, ext[i], bytes, kind));
+      else HIP_TRY(hipMemcpy(ext[i], in, bytes, kind));
+    }
+  }
+  return SAE_OK;
+}
+
+extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, const float* p2, const float* p3, int is_device) {
   if (!c || !p0 || !p1) return fail(SAE_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device_id));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
+  if (c->topk) {
+    if (!p2 || !p3) return fail(SAE_ERR_INVALID, "topk needs 4 parameter tensors");
+    float* const ext[4] = {const_cast<float*>(p0), const_cast<float*>(p1), const_cast<float*>(p2), const_cast<float*>(p3)};
+    return xfer_flat_topk(c, c->P, ext, 1, is_device);
+  }
   return xfer_flat(c, c->P, const_cast<float*>(p0), const_cast<float*>(p1), 1, is_device);
 }
 
-extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float*, float*, int is_device) {
+extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float* p2, float* p3, int is_device) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device_id));
   HIP_TRY(hipDeviceSynchronize());
+  if (c->topk) {
+    float* const ext[4] = {p0, p1, p2, p3};
+    return xfer_flat_topk(c, c->P, ext, 0, is_device);
+  }
   return xfer_flat(c, c->P, p0, p1, 0, is_device);
 }
 
@@ -263,6 +392,18 @@ extern "C" int sae_set_opt_state(sae_ctx* c, int64_t step, const float* const ex
   HIP_TRY(hipDeviceSynchronize());
   c->step = step;
   int rc = SAE_OK;
+  if (c->topk) {
+    if (exp_avg) {
+      float* const ext[4] = {const_cast<float*>(exp_avg[0]), const_cast<float*>(exp_avg[1]), const_cast<float*>(exp_avg[2]), const_cast<float*>(exp_avg[3])};
+      rc = xfer_flat_topk(c, c->Mom, ext, 1, is_device);
+      if (rc) return rc;
+    }
+    if (exp_avg_sq) {
+      float* const ext[4] = {const_cast<float*>(exp_avg_sq[0]), const_cast<float*>(exp_avg_sq[1]), const_cast<float*>(exp_avg_sq[2]), const_cast<float*>(exp_avg_sq[3])};
+      rc = xfer_flat_topk(c, c->Var, ext, 1, is_device);
+    }
+    return rc;
+  }
   if (exp_avg) rc = xfer_flat(c, c->Mom, const_cast<float*>(exp_avg[0]), const_cast<float*>(exp_avg[1]), 1, is_device);
   if (rc) return rc;
   if (exp_avg_sq) rc = xfer_flat(c, c->Var, const_cast<float*>(exp_avg_sq[0]), const_cast<float*>(exp_avg_sq[1]), 1, is_device);
@@ -276,6 +417,12 @@ extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg
   HIP_TRY(hipDeviceSynchronize());
   if (step) *step = c->step;
   int rc = SAE_OK;
+  if (c->topk) {
+    if (exp_avg) rc = xfer_flat_topk(c, c->Mom, exp_avg, 0, is_device);
+    if (rc) return rc;
+    if (exp_avg_sq) rc = xfer_flat_topk(c, c->Var, exp_avg_sq, 0, is_device);
+    return rc;
+  }
   if (exp_avg) rc = xfer_flat(c, c->Mom, exp_avg[0], exp_avg[1], 0, is_device);
   if (rc) return rc;
   if (exp_avg_sq) rc = xfer_flat(c, c->Var, exp_avg_sq[0], exp_avg_sq[1], 0, is_device);
@@ -285,7 +432,7 @@ extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg
 extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
   if (!c || !dev_ptr || !n_floats) return fail(SAE_ERR_INVALID, "null argument");
   *dev_ptr = c->G;
-  *n_floats = c->nparams + SAE_NUM_METRICS;
+  *n_floats = c->nparams + SAE_NUM_METRICS + (c->topk ? c->n_p : 0);   // TopK: + did_fire flags (OR == sum > 0)
   return SAE_OK;
 }
 
@@ -466,12 +613,170 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   return SAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// TopK variant: one train step's forward + backward (topkautoencoder.py:93-151, train_sae.py:436-448)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool backward) {
+  const int d = c->d, n = c->n, d_p = c->d_p, n_p = c->n_p, k = c->k;
+  const int64_t Mp = round_up(M, 128);
+  const int64_t T_rows = (c->rows_per_file > 0 && M % c->rows_per_file == 0) ? c->rows_per_file : M;
+  const int B = (int)(M / T_rows);
+  const float alpha = (float)c->cfg.auxk_alpha;
+  float* We = c->P;
+  float* be = c->P + c->nW;
+  float* Wd = c->P + c->nW + n_p;
+  float* bd = c->P + 2 * c->nW + n_p;
+  float* gWe = c->G;
+  float* gbe = c->G + c->nW;
+  float* gWd = c->G + c->nW + n_p;
+  float* gbd = c->G + 2 * c->nW + n_p;
+  float* metrics = c->G + c->nparams;
+  float* did_fire = metrics + SAE_NUM_METRICS;
+  int rc;
+  ev_begin(c, KID_STEP_TOTAL, s);
+
+  // dead mask from num_frames_since_fired; the number of dead latents decides whether the AuxK branch runs
+  hipLaunchKernelGGL(dead_mask_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
+                     c->tkf);
+  int num_dead = 0;
+  HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const bool aux = num_dead > 0 && alpha != 0.f;
+
+  {
+    const int64_t n8 = c->nW / 8;
+    int grid = (int)((n8 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, We, c->We_b, n8);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, Wd, c->Wd_b, n8);
+    const int64_t chunks = Mp * (d_p / 8);
+    int g2 = (int)((chunks + 255) / 256);
+    if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(topk_prep_x_kernel<T>, dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
+    const int64_t TD = T_rows * d;
+    hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
+  }
+  {  // pre = relu(sae_in We^T + be)
+    GemmArgs g{};
+    g.A0 = c->xs; g.B0 = c->We_b; g.lda = d_p; g.ldb = d_p;
+    g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+    EpiTopkEnc e{};
+    e.pre = c->pre; e.bias = be; e.M = M; e.n_p = n_p;
+    ev_begin(c, KID_TK_ENC, s);
+    rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+    ev_end(c, KID_TK_ENC, s);
+    if (rc) return rc;
+  }
+  ev_begin(c, KID_TK_SELECT, s);
+  hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->dense, c->top_idx, did_fire,
+                     (const unsigned char*)nullptr, (const int*)nullptr, k, k, n, n_p);
+  if (aux)
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense, c->aux_idx,
+                       (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p);
+  ev_end(c, KID_TK_SELECT, s);
+  ev_begin(c, KID_TK_DECODE, s);
+  hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)Mp), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b, bd, c->e,
+                     c->dh, c->e2_part, M, d, d_p, n_p, 0);
+  if (aux)
+    hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)Mp), dim3(256), 0, s, x, c->aux_dense, c->aux_idx, c->k_aux_cap,
+                       c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1);
+  const int64_t TD = T_rows * d;
+  hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
+                     aux ? c->a2_part : (const float*)nullptr, Mp, M, d, alpha, c->tk, c->tkf, metrics, (float)n);
+  ev_end(c, KID_TK_DECODE, s);
+  if (backward) {
+    const int rpb = 256;
+    const int nrb = (int)((Mp + rpb - 1) / rpb);
+    hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
+                       c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0);
+    {  // dpre = [selected] (de W_dec^T)  (+ aux part)
+      GemmArgs g{};
+      g.A0 = c->de_b; g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
+      g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+      EpiTopkDpre e{};
+      e.sel = c->dense; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = 0; e.last = aux ? 0 : 1;
+      ev_begin(c, KID_TK_DDENSE, s);
+      rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+      if (!rc && aux) {
+        g.A0 = c->dh_b;
+        e.sel = c->aux_dense; e.accumulate = 1; e.last = 1;
+        rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+      }
+      ev_end(c, KID_TK_DDENSE, s);
+      if (rc) return rc;
+    }
+    const int splits = c->dw_splits;
+    {  // dW_dec[n][d] = dense^T de (+ aux_dense^T de_hat)
+      GemmArgs g{};
+      g.A0 = c->dense; g.B0 = c->de_b; g.A1 = c->aux_dense; g.B1 = c->dh_b; g.lda = n_p; g.ldb = d_p;
+      g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = aux ? 2 * g.ktiles0 : g.ktiles0;
+      g.splits = splits > g.ktiles ? g.ktiles : splits;
+      EpiSlab e{};
+      e.slab = g.splits > 1 ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
+      ev_begin(c, KID_TK_DWD, s);
+      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+      if (!rc && g.splits > 1) {
+        const int64_t n4 = c->nW / 4;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWd, n4, n4, g.splits);
+      }
+      ev_end(c, KID_TK_DWD, s);
+      if (rc) return rc;
+    }
+    {  // dW_enc[n][d] = dpre^T sae_in
+      GemmArgs g{};
+      g.A0 = c->dpre; g.B0 = c->xs; g.lda = n_p; g.ldb = d_p;
+      g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
+      g.splits = splits > g.ktiles ? g.ktiles : splits;
+      EpiSlab e{};
+      e.slab = g.splits > 1 ? c->slab : gWe; e.slab_stride = c->nW; e.ld = d_p;
+      ev_begin(c, KID_TK_DWE, s);
+      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+      if (!rc && g.splits > 1) {
+        const int64_t n4 = c->nW / 4;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWe, n4, n4, g.splits);
+      }
+      ev_end(c, KID_TK_DWE, s);
+      if (rc) return rc;
+    }
+    {  // dsae_in = dpre We : only its column sums reach a parameter (b_dec)
+      GemmArgs g{};
+      g.A0 = c->dpre; g.B0 = c->We_b; g.lda = n_p; g.ldb = d_p;
+      g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
+      EpiTopkDsaeIn e{};
+      e.part = c->ds_part; e.d_p = d_p;
+      ev_begin(c, KID_TK_DSAE, s);
+      rc = launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
+      ev_end(c, KID_TK_DSAE, s);
+      if (rc) return rc;
+    }
+    ev_begin(c, KID_REDUCE, s);
+    hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
+    hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, (int)(Mp / 128),
+                       gbd, d_p);
+    ev_end(c, KID_REDUCE, s);
+  }
+  ev_end(c, KID_STEP_TOTAL, s);
+  HIP_TRY(hipGetLastError());
+  c->last_M = M;
+  c->last_M_p = Mp;
+  return SAE_OK;
+}
+
 static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream, bool backward) {
   if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
   if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
   HIP_TRY(hipSetDevice(c->cfg.device_id));
   hipStream_t s = (hipStream_t)stream;
   c->last_dtype = x_dtype;
+  if (c->topk) {
+    switch (x_dtype) {
+      case SAE_DTYPE_F32: return topk_fwd_bwd<float>(c, (const float*)x, M, s, backward);
+      case SAE_DTYPE_F16: return topk_fwd_bwd<_Float16>(c, (const _Float16*)x, M, s, backward);
+      case SAE_DTYPE_BF16: return topk_fwd_bwd<bf16_t>(c, (const bf16_t*)x, M, s, backward);
+      default: return fail(SAE_ERR_INVALID, "unknown x_dtype %d", x_dtype);
+    }
+  }
   switch (x_dtype) {
     case SAE_DTYPE_F32: return fwd_bwd_impl<float>(c, (const float*)x, M, s, backward);
     case SAE_DTYPE_F16: return fwd_bwd_impl<_Float16>(c, (const _Float16*)x, M, s, backward);
@@ -523,8 +828,19 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   if (oblocks > 2048) oblocks = 2048;
   hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
                      a, c->G + c->nparams);
+  if (c->topk)   // train_sae.py:443-446 with the (possibly data-parallel summed) did_fire flags
+    hipLaunchKernelGGL(nfsf_update_kernel, dim3((c->n + 255) / 256), dim3(256), 0, s, c->nfsf, c->G + c->nparams + SAE_NUM_METRICS,
+                       c->n, (long long)(c->last_M * (grad_scale > 0 ? (long long)llround(1.0 / grad_scale) : 1)));
   ev_end(c, KID_OPT, s);
   HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
+extern "C" int sae_set_topk_options(sae_ctx* c, double dead_feature_threshold, int64_t rows_per_file) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->topk) return fail(SAE_ERR_STATE, "not a topk context");
+  c->dead_threshold = dead_feature_threshold;
+  c->rows_per_file = rows_per_file;
   return SAE_OK;
 }
 
@@ -551,7 +867,8 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     const int cols = which == 0 ? c->n : c->d, ld = which == 0 ? c->n_p : c->d_p;
     if (cap < M * cols) return fail(SAE_ERR_INVALID, "capacity too small");
     std::vector<uint16_t> tmp((size_t)M * ld);
-    HIP_TRY(hipMemcpy(tmp.data(), which == 0 ? (void*)c->c : (void*)c->dxh, tmp.size() * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tmp.data(), which == 0 ? (c->topk ? (void*)c->dense : (void*)c->c) : (c->topk ? (void*)c->de_b : (void*)c->dxh),
+                      tmp.size() * 2, hipMemcpyDeviceToHost));
     for (int64_t r = 0; r < M; ++r)
       for (int j = 0; j < cols; ++j) {
         uint32_t u = (uint32_t)tmp[(size_t)r * ld + j] << 16;
@@ -559,6 +876,19 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
         memcpy(&f, &u, 4);
         out[r * cols + j] = f;
       }
+    return SAE_OK;
+  }
+  if (which == 2 && c->topk) {
+    const int64_t nd = (int64_t)c->n * c->d;
+    if (cap < 2 * nd + c->n + c->d) return fail(SAE_ERR_INVALID, "capacity too small");
+    float* const ext[4] = {out, out + nd, out + nd + c->n, out + 2 * nd + c->n};
+    return xfer_flat_topk(c, c->G, ext, 0, 0);
+  }
+  if (which == 3 && c->topk) {   // top-k indices of the last step as floats [M][k]
+    if (cap < M * c->k) return fail(SAE_ERR_INVALID, "capacity too small");
+    std::vector<int> tmp((size_t)M * c->k);
+    HIP_TRY(hipMemcpy(tmp.data(), c->top_idx, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); ++i) out[i] = (float)tmp[i];
     return SAE_OK;
   }
   if (which == 2) {
@@ -580,7 +910,8 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   const int rows_per_block = 256;
   dim3 grid(c->n_p / 128 / 2 > 0 ? c->n_p / 256 : 1, (unsigned)((c->last_M + rows_per_block - 1) / rows_per_block));
   if (c->n_p % 256 != 0) grid.x = (c->n_p + 255) / 256;
-  hipLaunchKernelGGL(latent_colmax_kernel, grid, dim3(256), 0, s, c->c, bits, c->last_M, c->n_p, rows_per_block);
+  hipLaunchKernelGGL(latent_colmax_kernel, grid, dim3(256), 0, s, c->topk ? c->dense : c->c, bits, c->last_M, c->n_p,
+                     rows_per_block);
   HIP_TRY(hipGetLastError());
   std::vector<float> tmp(c->n_p);
   HIP_TRY(hipMemcpyAsync(tmp.data(), bits, (size_t)c->n_p * 4, hipMemcpyDeviceToHost, s));

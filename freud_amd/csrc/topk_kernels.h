@@ -1,0 +1,420 @@
+// Kernels of the TopK SAE train step (reference: src/models/topkautoencoder.py:72-151 and the bookkeeping
+// in src/scripts/train_sae.py:424-446).  The dense encoder GEMM and the backward GEMMs reuse gemm.h; this
+// file holds the epilogues and the non-GEMM stages: activation prep, per-row top-k selection (radix select
+// on the bf16 bit patterns in LDS), sparse decode + losses, total variance, dead-latent bookkeeping.
+#pragma once
+#include "gemm.h"
+#include "l1_kernels.h"
+
+// fp32 master -> bf16 GEMM operand copy (both weight matrices, once per step)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+    bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    reinterpret_cast<bf16x8*>(dst)[i] = o;
+  }
+}
+
+// sae_in = bf16(x - b_dec) (topkautoencoder.py:74), zero padded to [M_p][d_p]
+template <typename T>
+__global__ __launch_bounds__(256) void topk_prep_x_kernel(const T* __restrict__ x, const float* __restrict__ b_dec,
+                                                           bf16_t* __restrict__ xs, int64_t M, int d, int64_t M_p, int d_p) {
+  const unsigned int cpr = (unsigned int)d_p >> 3;
+  const unsigned int total = (unsigned int)(M_p * cpr);
+  for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int64_t row = i / cpr;
+    const int c0 = (int)(i - (unsigned int)row * cpr) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (row < M && c0 + j < d) v = (float)x[row * d + c0 + j] - b_dec[c0 + j];
+      o[j] = (bf16_t)v;
+    }
+    *reinterpret_cast<bf16x8*>(xs + row * d_p + c0) = o;
+  }
+}
+
+// total_variance = sum (x - mean over files)^2 (topkautoencoder.py:104-106); x viewed as [B][T*d].
+// One thread per (t, feature) column; fixed-order partial sums per block.
+template <typename T>
+__global__ __launch_bounds__(256) void total_variance_kernel(const T* __restrict__ x, int B, int64_t TD, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double s = 0;
+  if (j < TD) {
+    float mean = 0.f;
+    for (int b = 0; b < B; ++b) mean += (float)x[(int64_t)b * TD + j];
+    mean /= (float)B;
+    for (int b = 0; b < B; ++b) {
+      const float dlt = (float)x[(int64_t)b * TD + j] - mean;
+      s += (double)(dlt * dlt);
+    }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dead_mask = num_frames_since_fired > threshold (train_sae.py:436-439); tk[0] = num_dead, tk[1] = k_aux,
+// tkf[0] = aux scale = min(num_dead / (d/2), 1) (topkautoencoder.py:111-115).  One block.
+__global__ __launch_bounds__(1024) void dead_mask_kernel(const long long* __restrict__ nfsf, unsigned char* __restrict__ dead,
+                                                          float* __restrict__ did_fire, int n, int n_p, double threshold,
+                                                          int d, int* __restrict__ tk, float* __restrict__ tkf) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < n_p; i += 1024) {
+    const bool dd = i < n && (double)nfsf[i] > threshold;
+    dead[i] = dd;
+    did_fire[i] = 0.f;
+    c += dd;
+  }
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int k_aux_full = d / 2;
+    tk[0] = cnt;
+    tk[1] = cnt < k_aux_full ? cnt : k_aux_full;
+    tkf[0] = fminf((float)cnt / (float)k_aux_full, 1.0f);
+  }
+}
+
+// encoder epilogue: pre = relu(bf16(acc + bias)) (Linear under autocast: bf16 addmm, one rounding), rows >= M zero
+struct EpiTopkEnc {
+  bf16_t* pre;          // [M_p][n_p]
+  const float* bias;    // [n_p] (fp32 master; rounded to bf16 as autocast casts it)
+  int64_t M;
+  int n_p;
+  __device__ void tile_begin(int, int, int) {}
+  __device__ void apply(int row, int col, f32x4 v) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float p = fmaxf(bf16_round(v[j] + bf16_round(b[j])), 0.f);
+      if (row >= M) p = 0.f;
+      o[j] = (bf16_t)p;
+    }
+    *reinterpret_cast<bf16x4*>(pre + (int64_t)row * n_p + col) = o;
+  }
+  __device__ void tile_end(float*) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// per-row top-k: one workgroup per row.  Values are non-negative bf16 (post-ReLU), so their 16-bit patterns
+// order like the values: two-level radix select (high byte, low byte) on LDS histograms finds the k-th largest
+// pattern `thr`; every element > thr is selected, ties at thr are taken in increasing column order.
+// Writes the masked dense row (selected activations, zeros elsewhere) and marks did_fire.
+// With `dead` != null only dead latents compete (where(dead, pre, -inf), topkautoencoder.py:118-121).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
+                                                           int* __restrict__ top_idx, float* __restrict__ did_fire,
+                                                           const unsigned char* __restrict__ dead, const int* __restrict__ k_ptr,
+                                                           int k_fixed, int kcap, int n, int n_p) {
+  __shared__ int hist[256];
+  __shared__ int sel_hi, need, sel_lo, ngt, ntie;
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int k = k_ptr ? *k_ptr : k_fixed;
+  const unsigned short* p = reinterpret_cast<const unsigned short*>(pre + row * n_p);
+  unsigned short* o = reinterpret_cast<unsigned short*>(dense + row * n_p);
+  int* ti = top_idx + row * kcap;
+  if (k <= 0) {
+    for (int i = t; i < n_p; i += 256) o[i] = 0;
+    return;
+  }
+  auto key = [&](int i) -> int {       // 16-bit key; -1 = not a candidate
+    if (i >= n) return -1;
+    if (dead && !dead[i]) return -1;
+    return (int)p[i];
+  };
+  // ---- level 1: histogram of the high byte
+  hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < n_p; i += 256) {
+    const int kk = key(i);
+    if (kk >= 0) atomicAdd(&hist[kk >> 8], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0, b = 255;
+    for (; b >= 0; --b) {
+      if (acc + hist[b] >= k) break;
+      acc += hist[b];
+    }
+    if (b < 0) b = 0;
+    sel_hi = b;
+    need = k - acc;      // how many to take from bin b
+  }
+  __syncthreads();
+  const int hi = sel_hi;
+  __syncthreads();
+  hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < n_p; i += 256) {
+    const int kk = key(i);
+    if (kk >= 0 && (kk >> 8) == hi) atomicAdd(&hist[kk & 255], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0, b = 255;
+    for (; b >= 0; --b) {
+      if (acc + hist[b] >= need) break;
+      acc += hist[b];
+    }
+    if (b < 0) b = 0;
+    sel_lo = b;
+    ntie = need - acc;   // how many elements equal to thr to take
+    ngt = 0;
+  }
+  __syncthreads();
+  const int thr = (hi << 8) | sel_lo;
+  const int take_ties = ntie;
+  // ---- emit: elements > thr unconditionally; ties in increasing column order (wave/block ordered scan)
+  __shared__ int wave_cnt[4];
+  __shared__ int tie_base, out_pos;
+  if (t == 0) {
+    tie_base = 0;
+    out_pos = 0;
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n_p; i0 += 256) {
+    const int i = i0 + t;
+    const int kk = key(i);
+    const bool gt = kk > thr;
+    const bool tie = kk == thr;
+    // ordered rank among ties in this chunk
+    const unsigned long long tb = __ballot(tie);
+    const int lane = t & 63, w = t >> 6;
+    const int before_in_wave = __popcll(tb & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[w] = __popcll(tb);
+    __syncthreads();
+    int before = tie_base + before_in_wave;
+    for (int ww = 0; ww < w; ++ww) before += wave_cnt[ww];
+    const bool take = gt || (tie && before < take_ties);
+    unsigned short val = 0;
+    if (take) {
+      val = (unsigned short)kk;
+      const int pos = atomicAdd(&out_pos, 1);
+      if (pos < kcap) ti[pos] = i;
+      if (did_fire) did_fire[i] = 1.0f;
+    }
+    if (i < n_p) o[i] = val;
+    __syncthreads();
+    if (t == 0) tie_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  // pad the index list (fewer than kcap candidates, e.g. k_aux < kcap)
+  __syncthreads();
+  for (int j = out_pos + t; j < kcap; j += 256) ti[j] = -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse decode + losses: x_hat = bf16(sum_j act_j W_dec[idx_j]) + b_dec ; e = x_hat - x
+// (topkautoencoder.py:15-18,87-91,101-102).  One workgroup per activation row, threads over d.
+// pass 0 (aux == 0): writes e (fp32) and sum e^2, sum over valid elements.
+// pass 1 (aux == 1): e_hat from the aux selection, accumulates sum (e_hat - e)^2 and writes dh = e_hat - e.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ dense,
+                                                           const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
+                                                           const float* __restrict__ b_dec, float* __restrict__ e,
+                                                           float* __restrict__ dh, float* __restrict__ part, int64_t M, int d,
+                                                           int d_p, int n_p, int aux) {
+  __shared__ float red[8];
+  __shared__ int s_idx[1024];
+  __shared__ float s_act[1024];
+  const int64_t row = blockIdx.x;
+  const int t = threadIdx.x;
+  for (int j = t; j < kcap; j += 256) {
+    const int ii = idx[row * kcap + j];
+    s_idx[j] = ii;
+    s_act[j] = ii >= 0 ? (float)dense[row * n_p + ii] : 0.f;
+  }
+  __syncthreads();
+  float sq = 0.f;
+  for (int c = t; c < d_p; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < kcap; ++j) {
+      const int ii = s_idx[j];
+      if (ii >= 0) acc += s_act[j] * (float)Wd[(int64_t)ii * d_p + c];
+    }
+    float out = 0.f;
+    if (row < M && c < d) {
+      const float xh = bf16_round(acc) + b_dec[c];
+      if (!aux) {
+        out = xh - (float)x[row * d + c];
+        sq += out * out;
+      } else {
+        out = xh - e[row * d_p + c];                               // e_hat - e: the aux decode predicts the residual
+        sq += out * out;
+      }
+    }
+    if (!aux) e[row * d_p + c] = out;
+    else dh[row * d_p + c] = out;
+  }
+  const float s = block_sum_256(sq, red);
+  if (t == 0) part[row] = s;
+}
+
+// tkf: [0] aux scale, [1] total_variance, [2] fvu, [3] auxk*alpha, [4] mse, [5] coef = alpha*scale*2/tv
+__global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __restrict__ tv_part, int n_tv,
+                                                             const float* __restrict__ e2_part, const float* __restrict__ a2_part,
+                                                             int64_t Mp, int64_t M, int d, float auxk_alpha, const int* tk,
+                                                             float* __restrict__ tkf, float* __restrict__ metrics,
+                                                             float dead_frac_n) {
+  __shared__ double red[3][4];
+  double a = 0, b = 0, c = 0;
+  for (int i = threadIdx.x; i < n_tv; i += 256) a += tv_part[i];
+  for (int64_t i = threadIdx.x; i < Mp; i += 256) {
+    b += (double)e2_part[i];
+    if (a2_part) c += (double)a2_part[i];
+  }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+    red[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double e2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double a2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    if (tv == 0) tv = 1.0;
+    const float tvf = (float)tv;
+    const float scale = tkf[0];
+    tkf[1] = tvf;
+    const float fvu = (float)e2 / tvf;
+    const float auxk = (tk[0] > 0 && a2_part) ? (scale * (float)a2 / tvf) * auxk_alpha : 0.f;
+    tkf[5] = (tk[0] > 0 && a2_part) ? auxk_alpha * scale * 2.0f / tvf : 0.f;
+    metrics[0] = fvu;
+    metrics[1] = auxk;
+    metrics[2] = (float)(e2 / ((double)M * d));
+    metrics[3] = 0.f;
+    metrics[4] = 0.f;
+    metrics[5] = (float)tk[0] / dead_frac_n;   // dead_pct (train/dead_pct, train_sae.py:481-485)
+    metrics[6] = metrics[7] = 0.f;
+  }
+}
+
+// de = 2 e / tv - de_hat,  de_hat = coef (e_hat - e)  -> bf16 GEMM operands; column sums for d b_dec
+__global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ e, const float* __restrict__ dh,
+                                                       const float* __restrict__ tkf, bf16_t* __restrict__ de_b,
+                                                       bf16_t* __restrict__ dh_b, float* __restrict__ dbd_part, int64_t Mp,
+                                                       int d_p, int rows_per_block, int use_aux) {
+  // grid (d_p / 256, ceil(Mp / rows_per_block)); thread = one column, fixed row order
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < Mp ? r0 + rows_per_block : Mp;
+  const float two_over_tv = 2.0f / tkf[1], coef = tkf[5];
+  float s = 0.f;
+  if (c < d_p)
+    for (int64_t r = r0; r < r1; ++r) {
+      const float ev = e[r * d_p + c];
+      float g = ev * two_over_tv, gh = 0.f;
+      if (use_aux) {
+        gh = coef * dh[r * d_p + c];
+        g -= gh;
+        dh_b[r * d_p + c] = (bf16_t)gh;
+      }
+      de_b[r * d_p + c] = (bf16_t)g;
+      s += g + gh;                        // d b_dec gets de + de_hat (both decoders add b_dec)
+    }
+  if (c < d_p) dbd_part[(int64_t)blockIdx.y * d_p + c] = s;
+}
+
+// ddense epilogue: dpre = [selected] * bf16(de . W_dec^T) (+ aux part), gated by pre > 0; column sums -> d b_enc
+struct EpiTopkDpre {
+  const bf16_t* sel;    // masked dense activations of this pass (selection mask = value > 0)
+  bf16_t* dpre;         // [M_p][n_p]
+  float* dbe_part;      // [nbm][n_p] (only written when `last`)
+  int n_p, accumulate, last;
+  float colsum[4];
+  int row_tile, col0_;
+  __device__ void tile_begin(int row0, int col0, int) {
+    colsum[0] = colsum[1] = colsum[2] = colsum[3] = 0.f;
+    row_tile = row0 / GEMM_BM;
+    col0_ = col0;
+  }
+  __device__ void apply(int row, int col, f32x4 v) {
+    const int64_t o = (int64_t)row * n_p + col;
+    const bf16x4 sv = *reinterpret_cast<const bf16x4*>(sel + o);
+    bf16x4 prev = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (accumulate) prev = *reinterpret_cast<const bf16x4*>(dpre + o);
+    bf16x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = ((float)sv[j] > 0.f) ? bf16_round(v[j]) : 0.f;
+      g += (float)prev[j];
+      colsum[j] += g;
+      out[j] = (bf16_t)g;
+    }
+    *reinterpret_cast<bf16x4*>(dpre + o) = out;
+  }
+  __device__ void tile_end(float* scratch) {
+    if (!last) return;
+    const int t = threadIdx.x;
+    f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
+    *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
+    __syncthreads();
+    if (t < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += scratch[g * 128 + t];
+      dbe_part[(int64_t)row_tile * n_p + col0_ + t] = s;
+    }
+  }
+};
+
+// dsae_in epilogue: only its column sums are needed (d b_dec -= sum_rows dsae_in, topkautoencoder.py:74)
+struct EpiTopkDsaeIn {
+  float* part;          // [nbm][d_p]
+  int d_p;
+  float colsum[4];
+  int row_tile, col0_;
+  __device__ void tile_begin(int row0, int col0, int) {
+    colsum[0] = colsum[1] = colsum[2] = colsum[3] = 0.f;
+    row_tile = row0 / GEMM_BM;
+    col0_ = col0;
+  }
+  __device__ void apply(int, int, f32x4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) colsum[j] += bf16_round(v[j]);
+  }
+  __device__ void tile_end(float* scratch) {
+    const int t = threadIdx.x;
+    f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
+    *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
+    __syncthreads();
+    if (t < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += scratch[g * 128 + t];
+      part[(int64_t)row_tile * d_p + col0_ + t] = s;
+    }
+  }
+};
+
+// d b_dec[c] = sum_blocks dbd_part[.][c] - sum_tiles dsae_part[.][c]
+__global__ __launch_bounds__(256) void topk_dbd_kernel(const float* __restrict__ dbd_part, int nb, const float* __restrict__ ds_part,
+                                                        int nt, float* __restrict__ out, int d_p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d_p) return;
+  float s = 0.f;
+  for (int i = 0; i < nb; ++i) s += dbd_part[(int64_t)i * d_p + c];
+  for (int i = 0; i < nt; ++i) s -= ds_part[(int64_t)i * d_p + c];
+  out[c] = s;
+}
+
+// num_frames_since_fired += rows; [did_fire] = 0 (train_sae.py:443-446).  did_fire may be a data-parallel SUM.
+__global__ __launch_bounds__(256) void nfsf_update_kernel(long long* __restrict__ nfsf, const float* __restrict__ did_fire, int n,
+                                                           long long rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) nfsf[i] = did_fire[i] > 0.f ? 0 : nfsf[i] + rows;
+}

@@ -77,6 +77,7 @@ def load() -> C.CDLL:
         "sae_forward_backward": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_grad_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_optimizer_step": (C.c_int, [vp, dbl, dbl, vp]),
+        "sae_set_topk_options": (C.c_int, [vp, dbl, i64]),
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_read_metrics": (C.c_int, [vp, fptr, vp]),
@@ -98,6 +99,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
+    "sae_set_topk_options",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
@@ -186,6 +188,14 @@ class SaeEngine:
         _check(self._lib.sae_get_opt_state(self._ctx, C.byref(step), pa, pb, 0))
         return int(step.value), a, b
 
+    def set_topk_options(self, dead_feature_threshold: float, rows_per_file: int) -> None:
+        """TopK only: autoencoder_config["dead_feature_threshold"] (train_sae.py:438) and T of the [B][T][d] batch."""
+        self._dead_threshold, self._rows_per_file = float(dead_feature_threshold), int(rows_per_file)
+        _check(self._lib.sae_set_topk_options(self._ctx, float(dead_feature_threshold), int(rows_per_file)))
+
+    def set_dead_feature_threshold(self, v: float) -> None:
+        self.set_topk_options(v, getattr(self, "_rows_per_file", 0))
+
     # -- the hot path -------------------------------------------------------------------------
     @staticmethod
     def _x_args(x):
@@ -201,6 +211,11 @@ class SaeEngine:
         rows = x.numel() // x.shape[-1]
         return x, x.data_ptr(), rows, DTYPE[name]
 
+    def _note_shape(self, x) -> None:
+        """TopK: x.mean(0) is over the files of a [B, T, d] batch -> tell the engine T when it changes."""
+        if self.variant == "topk" and x.dim() == 3 and getattr(self, "_rows_per_file", None) != x.shape[1]:
+            self.set_topk_options(getattr(self, "_dead_threshold", 1e300), x.shape[1])
+
     @staticmethod
     def _stream(stream=None):
         import torch
@@ -208,6 +223,7 @@ class SaeEngine:
         return C.c_void_p(s.cuda_stream)
 
     def forward_backward(self, x, stream=None) -> None:
+        self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_forward_backward(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
 
@@ -215,10 +231,12 @@ class SaeEngine:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))
 
     def step(self, x, lr: float, stream=None) -> None:
+        self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_step(self._ctx, C.c_void_p(ptr), rows, dt, float(lr), self._stream(stream)))
 
     def eval(self, x, stream=None) -> None:
+        self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_eval(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
 

@@ -115,6 +115,12 @@ int sae_grad_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* n_floats);
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
 int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream);
 
+/* TopK only.  dead_feature_threshold: a latent is dead when num_frames_since_fired > threshold
+ * (autoencoder_config["dead_feature_threshold"], train_sae.py:436-439).  rows_per_file: T of the
+ * [B][T][d] batch -- the FVU denominator is sum (x - x.mean(0))^2 with the mean over the B files
+ * (topkautoencoder.py:104); 0 = treat the batch as one file. */
+int sae_set_topk_options(sae_ctx* ctx, double dead_feature_threshold, int64_t rows_per_file);
+
 /* Convenience: sae_forward_backward + sae_optimizer_step(lr, 1). */
 int sae_step(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, double lr, void* stream);
 

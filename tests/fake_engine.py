@@ -29,6 +29,9 @@ class OracleEngine:
     def set_dead_feature_threshold(self, v):
         self.dead_threshold = v
 
+    def set_topk_options(self, dead_feature_threshold, rows_per_file):
+        self.dead_threshold = dead_feature_threshold
+
     def set_params(self, params):
         self.P = {k: torch.tensor(np.asarray(params[k], dtype=np.float32)).reshape(s).clone()
                   for k, s in self.param_shapes().items()}
