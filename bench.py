@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--x-dtype", default="bfloat16", choices=["bfloat16", "float16", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--variant", default="l1", choices=["l1", "topk"], help="topk = BASELINE configs[2] style run")
+    ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -94,9 +96,19 @@ def main():
     dtype = getattr(torch, args.x_dtype)
     x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype)
     x = x_cpu.cuda()
-    eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
-                    clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg)
-    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    if args.variant == "topk":
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
+                        clip_thresh=1.0, device_id=local_rank)
+        eng.set_topk_options(1e6, 1024)
+        g = torch.Generator().manual_seed(0)
+        We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
+        Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
+        eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
+                        "b_dec": np.zeros(d, np.float32)})
+    else:
+        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
+                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     grads = eng.grad_tensor() if world > 1 else None
     total_steps, base_lr = 100000, 4e-4
     lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
@@ -140,8 +152,12 @@ def main():
     # algorithmic FLOPs of the dominant kernel: fused backward = dc, dW(dec), dW(enc) GEMMs = 3 x 2*M*d*n;
     # generic path's dw_gemm = the two weight-gradient GEMMs = 2 x 2*M*d*n
     dom_flops = (6.0 if dom == "bwd_fused_gemm" else 4.0) * M * d * n
+    if args.variant == "topk":
+        dom_flops = 2.0 * M * d * n                  # the dense encoder GEMM
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12 if dom_avg_ms > 0 else 0.0
     step_flops = 10.0 * M * d * n                    # algorithmic FLOPs per activation = 10 d n
+    if args.variant == "topk":
+        step_flops = (2.0 * d * n + 10.0 * args.k * d) * M   # 2 d n + 10 k d per activation
     fb_ms, fb_cnt = times["fwd_bwd_total"]
 
     breakdown = None
@@ -170,7 +186,12 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.variant == "topk":
+        out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
+        out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "
+                                     "resident in HBM (BASELINE configs[2] shape)")
+        out["loss"] = {"fvu": float(metrics[0]), "auxk": float(metrics[1]), "grad_norm": float(metrics[3])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.variant == "l1":
         out["cpu_baseline"] = cpu_baseline(x_cpu, W, b, args.cpu_steps, base_lr)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -277,7 +277,7 @@ class SaeEngine:
         _check(self._lib.sae_profile(self._ctx, level))
 
     def kernel_times(self) -> Dict[str, tuple]:
-        n = 16
+        n = 32
         ms = (C.c_float * n)()
         cnt = (C.c_int32 * n)()
         _check(self._lib.sae_kernel_times(self._ctx, ms, cnt, n))

@@ -297,7 +297,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                 "W_dec": W_dec.numpy(), "b_dec": np.zeros(feat_dim, np.float32)}
         param_order = ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]
         state_dict_order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
-        eng.set_dead_feature_threshold(float(autoencoder_config["dead_feature_threshold"]))   # raw key, :438
+        eng.set_topk_options(float(autoencoder_config["dead_feature_threshold"]), T)   # raw key (:438); T for x.mean(0)
     eng.set_params(init)
 
     is_main = rank == 0
