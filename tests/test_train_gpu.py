@@ -63,3 +63,33 @@ def test_cuda_streamer_delivers_exact_rows(tmp_path):
             np.testing.assert_array_equal(xi.reshape(-1), rows[i])
             seen.add(i)
     assert seen == set(range(n_files))
+
+
+def test_topk_train_path_matches_reference(tmp_path, golden_dir):
+    """TopK end to end (shards -> engine -> checkpoint) against the reference's own train() run.  Boundary ties in
+    the bf16 top-k (tests/test_topk_gpu.py) make trajectories drift slightly: losses rtol 3e-2."""
+    from freud_amd.train_sae import main
+    z = np.load(os.path.join(golden_dir, "trainloop_topk.npz"))
+    meta = json.loads(str(z["meta"]))
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, meta["layer"], z["shard"], [meta["T"], meta["d"]],
+                 [f"/data/audio/file_{i:04d}.flac" for i in range(meta["n_files"])])
+    cfg = copy.deepcopy(meta["config"])
+    cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run"), device="cuda")
+    cfg_path = os.path.join(str(tmp_path), "cfg.json")
+    json.dump(cfg, open(cfg_path, "w"))
+    main(["--config", cfg_path])
+    ck_dir = os.path.join(cfg["run_dir"], "checkpoints")
+    assert sorted(os.listdir(ck_dir)) == sorted(meta["checkpoint_files"])
+    got = {}
+    for line in open(os.path.join(cfg["run_dir"], "metrics.jsonl")):
+        s = json.loads(line)
+        got[(s["tag"], s["step"])] = s["value"]
+    for tag, val, step in meta["scalars"]:
+        if tag in ("train/fvu", "train/loss", "train/lr"):
+            assert got[(tag, step)] == pytest.approx(val, rel=3e-2), (tag, step)
+    ck = torch.load(os.path.join(ck_dir, "step7.pth"), map_location="cpu", weights_only=True)
+    assert list(ck["model"].keys()) == meta["model_keys"]
+    for k in ("W_dec", "encoder.weight"):
+        W, Wref = ck["model"][k].numpy(), z[f"model__{k}"]
+        assert np.linalg.norm(W - Wref) / np.linalg.norm(Wref) < 5e-3
