@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     f32x16 dc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dc[r] = 0.f;
-    constexpr int DIST = 8;          // fragments are requested DIST MFMAs ahead of their use
+    constexpr int DIST = 12;         // fragments are requested DIST MFMAs ahead of their use
     bf16x8 ring[DIST + 1];
 #pragma unroll
     for (int i = 0; i < DIST; ++i) ring[i] = load_frag(i);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], S, 0, 0, 0);
   }
 
-  constexpr int DIST = 8;
+  constexpr int DIST = 12;
   for (int j = 0; j < a.ntiles; ++j) {
     // iteration j: encoder MFMAs of tile j+1 (rows of ring slot (j+1)%4) with the bias/ReLU/staging work of tile
     // j in their gaps, then decoder MFMAs of tile j (transposed reads of ring slot j%4).  DMA issued now: tile
