@@ -40,7 +40,8 @@ struct BwdFusedArgs {
   const bf16_t* xb;    // [M_p][384]
   const bf16_t* c;     // [M_p][n_p]
   const bf16_t* Wt;    // [n_p][384]
-  const float* scal;   // scal[2] = 1/M
+  const float* scal;   // scal[1] = alpha/count, scal[2] = 1/M
+  int unscaled;        // 1: dxh holds 2 (x_hat - x)[keep] without the alpha/count factor (fused forward)
   float* slab;         // [splits][384][n_p]
   float* db_part;      // [splits][n_p]
   int n_p;
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   const int step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
   const int n0 = ntile * BF_BN;           // first dictionary column of the workgroup
   const int nw = n0 + 32 * w;             // first column of this wave
-  const float inv_m = a.scal[2];
+  // With an unscaled dx_hat everything is computed in units of 1/scale: dpre' = dc' + (1/M)/scale, and the
+  // epilogue multiplies the dW slab and db by scale = alpha/count.
+  const float scale = a.unscaled ? a.scal[1] : 1.0f;
+  const float inv_m = a.unscaled ? a.scal[2] / a.scal[1] : a.scal[2];
 
   // W^T fragments of this wave: B[k = d][col = n] -> lane (n = lane & 31, h) holds Wt[nw + n][16 kk + 8 h ..+8]
   bf16x8 wfrag[24];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       if (i % 3 == 1 && i / 3 < 7 && !(a.dbg & 4)) dma_pair(i / 3, next_row0, cur ^ 1);
       if (i >= 30 && i < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = i - 30, s2 = e >> 3, j = e & 7;
-        const float gv = ((float)cf[s2][j] > 0.f) ? (bf16_round(dc[e]) + inv_m) : 0.f;
+        const float gv = ((float)cf[s2][j] > 0.f) ? (dc[e] + inv_m) : 0.f;    // rounded to bf16 once, when packed
         db_acc += gv;
         pf[s2][j] = (bf16_t)gv;
       }
@@ -264,9 +268,9 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int drow = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        out[(int64_t)drow * a.n_p] = acc[dt][r];
+        out[(int64_t)drow * a.n_p] = acc[dt][r] * scale;
       }
     db_acc += __shfl_xor(db_acc, 32, 64);
-    if (lane < 32) a.db_part[(int64_t)split * a.n_p + nw + lane] = db_acc;
+    if (lane < 32) a.db_part[(int64_t)split * a.n_p + nw + lane] = db_acc * scale;
   }
 }

@@ -83,6 +83,8 @@ struct sae_ctx {
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
   float* cn_part = nullptr;
+  float* cnt_part = nullptr;   // fused forward: per-workgroup masked-entry counts
+  const bf16_t* xb_cur = nullptr;   // bf16 GEMM copy of the current batch (== the caller's x when no copy is needed)
   unsigned int* masked = nullptr;
   int dw_splits = 1;
   int bwd_splits = 1;       // row ranges of the fused backward
@@ -195,7 +197,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
   hipSetDevice(c->cfg.device_id);
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
-                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->Wp,
+                  c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->Wp, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead};
   for (void* p : ptrs)
@@ -295,6 +297,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->gn_part, 1024 * 8);
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
   ALLOC(c->masked, 2048 * 4);
+  ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
 #undef ALLOC
   hipMemset(c->P, 0, c->nparams * 4);
   hipMemset(c->Mom, 0, c->nparams * 4);
@@ -454,6 +457,9 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   return SAE_OK;
 }
 
+template <typename T> static constexpr bool x_dtype_is_bf16() { return false; }
+template <> constexpr bool x_dtype_is_bf16<bf16_t>() { return true; }
+
 template <typename T>
 static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream_t s, bool need_backward) {
   const int d = c->d, d_p = c->d_p, n_p = c->n_p;
@@ -468,7 +474,12 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   ev_end(c, KID_PREP_W, s);
 
   ev_begin(c, KID_PREP_X, s);
-  {
+  // bf16 activations that already have the padded GEMM shape need no copy; with the fused forward the masked-entry
+  // count comes from the forward's own epilogue, so the whole pass over x disappears.
+  const bool alias_x = c->use_fused_fwd && sizeof(T) == 2 && x_dtype_is_bf16<T>() && d == d_p && M == Mp &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  c->xb_cur = alias_x ? reinterpret_cast<const bf16_t*>(x) : c->xb;
+  if (!alias_x) {
     const int64_t chunks = Mp * (d_p / 8);
     int grid = (int)((chunks + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -476,7 +487,8 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       hipLaunchKernelGGL((prep_x_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
     else
       hipLaunchKernelGGL((prep_x_kernel<T, false>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
-    hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha);
+    if (!c->use_fused_fwd)
+      hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha);
   }
   ev_end(c, KID_PREP_X, s);
 
@@ -484,7 +496,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   if (c->use_fused_fwd) {
     const int lds = FF_FIXED_LDS + n_p * 4;
     FwdFusedArgs a{};
-    a.xb = c->xb; a.x = x; a.Wt = c->Wt; a.bias = b; a.scal = c->scal; a.c = c->c; a.dxh = c->dxh;
+    a.xb = c->xb_cur; a.x = x; a.Wt = c->Wt; a.bias = b; a.cnt_part = c->cnt_part; a.c = c->c; a.dxh = c->dxh;
     a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
     void (*kern)(FwdFusedArgs) = fwd_fused_d384_kernel<T, 0>;
     switch (c->cfg.reserved[1]) {   // timing experiments (bench.py --dbg); 0 in production
@@ -513,7 +525,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   }
   {  // c = relu(x W + b)
     GemmArgs g{};
-    g.A0 = c->xb; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
+    g.A0 = c->xb_cur; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
     g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
     EpiEnc e{};
     e.c = c->c; e.bias = b; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = g.nbn;
@@ -545,6 +557,9 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   ev_begin(c, KID_STEP_TOTAL, s);
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
   if (rc) return rc;
+  if (c->use_fused_fwd)   // the fused forward counted the masked entries itself: scal[] and the losses are due now
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)(Mp / 128), c->sq_part,
+                       (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128));
   if (backward) {
     int splits = c->dw_splits;
     int db_rows = (int)(Mp / 128);
@@ -556,7 +571,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         attr_set = true;
       }
       BwdFusedArgs a{};
-      a.dxh = c->dxh; a.xb = c->xb; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
+      a.dxh = c->dxh; a.xb = c->xb_cur; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
+      a.unscaled = c->use_fused_fwd ? 1 : 0;
       a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
       a.dbg = c->cfg.reserved[1];
       splits = c->bwd_splits;
@@ -581,7 +597,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       {  // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs)
         GemmArgs g{};
-        g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
+        g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb_cur; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
         g.nbm = d_p / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
         if (splits > g.ktiles) splits = g.ktiles;
         g.splits = splits;
@@ -602,10 +618,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     }
     ev_end(c, KID_REDUCE, s);
   }
-  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part,
-                     c->use_fused_fwd ? (int)(Mp / 128) : (int)((Mp / 128) * (n_p / 128)), c->sq_part,
-                     c->use_fused_fwd ? (int)(Mp / 128) : (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d,
-                     alpha);
+  if (!c->use_fused_fwd)
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
+                       c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha,
+                       (const float*)nullptr, 0);
   ev_end(c, KID_STEP_TOTAL, s);
   HIP_TRY(hipGetLastError());
   c->last_M = M;

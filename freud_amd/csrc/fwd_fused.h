@@ -2,7 +2,9 @@
 //
 //   c = relu(bf16(x W) + b)          (l1autoencoder.py:74)        -> stored once as bf16 for the backward
 //   x_hat = bf16(c W^T)              (l1autoencoder.py:84)
-//   l1 = sum c ; masked squared error, dx_hat = bf16(2 alpha (x_hat - x)[x != -1] / count)   (:85-86, :29-36)
+//   l1 = sum c ; masked squared error, UNSCALED dx_hat = bf16(2 (x_hat - x)[x != -1])   (:85-86, :29-36);
+//   the factor alpha / count (count = unmasked entries, known only after every workgroup has looked at its x
+//   rows) is applied by the backward's epilogue, so no separate counting pass over x is needed.
 //
 // One workgroup = 4 waves (one per SIMD, whole register file) = 128 activation rows; wave w owns rows
 // 32w..32w+31 for the whole dictionary sweep:
@@ -32,7 +34,7 @@ struct FwdFusedArgs {
   const void* x;         // original activations [M][d] (dtype T) for the residual
   const bf16_t* Wt;      // [n_p][384]
   const float* bias;     // [n_p]
-  const float* scal;     // scal[1] = alpha / count
+  float* cnt_part;       // [M_p/128] masked-entry (x == -1) counts per workgroup
   bf16_t* c;             // [M_p][n_p]
   bf16_t* dxh;           // [M_p][384]
   float* l1_part;        // [M_p/128]
@@ -237,8 +239,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 
   // ---- epilogue: x_hat^T accumulators -> residual / dx_hat / squared-error sums.
   // acc[dt][r] <-> d = 32 dt + (r&3) + 8 (r>>2) + 4 h, row mrow.
-  const float scale = a.scal[1];
-  float sq = 0.f, plain = 0.f;
+  float sq = 0.f, plain = 0.f, nmask = 0.f;
   // every value of this lane belongs to ONE activation row (mrow): rows past M read row M-1 (valid memory) and the
   // row mask is applied once at the end.  With d == 384 every 4-column group is whole -> vector loads, no branches.
   const int64_t lrow = row_ok ? mrow : a.M - 1;
@@ -263,8 +264,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
           const float e2 = e * e;
           plain += e2;
           const float keep = (xf != -1.0f) ? rmask : 0.f;
+          nmask += rmask - keep;
           sq += keep * e2;
-          o[q] = (bf16_t)((keep * (e * 2.0f)) * scale);
+          o[q] = (bf16_t)(keep * (e * 2.0f));
         }
         *reinterpret_cast<bf16x4*>(drow + 32 * dt + 8 * k + 4 * ah) = o;
       }
@@ -287,8 +289,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
           const float e2 = valid ? e * e : 0.f;
           plain += e2;
           const float keep = (valid && xf != -1.0f) ? rmask : 0.f;
+          nmask += (valid ? rmask : 0.f) - keep;
           sq += keep * e2;
-          o[q] = (bf16_t)((keep * (e * 2.0f)) * scale);
+          o[q] = (bf16_t)(keep * (e * 2.0f));
         }
         *reinterpret_cast<bf16x4*>(drow + d0) = o;
       }
@@ -298,7 +301,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const float l1s = block_sum_256(l1_acc, red);
   const float sqs = block_sum_256(sq, red + 8);
   const float pls = block_sum_256(plain, red + 16);
+  const float nms = block_sum_256(nmask, red + 24);
   if (t == 0) {
+    a.cnt_part[blockIdx.x] = nms;
     a.l1_part[blockIdx.x] = l1s;
     a.sq_part[2 * blockIdx.x] = sqs;
     a.sq_part[2 * blockIdx.x + 1] = pls;

@@ -311,11 +311,30 @@ __global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict_
 
 // One block: loss scalars from the per-tile partials (double accumulation, fixed order -> deterministic).
 // metrics: [0]=alpha*sq/count  [1]=l1_sum/M  [2]=plain_sq/(M*d)  [4]=count
+// With cnt_part != null (fused forward) the masked-entry count comes from the forward's own partials and the
+// scalars scal[0..2] = {count, alpha/count, 1/M} are produced here instead of by finalize_count_kernel.
 __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
-                                                                int n_sq, const float* scal, float* metrics, int64_t M,
-                                                                int d, float alpha) {
+                                                                int n_sq, float* scal, float* metrics, int64_t M,
+                                                                int d, float alpha, const float* cnt_part, int n_cnt) {
   __shared__ double red[3][16];
+  __shared__ double redc[16];
   double a = 0, b = 0, c = 0;
+  if (cnt_part) {
+    double m = 0;
+    for (int i = threadIdx.x; i < n_cnt; i += 1024) m += (double)cnt_part[i];
+    m = wave_sum_d(m);
+    if ((threadIdx.x & 63) == 0) redc[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0;
+      for (int k = 0; k < 16; ++k) tot += redc[k];
+      const double count = (double)M * d - tot;
+      scal[0] = (float)count;
+      scal[1] = alpha / (float)count;
+      scal[2] = 1.0f / (float)M;
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < n_l1; i += 1024) a += (double)l1_part[i];
   for (int i = threadIdx.x; i < n_sq; i += 1024) {
     b += (double)sq_part[2 * i];
