@@ -84,6 +84,9 @@ struct sae_ctx {
   double* gn_part = nullptr;
   float* cn_part = nullptr;
   float* cnt_part = nullptr;   // fused forward: per-workgroup masked-entry counts
+  int gn_blocks = 0;
+  bool step_fused_call = false; // set by sae_step: forward_backward and optimizer_step back to back
+  bool gn_valid = false;       // gn_part holds the sum of squares of the UNSCALED local gradient
   const bf16_t* xb_cur = nullptr;   // bf16 GEMM copy of the current batch (== the caller's x when no copy is needed)
   unsigned int* masked = nullptr;
   int dw_splits = 1;
@@ -610,11 +613,20 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
     }
     ev_begin(c, KID_REDUCE, s);
-    {
+    if (c->use_fused_bwd) {   // one pass: slabs + db partials -> grads, plus the local gradient sum of squares
+      const int64_t nW4 = c->nW / 4, n4 = c->nparams / 4;
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(reduce_grads_kernel, dim3(blocks), dim3(256), 0, s, c->slab, nW4, splits, c->db_part, db_rows, n_p,
+                         c->G, nW4, n4, c->gn_part);
+      c->gn_blocks = blocks;
+      c->gn_valid = true;
+    } else {
       const int64_t n4 = c->nW / 4;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
                          splits);
       hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, c->G + c->nW, db_rows, n_p);
+      c->gn_valid = false;
     }
     ev_end(c, KID_REDUCE, s);
   }
@@ -839,7 +851,14 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   const int64_t n4 = c->nparams / 4;  // nW and n_p are multiples of 128
   int gblocks = (int)((n4 + 255) / 256);
   if (gblocks > 1024) gblocks = 1024;
-  hipLaunchKernelGGL(gnorm_partial_kernel, dim3(gblocks), dim3(256), 0, s, c->G, n4, a.grad_scale, c->gn_part);
+  // the reduction kernel already left the local sum of squares; it is only valid when nothing (no all-reduce, no
+  // rescaling) touched the gradient buffer in between, i.e. for the single-GPU sae_step path
+  if (c->gn_valid && grad_scale == 1.0 && c->step_fused_call) {
+    gblocks = c->gn_blocks;
+  } else {
+    hipLaunchKernelGGL(gnorm_partial_kernel, dim3(gblocks), dim3(256), 0, s, c->G, n4, a.grad_scale, c->gn_part);
+  }
+  c->gn_valid = false;
   int oblocks = (int)((n4 + 255) / 256);
   if (oblocks > 2048) oblocks = 2048;
   hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
@@ -863,7 +882,10 @@ extern "C" int sae_set_topk_options(sae_ctx* c, double dead_feature_threshold, i
 extern "C" int sae_step(sae_ctx* c, const void* x, int64_t M, int x_dtype, double lr, void* stream) {
   int rc = sae_forward_backward(c, x, M, x_dtype, stream);
   if (rc) return rc;
-  return sae_optimizer_step(c, lr, 1.0, stream);
+  c->step_fused_call = true;
+  rc = sae_optimizer_step(c, lr, 1.0, stream);
+  c->step_fused_call = false;
+  return rc;
 }
 
 extern "C" int sae_read_metrics(sae_ctx* c, float out[SAE_NUM_METRICS], void* stream) {

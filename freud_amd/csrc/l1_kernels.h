@@ -286,6 +286,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   reinterpret_cast<f32x4*>(grad)[i] = a;
 }
 
+// Fused gradient reduction: grad[i] = sum_s slab[s][i] over the flat [dW | db] range (db partials live at
+// part_db[s][j]) AND the per-block sum of squares of the result (for clip_grad_norm_ when no data-parallel
+// all-reduce follows).  Fixed order everywhere -> deterministic.
+__global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restrict__ slab, int64_t stride4, int splits,
+                                                            const float* __restrict__ db_part, int db_rows, int n_p,
+                                                            float* __restrict__ grad, int64_t nW4, int64_t n4,
+                                                            double* __restrict__ gn_part) {
+  __shared__ double red[4];
+  double ss = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 a;
+    if (i < nW4) {
+      const f32x4* s = reinterpret_cast<const f32x4*>(slab);
+      a = s[i];
+      for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+    } else {
+      const int64_t j4 = i - nW4;
+      const f32x4* s = reinterpret_cast<const f32x4*>(db_part);
+      a = s[j4];
+      for (int k = 1; k < db_rows; ++k) a += s[j4 + (int64_t)k * (n_p / 4)];
+    }
+    reinterpret_cast<f32x4*>(grad)[i] = a;
+    ss += (double)(a[0] * a[0]) + (double)(a[1] * a[1]) + (double)(a[2] * a[2]) + (double)(a[3] * a[3]);
+  }
+  ss = wave_sum_d(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) gn_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // db[j] = sum over row tiles of db_part[tile][j]; block = 32 columns x 8 row lanes (fixed order)
 __global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict__ part, float* __restrict__ db, int nbm,
                                                          int n_p) {
