@@ -27,7 +27,7 @@ constexpr int FF_WT_BYTES = FF_BN * FF_D * 2;     // 24576: W^T tile [32 n][384 
 constexpr int FF_DEPTH = 4;                       // W^T ring: tile j (decoder), j+1 (encoder), j+2 / j+3 landing
 constexpr int FF_RING_BYTES = FF_DEPTH * FF_WT_BYTES;          // 98304
 constexpr int FF_CST_BYTES = 4 * 2 * 4096;        // per wave two [32 rows][64 cols] bf16 latent staging buffers
-constexpr int FF_FIXED_LDS = FF_RING_BYTES + FF_CST_BYTES;     // + 4 * n_p bytes of bias
+constexpr int FF_FIXED_LDS = FF_RING_BYTES + FF_CST_BYTES;     // + 4 * (n_p + 32) bytes of bias
 
 struct FwdFusedArgs {
   const bf16_t* xb;      // [M_p][384]  bf16 GEMM operand
@@ -41,12 +41,10 @@ struct FwdFusedArgs {
   float* sq_part;        // [M_p/128][2]
   int64_t M;
   int d, n_p, ntiles;    // ntiles = n_p / 32 (even)
-  int dbg;               // timing experiments only: 1 = skip latent stores, 2 = skip in-loop DMA
+  int64_t c_rows;        // M_p: a dummy 1-KiB line lives at c[M_p][0..] (engine allocates the slack)
 };
 
-// DBG (compile time, timing experiments only; results become wrong): 1 = no latent stores, 2 = no in-loop DMA,
-// 8 = no end-of-iteration wait/barrier, 16 = no bias/ReLU/staging work, 32 = no decoder MFMAs
-template <typename T, int DBG>
+template <typename T>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -54,7 +52,6 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const int64_t m0 = (int64_t)blockIdx.x * FF_BM + 32 * w;     // first row of this wave
   const int64_t mrow = m0 + arow;                               // the row this lane's accumulator column is
   const bool row_ok = mrow < a.M;
-  const bool wave_has_pad = __builtin_amdgcn_readfirstlane((int)(m0 + 32 > a.M)) != 0;
   char* cst = smem + FF_RING_BYTES + w * 8192;                  // this wave's latent staging (2 x 4 KB)
   float* bias_s = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
 
@@ -65,7 +62,10 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
   }
-  for (int i = t; i < a.n_p; i += 256) bias_s[i] = a.bias[i];
+  for (int i = t; i < a.n_p + FF_BN; i += 256) bias_s[i] = i < a.n_p ? a.bias[i] : 0.f;
+  // ring slot 3 is read (times zero) by the first iteration's decoder phase: make it finite
+  for (int i = t; i < FF_WT_BYTES / 16; i += 256)
+    reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
 
   f32x16 acc[12];
 #pragma unroll
@@ -85,16 +85,14 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   }
   typedef __attribute__((address_space(3))) char* lptr_t;
   const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
-  // pieces 2p, 2p+1 of W^T tile `jt` into ring slot `st`
-  auto dma_pair = [&](int p, int jt, int st) {
+  auto dma_pair = [&](int p, int jt, int st) {     // pieces 2p, 2p+1 of W^T tile `jt` into ring slot `st`
     const bf16_t* src = a.Wt + (int64_t)jt * FF_BN * FF_D;
     const unsigned dst = smem_base + st * FF_WT_BYTES;
     glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], dst + loff_t[2 * p], dst + loff_t[2 * p + 1]);
   };
   const int last = a.ntiles - 1;
-  // prologue: W^T tiles 0, 1, 2 into slots 0, 1, 2
 #pragma unroll
-  for (int q = 0; q < 3; ++q)
+  for (int q = 0; q < 2; ++q)                       // prologue: W^T tiles 0, 1 into slots 0, 1
 #pragma unroll
     for (int p = 0; p < 3; ++p) dma_pair(p, q <= last ? q : last, q);
 #pragma unroll
@@ -130,105 +128,118 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 
   float l1_acc = 0.f;
 
-  // ---- S for tile 0 (no overlap partner yet)
-  f32x16 S;
+  // ---- S(0): encoder product of tile 0 (outside the pipeline)
+  f32x16 Sn;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) S[r] = 0.f;
+  for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
 #pragma unroll
   for (int kk = 0; kk < 24; ++kk) {
     const bf16x8 fa = *reinterpret_cast<const bf16x8*>(smem + (kk >> 3) * 8192 + roff[kk & 7]);
-    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], S, 0, 0, 0);
+    Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], Sn, 0, 0, 0);
   }
 
-  constexpr int DIST = 12;
-  for (int j = 0; j < a.ntiles; ++j) {
-    // iteration j: encoder MFMAs of tile j+1 (rows of ring slot (j+1)%4) with the bias/ReLU/staging work of tile
-    // j in their gaps, then decoder MFMAs of tile j (transposed reads of ring slot j%4).  DMA issued now: tile
-    // j+3 -> slot (j+3)%4 (its previous tile j-1 was last read in iteration j-1); it has to have landed only
-    // by the END of iteration j+1 (counted vmcnt), i.e. it has more than one whole iteration to arrive.
-    const int jt = j + 3 <= last ? j + 3 : last;
-    const char* img_e = smem + ((j + 1) & 3) * FF_WT_BYTES;
-    const char* img_d = smem + (j & 3) * FF_WT_BYTES;
-    const float* bj = bias_s + j * FF_BN;
-    char* cst_w = cst + ((j >> 1) & 1) * 4096;               // staging buffer being filled by tiles 2t, 2t+1
-    const char* cst_r = cst + (((j >> 1) & 1) ^ 1) * 4096;   // staging buffer being drained (tiles 2t-2, 2t-1)
-    const bool drain = j >= 2;
-
-    auto load_frag = [&](int i) -> bf16x8 {
-      if (i < 24) return *reinterpret_cast<const bf16x8*>(img_e + (i >> 3) * 8192 + roff[i & 7]);
-      const int tt = i - 24, dt = tt >> 1, sk = tt & 1;
-      const char* b = img_d + (dt >> 2) * 8192 + sk * 4096;
-      return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
-    };
-    bf16x8 ring[DIST + 1];
+  // ---- skewed software pipeline.  Iteration j (0..ntiles) issues 48 MFMAs:
+  //   i in [ 0,24): decoder of tile j-1:  x_hat^T[dt] += W tile (transposed reads of slot (j-1)%4) . c^T(j-1)
+  //   i in [24,48): encoder of tile j+1:  S(j+1)      += W^T tile (row reads of slot (j+1)%4)      . x^T
+  // while the bias/ReLU/L1/staging work that turns S(j) into c(j) is spread over all 48 gaps (one latent element per
+  // ~3 MFMAs).  A-fragments are requested DIST MFMAs ahead through a 12-deep register ring that is carried ACROSS
+  // iterations (the next decoder tile is long resident), so no LDS latency is exposed at iteration boundaries.
+  // One barrier per iteration at gap 12: by then the DMA of tile j+1 (issued in iteration j-1) has had a full
+  // iteration to land (counted vmcnt); the DMA of tile j+2 is issued after it into the slot whose tile j-2 was last
+  // read before this barrier.
+  constexpr int DIST = 11, RING = 12;
+  constexpr int EGAP[16] = {6, 9, 11, 14, 17, 19, 22, 25, 27, 30, 33, 35, 38, 41, 43, 46};
+  bf16x8 ring[RING];
+  bf16x8 cfp[2], cfn[2];
 #pragma unroll
-    for (int i = 0; i < DIST; ++i) ring[i] = load_frag(i);
+  for (int q = 0; q < 8; ++q) cfp[0][q] = cfp[1][q] = (bf16_t)0.f;
+  auto load_dec = [&](const char* img, int i) -> bf16x8 {       // decoder fragment of MFMA i (0..23)
+    const int dt = i >> 1, sk = i & 1;
+    const char* b = img + (dt >> 2) * 8192 + sk * 4096;
+    return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
+  };
+#pragma unroll
+  for (int i = 0; i < DIST; ++i) ring[i] = load_dec(smem + 3 * FF_WT_BYTES, i);
 
-    f32x16 Sn;
+  u32x4 dr[2];
+  for (int j = 0; j <= a.ntiles; ++j) {
+    const char* img_d = smem + ((j + 3) & 3) * FF_WT_BYTES;          // tile j-1
+    const char* img_dn = smem + (j & 3) * FF_WT_BYTES;               // tile j (next iteration's decoder operand)
+    const char* img_e = smem + ((j + 1) & 3) * FF_WT_BYTES;          // tile j+1
+    const int jt = j + 2 <= last ? j + 2 : last;                     // DMA source (clamped in the tail)
+    const float* bj = bias_s + (j <= last ? j : a.ntiles) * FF_BN;   // bias slice of tile j (zeros past the end)
+    char* cst_w = cst + ((j >> 1) & 1) * 4096;                       // staging buffer filled by tiles 2t, 2t+1
+    const char* cst_r = cst + (((j >> 1) & 1) ^ 1) * 4096;           // staging buffer drained (tiles 2t-2, 2t-1)
+    // the first two iterations have no finished pair to drain: their two stores go to a dummy line past the latent
+    // (keeps the loop branch-free and the number of memory operations per iteration constant for the counted wait)
+    bf16_t* dst_pair = j >= 2 ? cdrain + 64 * ((j >> 1) - 1) : a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
+    const int64_t dst_rstride = j >= 2 ? (int64_t)a.n_p : 0;
+    const float mask_f = (row_ok && j <= last) ? 1.f : 0.f;
+    (void)img_d;
+
+    f32x16 S = Sn;                 // S(j), finished in the previous iteration
 #pragma unroll
     for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
-    bf16x8 cf[2];
-    if (DBG & 16) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { cf[0][q] = (bf16_t)S[q]; cf[1][q] = (bf16_t)S[8 + q]; }
-    }
     f32x4 bq[4];
-    u32x4 dr[2];
 
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
-      if (i + DIST < 48) ring[(i + DIST) % (DIST + 1)] = load_frag(i + DIST);
-      if (i % 4 == 1 && i / 4 < 3 && !(DBG & 2)) dma_pair(i / 4, jt, (j + 3) & 3);
+      // ---- fragment prefetch (ring carried across iterations)
+      {
+        const int g = i + DIST;
+        if (g < 24) ring[g % RING] = load_dec(img_d, g);
+        else if (g < 48) ring[g % RING] = *reinterpret_cast<const bf16x8*>(img_e + ((g - 24) >> 3) * 8192 + roff[(g - 24) & 7]);
+        else ring[g % RING] = load_dec(img_dn, g - 48);
+      }
       if (i < 4) bq[i] = *reinterpret_cast<const f32x4*>(bj + 8 * i + 4 * ah);    // bias of S rows 8 i + 4 h + (0..3)
-      if (i >= 4 && i < 20 && !(DBG & 16)) {     // one latent element per gap: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
-        const int e = i - 4;
-        float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
-        if (wave_has_pad) cv = row_ok ? cv : 0.f;
-        l1_acc += cv;
-        cf[e >> 3][e & 7] = (bf16_t)cv;
-        if ((e & 3) == 3) {       // 4 consecutive columns ready: 8 bytes into the staging image
-          const int k = e >> 2;
-          const bf16x4 o = {cf[e >> 3][(e & 7) - 3], cf[e >> 3][(e & 7) - 2], cf[e >> 3][(e & 7) - 1], cf[e >> 3][e & 7]};
-          const int chunk = 4 * (j & 1) + k;                 // 16-B chunk of the 128-B row; +8 bytes for h = 1
-          *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
+      if (i == 12) {
+        // everything older than this iteration's (<= 2) latent stores has completed once <= 2 operations are
+        // outstanding: in particular the 6 DMA pieces of tile j+1.  Raw barrier (no fence).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 15 || i == 19 || i == 23) dma_pair((i - 15) / 4, jt, (j + 2) & 3);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (EGAP[e] == i) {     // latent element e: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+          const float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f) * mask_f;
+          l1_acc += cv;
+          cfn[e >> 3][e & 7] = (bf16_t)cv;
+          if ((e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
+            const int k = e >> 2;
+            const bf16x4 o = {cfn[e >> 3][(e & 7) - 3], cfn[e >> 3][(e & 7) - 2], cfn[e >> 3][(e & 7) - 1], cfn[e >> 3][e & 7]};
+            const int chunk = 4 * (j & 1) + k;               // 16-B chunk of the 128-B row; +8 bytes for h = 1
+            *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
+          }
         }
+      // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 8 gaps later
+      if (i == 29 || i == 34) {
+        const int r = 8 * (2 * (j & 1) + (i == 34)) + drow_l;
+        dr[i == 34] = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
       }
-      // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 10 gaps later
-      if ((i == 24 || i == 28) && drain && !(DBG & 1)) {
-        const int r = 8 * (2 * (j & 1) + (i == 28)) + drow_l;
-        dr[i == 28] = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
-      }
-      if ((i == 34 || i == 38) && drain && !(DBG & 1)) {
-        const int p = 2 * (j & 1) + (i == 38);
-        *reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((j >> 1) - 1)) = dr[i == 38];
+      if (i == 37 || i == 42) {
+        const int p = 2 * (j & 1) + (i == 42);
+        *reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride) = dr[i == 42];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 fa = ring[i % (DIST + 1)];
+      const bf16x8 fa = ring[i % RING];
       if (i < 24) {
-        Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i], Sn, 0, 0, 0);
-      } else if (!(DBG & 32)) {
-        acc[(i - 24) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cf[i & 1], acc[(i - 24) >> 1], 0, 0, 0);
+        acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cfp[i & 1], acc[i >> 1], 0, 0, 0);
       } else {
-        asm volatile("" ::"v"(fa));
+        Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i - 24], Sn, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    S = Sn;
-    // this iteration issued 6 LDS-DMA pieces (+ 2 latent stores when draining) per wave: everything older has
-    // completed once at most that many operations are outstanding.  Raw barrier: __syncthreads() would drain to 0.
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 8)) {
-      if (drain) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    cfp[0] = cfn[0];
+    cfp[1] = cfn[1];
   }
-  // drain the last pair of latent tiles
-  if (!(DBG & 1)) {
+  // drain the second half of the last pair of latent tiles (its first half went out in the final iteration)
+  {
     const char* cst_r = cst + (((a.ntiles >> 1) - 1) & 1) * 4096;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 2; p < 4; ++p) {
       const int r = 8 * p + drow_l;
       const u32x4 v = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
       *reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)) = v;
