@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     bf16x8 cf[2], pf[2];
     cf[0] = tr_pair(img_c + coff0, img_c + coff1);
     cf[1] = tr_pair(img_c + 4096 + coff0, img_c + 4096 + coff1);
-    f32x16 dc;
+    f32x16 dc;        // starts at (1/M)/scale: the L1 term sign(c)/M of d loss / d c, so the gate needs no add
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) dc[r] = inv_m;
     constexpr int DIST = 12;         // fragments are requested DIST MFMAs ahead of their use
     bf16x8 ring[DIST + 1];
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       if (i % 3 == 1 && i / 3 < 7 && !(a.dbg & 4)) dma_pair(i / 3, next_row0, cur ^ 1);
       if (i >= 30 && i < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = i - 30, s2 = e >> 3, j = e & 7;
-        const float gv = ((float)cf[s2][j] > 0.f) ? (dc[e] + inv_m) : 0.f;    // rounded to bf16 once, when packed
+        const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed
         db_acc += gv;
         pf[s2][j] = (bf16_t)gv;
       }

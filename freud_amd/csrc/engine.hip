@@ -502,15 +502,25 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     a.xb = c->xb_cur; a.x = x; a.Wt = c->Wt; a.bias = b; a.cnt_part = c->cnt_part; a.c = c->c; a.dxh = c->dxh;
     a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
     a.c_rows = c->max_rows_p;
-    void (*kern)(FwdFusedArgs) = fwd_fused_d384_kernel<T>;
-    static const void* attr_done = nullptr;   // one opt-in per kernel variant (> 64 KiB dynamic LDS)
-    if (attr_done != reinterpret_cast<const void*>(kern)) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
-      attr_done = reinterpret_cast<const void*>(kern);
+    // full workgroups (all 128 rows < M) run the mask-free instantiation; a ragged last workgroup the padded one
+    const int full_wgs = (int)(M / FF_BM), all_wgs = (int)(Mp / FF_BM);
+    static bool attr_done = false;
+    if (!attr_done) {   // opt in to > 64 KiB dynamic LDS once per instantiation
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
     }
     ev_begin(c, KID_FWD_FUSED, s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Mp / FF_BM)), dim3(256), lds, s, a);
+    if (full_wgs > 0) {
+      a.block_offset = 0;
+      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false>), dim3(full_wgs), dim3(256), lds, s, a);
+    }
+    if (all_wgs > full_wgs) {
+      a.block_offset = full_wgs;
+      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, true>), dim3(all_wgs - full_wgs), dim3(256), lds, s, a);
+    }
     ev_end(c, KID_FWD_FUSED, s);
     HIP_TRY(hipGetLastError());
     return SAE_OK;

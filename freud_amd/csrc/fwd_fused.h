@@ -41,15 +41,18 @@ struct FwdFusedArgs {
   float* sq_part;        // [M_p/128][2]
   int64_t M;
   int d, n_p, ntiles;    // ntiles = n_p / 32 (even)
+  int block_offset;      // first workgroup index of this launch
   int64_t c_rows;        // M_p: a dummy 1-KiB line lives at c[M_p][0..] (engine allocates the slack)
 };
 
-template <typename T>
+// PAD: the workgroup may contain rows >= M (only the last, ragged workgroup is launched with PAD = true).
+template <typename T, bool PAD>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int arow = lane & 31, ah = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * FF_BM + 32 * w;     // first row of this wave
+  const int wg = blockIdx.x + a.block_offset;
+  const int64_t m0 = (int64_t)wg * FF_BM + 32 * w;             // first row of this wave
   const int64_t mrow = m0 + arow;                               // the row this lane's accumulator column is
   const bool row_ok = mrow < a.M;
   char* cst = smem + FF_RING_BYTES + w * 8192;                  // this wave's latent staging (2 x 4 KB)
@@ -174,13 +177,11 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     // (keeps the loop branch-free and the number of memory operations per iteration constant for the counted wait)
     bf16_t* dst_pair = j >= 2 ? cdrain + 64 * ((j >> 1) - 1) : a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
     const int64_t dst_rstride = j >= 2 ? (int64_t)a.n_p : 0;
-    const float mask_f = (row_ok && j <= last) ? 1.f : 0.f;
-    (void)img_d;
+    const float live = j <= last ? 1.f : 0.f;                        // the extra tail iteration must not count in l1
 
     f32x16 S = Sn;                 // S(j), finished in the previous iteration
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
     f32x4 bq[4];
+    float l1_it = 0.f;
 
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
@@ -204,8 +205,10 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         if (EGAP[e] == i) {     // latent element e: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
-          const float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f) * mask_f;
-          l1_acc += cv;
+          // pre-activation rounded to bf16 BEFORE the fp32 bias add, as CPU autocast does (l1autoencoder.py:74)
+          float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
+          if (PAD) cv = row_ok ? cv : 0.f;
+          l1_it += cv;
           cfn[e >> 3][e & 7] = (bf16_t)cv;
           if ((e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
             const int k = e >> 2;
@@ -227,6 +230,11 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       const bf16x8 fa = ring[i % RING];
       if (i < 24) {
         acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cfp[i & 1], acc[i >> 1], 0, 0, 0);
+      } else if (i == 24) {      // S(j+1) starts from zero (the MFMA's C operand is the literal 0)
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[0], zero, 0, 0, 0);
       } else {
         Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i - 24], Sn, 0, 0, 0);
       }
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     }
     cfp[0] = cfn[0];
     cfp[1] = cfn[1];
+    l1_acc += l1_it * live;
   }
   // drain the second half of the last pair of latent tiles (its first half went out in the final iteration)
   {
@@ -314,9 +323,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const float pls = block_sum_256(plain, red + 16);
   const float nms = block_sum_256(nmask, red + 24);
   if (t == 0) {
-    a.cnt_part[blockIdx.x] = nms;
-    a.l1_part[blockIdx.x] = l1s;
-    a.sq_part[2 * blockIdx.x] = sqs;
-    a.sq_part[2 * blockIdx.x + 1] = pls;
+    a.cnt_part[wg] = nms;
+    a.l1_part[wg] = l1s;
+    a.sq_part[2 * wg] = sqs;
+    a.sq_part[2 * wg + 1] = pls;
   }
 }
