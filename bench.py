@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--variant", default="l1", choices=["l1", "topk"], help="topk = BASELINE configs[2] style run")
     ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -85,9 +86,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the train step)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from freud_amd.engine import SaeEngine
@@ -109,12 +114,12 @@ def main():
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
                         clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
-    grads = eng.grad_tensor() if world > 1 else None
+    grads = eng.grad_tensor() if use_dist else None
     total_steps, base_lr = 100000, 4e-4
     lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
     def one_step(i):
-        if world > 1:
+        if use_dist:
             eng.forward_backward(x)
             dist.all_reduce(grads)
             eng.optimizer_step(lr_of(i), 1.0 / world)
@@ -125,18 +130,18 @@ def main():
         one_step(i)
     torch.cuda.synchronize()
     eng.profile(1)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,7 +203,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

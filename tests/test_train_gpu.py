@@ -93,3 +93,22 @@ def test_topk_train_path_matches_reference(tmp_path, golden_dir):
     for k in ("W_dec", "encoder.weight"):
         W, Wref = ck["model"][k].numpy(), z[f"model__{k}"]
         assert np.linalg.norm(W - Wref) / np.linalg.norm(Wref) < 5e-3
+
+
+def test_bench_data_parallel_path_single_rank():
+    """The DP code path of bench.py (RCCL all-reduce of the engine's gradient buffer aliased as a torch tensor,
+    1/R scaling, separate optimizer call) on one rank: same throughput contract, finite losses."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--rows", "8192", "--force-dist", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and np.isfinite(res["loss"]["recon"])
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                             "--rows", "8192", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    ref = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["loss"]["recon"] == pytest.approx(ref["loss"]["recon"], rel=1e-5)      # same arithmetic either way
+    assert res["loss"]["grad_norm"] == pytest.approx(ref["loss"]["grad_norm"], rel=1e-4)
