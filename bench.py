@@ -89,6 +89,8 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"      # RCCL prints its version banner on STDOUT: keep stdout to one JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -200,11 +202,13 @@ def main():
         out["cpu_baseline"] = cpu_baseline(x_cpu, W, b, args.cpu_steps, base_lr)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     eng.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
