@@ -89,8 +89,11 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"      # RCCL prints its version banner on STDOUT: keep stdout to one JSON line
+        # RCCL writes its NCCL_DEBUG output (version banner, warnings) to STDOUT: send it to a file instead so that
+        # stdout carries exactly one JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":     # the version banner ignores NCCL_DEBUG_FILE
+            os.environ.pop("NCCL_DEBUG")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")

@@ -60,7 +60,7 @@ enum KernelId {
 static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x", "enc_fwd_gemm", "dec_fwd_gemm", "fwd_fused_gemm", "dpre_gemm",
                                               "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "topk_enc_gemm", "topk_select",
                                               "topk_decode", "topk_ddense_gemm", "topk_dwdec_gemm", "topk_dwenc_gemm",
-                                              "topk_dsaein_gemm", "fwd_bwd_total"};
+                                              "topk_dsaein_colsum", "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
 struct EvRing {
@@ -169,7 +169,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->e2_part, Mp * 4);
   TALLOC(c->a2_part, Mp * 4);
   TALLOC(c->dbd_part, (Mp / 128 + 1) * c->d_p * 4);
-  TALLOC(c->ds_part, (Mp / 128) * c->d_p * 4);
+  TALLOC(c->ds_part, (int64_t)((c->n_p + 255) / 256) * c->d_p * 4);
   TALLOC(c->db_part, (Mp / 128) * c->n_p * 4);
   TALLOC(c->tkf, 64);
   TALLOC(c->tk, 64);
@@ -696,11 +696,22 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     if (rc) return rc;
   }
   ev_begin(c, KID_TK_SELECT, s);
-  hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->dense, c->top_idx, did_fire,
-                     (const unsigned char*)nullptr, (const int*)nullptr, k, k, n, n_p);
-  if (aux)
-    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense, c->aux_idx,
-                       (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p);
+  {
+    auto launch_select = [&](bf16_t* dense_out, int* idx_out, float* fire, const unsigned char* dead_mask, const int* k_ptr,
+                             int k_fixed, int kcap) {
+      if (n_p <= 2048 * 12)
+        hipLaunchKernelGGL(topk_select_reg_kernel<12>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p);
+      else if (n_p <= 2048 * 44)
+        hipLaunchKernelGGL(topk_select_reg_kernel<44>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p);
+      else
+        hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire, dead_mask,
+                           k_ptr, k_fixed, kcap, n, n_p);
+    };
+    launch_select(c->dense, c->top_idx, did_fire, nullptr, nullptr, k, k);
+    if (aux) launch_select(c->aux_dense, c->aux_idx, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
+  }
   ev_end(c, KID_TK_SELECT, s);
   ev_begin(c, KID_TK_DECODE, s);
   hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)Mp), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b, bd, c->e,
@@ -766,21 +777,15 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       ev_end(c, KID_TK_DWE, s);
       if (rc) return rc;
     }
-    {  // dsae_in = dpre We : only its column sums reach a parameter (b_dec)
-      GemmArgs g{};
-      g.A0 = c->dpre; g.B0 = c->We_b; g.lda = n_p; g.ldb = d_p;
-      g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
-      EpiTopkDsaeIn e{};
-      e.part = c->ds_part; e.d_p = d_p;
-      ev_begin(c, KID_TK_DSAE, s);
-      rc = launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
-      ev_end(c, KID_TK_DSAE, s);
-      if (rc) return rc;
-    }
     ev_begin(c, KID_REDUCE, s);
     hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
-    hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, (int)(Mp / 128),
-                       gbd, d_p);
+    // d b_dec also receives -sum_rows(dpre W_enc) through sae_in = x - b_dec; that row sum is a GEMV on d b_enc
+    ev_begin(c, KID_TK_DSAE, s);
+    const int nchunks = (n_p + 255) / 256;
+    hipLaunchKernelGGL(topk_dsae_colsum_kernel, dim3((d_p + 255) / 256, nchunks), dim3(256), 0, s, gbe, c->We_b, c->ds_part, n_p,
+                       d_p);
+    ev_end(c, KID_TK_DSAE, s);
+    hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
     ev_end(c, KID_REDUCE, s);
   }
   ev_end(c, KID_STEP_TOTAL, s);

@@ -213,6 +213,175 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// per-row top-k, register-resident version: the whole row (n_p <= 2048 * MAXV bf16) is loaded once into
+// registers as packed 15-bit keys (post-ReLU values are non-negative, so the bf16 bit pattern orders like the
+// value; non-candidates -- padding columns, or living latents in the AuxK pass -- become key 0).  The k-th largest
+// key is found by a binary search on the key value; each probe counts "key >= T" on two packed keys per
+// instruction: ((w | 0x80008000) - T*0x00010001) has bit 15 / 31 set exactly where the half is >= T.
+// Elements > T are selected; ties at T are taken in (thread, register) order up to k; exact zeros only enter the
+// selection when fewer than k positive candidates exist (then in the same order).  Writes the masked dense row,
+// the index list and did_fire.  Deterministic.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan_256(int v, int* wave_tot /* >= 4 ints LDS */, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int ww = 0; ww < w; ++ww) base += wave_tot[ww];
+  *total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  return base + inc - v;
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
+                                                               int* __restrict__ top_idx, float* __restrict__ did_fire,
+                                                               const unsigned char* __restrict__ dead,
+                                                               const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
+                                                               int n_p) {
+  __shared__ int red[4];
+  __shared__ int sc[4];
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int k_req = k_ptr ? *k_ptr : k_fixed;
+  const int nvec = n_p >> 3;                       // 16-byte vectors in the row
+  const u32x4* src = reinterpret_cast<const u32x4*>(pre + row * n_p);
+  u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
+  int* ti = top_idx + row * kcap;
+
+  // ---- load + candidate filter.  keys[v][q] packs columns 8 g + 2 q (low half) and 8 g + 2 q + 1 (high half)
+  u32x4 keys[MAXV];
+  unsigned cand[MAXV];                             // 8 candidate bits per vector
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int g = v * 256 + t;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    unsigned cb = 0;
+    if (g < nvec) {
+      w = src[g];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = 8 * g + e;
+        const bool ok = col < n && (!dead || dead[col]);
+        cb |= ok ? (1u << e) : 0u;
+      }
+      // zero the keys of non-candidates
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned m = ((cb >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((cb >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
+        w[q] &= m;
+      }
+    }
+    keys[v] = w;
+    cand[v] = cb;
+  }
+  auto count_ge = [&](unsigned T) -> int {         // block-wide number of keys >= T (T in 1..0x8000)
+    const unsigned tp = T * 0x00010001u;
+    unsigned c2 = 0;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c2 += (((keys[v][q] | 0x80008000u) - tp) >> 15) & 0x00010001u;
+    int c = (int)((c2 & 0xFFFFu) + (c2 >> 16));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = c;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  int ncand_l = 0;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) ncand_l += __popc(cand[v]);
+  int ncand;
+  (void)block_excl_scan_256(ncand_l, sc, &ncand);
+  const int k = k_req < ncand ? k_req : ncand;     // where(dead, pre, -inf).topk(k_aux): k_aux <= num_dead by construction
+  if (k <= 0) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+      if (v * 256 + t < nvec) dst[v * 256 + t] = u32x4{0u, 0u, 0u, 0u};
+    for (int j = t; j < kcap; j += 256) ti[j] = -1;
+    return;
+  }
+  // ---- largest T in [1, 0x8000] with count(key >= T) >= k; T = 0 if fewer than k positive keys
+  const int npos = count_ge(1u);
+  unsigned T = 0;
+  if (npos >= k) {
+    unsigned lo = 1, hi = 0x8000u;                 // invariant: count_ge(lo) >= k, count_ge(hi + 1) < k
+    while (lo < hi) {
+      const unsigned mid = (lo + hi + 1) >> 1;
+      if (count_ge(mid) >= k) lo = mid;
+      else hi = mid - 1;
+    }
+    T = lo;
+  }
+  const int n_gt = T >= 0x8000u ? 0 : (T == 0 ? npos : count_ge(T + 1));
+  const int need_ties = k - n_gt;                  // elements equal to T to take (for T == 0: candidate zeros)
+  // ---- ties in (thread, register) order
+  int tie_l = 0;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned key = (keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+      tie_l += (key == T && ((cand[v] >> e) & 1u)) ? 1 : 0;
+    }
+  int tie_tot;
+  const int tie_before = block_excl_scan_256(tie_l, sc, &tie_tot);
+  int tie_budget = need_ties - tie_before;         // how many of this thread's ties are taken
+  // ---- emit
+  int sel_l = 0;
+  unsigned selmask[MAXV];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    unsigned sm = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned key = (keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+      const bool c = (cand[v] >> e) & 1u;
+      bool take = c && key > T;
+      if (c && key == T) {
+        take = tie_budget > 0;
+        tie_budget -= 1;
+      }
+      sm |= take ? (1u << e) : 0u;
+    }
+    selmask[v] = sm;
+    sel_l += __popc(sm);
+  }
+  int sel_tot;
+  int pos = block_excl_scan_256(sel_l, sc, &sel_tot);
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int g = v * 256 + t;
+    if (g < nvec) {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned m = ((selmask[v] >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((selmask[v] >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
+        o[q] = keys[v][q] & m;
+      }
+      dst[g] = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((selmask[v] >> e) & 1u) {
+          const int col = 8 * g + e;
+          if (pos < kcap) ti[pos] = col;
+          ++pos;
+          if (did_fire) did_fire[col] = 1.0f;
+        }
+    }
+  }
+  for (int j = sel_tot + t; j < kcap; j += 256) ti[j] = -1;
+}
+
+// ------------------------------------------------------------------------------------------
 // sparse decode + losses: x_hat = bf16(sum_j act_j W_dec[idx_j]) + b_dec ; e = x_hat - x
 // (topkautoencoder.py:15-18,87-91,101-102).  One workgroup per activation row, threads over d.
 // pass 0 (aux == 0): writes e (fp32) and sum e^2, sum over valid elements.
@@ -400,6 +569,18 @@ struct EpiTopkDsaeIn {
     }
   }
 };
+
+// sum over rows of dsae_in = dpre W_enc without the [M][d] GEMM: sum_m sum_n dpre[m][n] We[n][c] = sum_n dbe[n] We[n][c]
+// (dbe = column sums of dpre = the encoder-bias gradient).  Partials over 256-latent chunks, fixed order.
+__global__ __launch_bounds__(256) void topk_dsae_colsum_kernel(const float* __restrict__ dbe, const bf16_t* __restrict__ We_b,
+                                                                float* __restrict__ part, int n_p, int d_p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int n0 = blockIdx.y * 256;
+  if (c >= d_p) return;
+  float s = 0.f;
+  for (int i = 0; i < 256 && n0 + i < n_p; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
+  part[(int64_t)blockIdx.y * d_p + c] = s;
+}
 
 // d b_dec[c] = sum_blocks dbd_part[.][c] - sum_tiles dsae_part[.][c]
 __global__ __launch_bounds__(256) void topk_dbd_kernel(const float* __restrict__ dbd_part, int nb, const float* __restrict__ ds_part,

@@ -237,6 +237,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")   # RCCL logs to stdout otherwise
             backend = dist_backend or ("nccl" if device.type == "cuda" else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, **kw)
