@@ -221,6 +221,8 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     return fail(SAE_ERR_INVALID, "Invalid autoencoder variant: %d, must be 'l1' or 'topk'", cfg->variant);
   if (cfg->variant == SAE_VARIANT_TOPK && (cfg->k <= 0 || cfg->k > cfg->n_dict || cfg->k > 1024))
     return fail(SAE_ERR_INVALID, "topk: k=%d must be in [1, min(n_dict, 1024)]", cfg->k);
+  if (cfg->variant == SAE_VARIANT_TOPK && cfg->d_model > 1536)
+    return fail(SAE_ERR_INVALID, "topk: d_model=%d above the 1536 the sparse decoder is built for", cfg->d_model);
   if (cfg->d_model <= 0 || cfg->n_dict <= 0 || cfg->max_rows <= 0)
     return fail(SAE_ERR_INVALID, "d_model, n_dict and max_rows must be positive");
   if (cfg->optimizer != SAE_OPT_RADAM && cfg->optimizer != SAE_OPT_ADAM)
@@ -714,10 +716,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   }
   ev_end(c, KID_TK_SELECT, s);
   ev_begin(c, KID_TK_DECODE, s);
-  hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)Mp), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b, bd, c->e,
+  hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b, bd, c->e,
                      c->dh, c->e2_part, M, d, d_p, n_p, 0);
   if (aux)
-    hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)Mp), dim3(256), 0, s, x, c->aux_dense, c->aux_idx, c->k_aux_cap,
+    hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx, c->k_aux_cap,
                        c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1);
   const int64_t TD = T_rows * d;
   hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,

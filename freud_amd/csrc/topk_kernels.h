@@ -387,46 +387,61 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
 // pass 0 (aux == 0): writes e (fp32) and sum e^2, sum over valid elements.
 // pass 1 (aux == 1): e_hat from the aux selection, accumulates sum (e_hat - e)^2 and writes dh = e_hat - e.
 // ------------------------------------------------------------------------------------------
+// One WAVE per activation row (4 rows per workgroup): lane l owns the d_p/64 contiguous columns
+// [l*cpl, (l+1)*cpl), so every gathered W_dec row is read as one contiguous, fully coalesced line by the wave.
 template <typename T>
 __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ dense,
                                                            const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
                                                            const float* __restrict__ b_dec, float* __restrict__ e,
                                                            float* __restrict__ dh, float* __restrict__ part, int64_t M, int d,
                                                            int d_p, int n_p, int aux) {
-  __shared__ float red[8];
-  __shared__ int s_idx[1024];
-  __shared__ float s_act[1024];
-  const int64_t row = blockIdx.x;
-  const int t = threadIdx.x;
-  for (int j = t; j < kcap; j += 256) {
-    const int ii = idx[row * kcap + j];
-    s_idx[j] = ii;
-    s_act[j] = ii >= 0 ? (float)dense[row * n_p + ii] : 0.f;
-  }
-  __syncthreads();
-  float sq = 0.f;
-  for (int c = t; c < d_p; c += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < kcap; ++j) {
-      const int ii = s_idx[j];
-      if (ii >= 0) acc += s_act[j] * (float)Wd[(int64_t)ii * d_p + c];
+  constexpr int MAXP = 12;                 // column pairs per lane: d_p <= 64 * 2 * MAXP = 1536
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  const int npair = d_p >> 7;              // (d_p / 64) / 2 column pairs per lane
+  const int c0 = lane * 2 * npair;
+  float acc[2 * MAXP];
+#pragma unroll
+  for (int i = 0; i < 2 * MAXP; ++i) acc[i] = 0.f;
+  const int* ri = idx + row * kcap;
+  const bf16_t* rd = dense + row * n_p;
+  for (int j0 = 0; j0 < kcap; j0 += 64) {
+    // 64 (index, activation) pairs at a time, one per lane, broadcast with readlane-style shuffles
+    const int jj = j0 + lane;
+    const int my_i = jj < kcap ? ri[jj] : -1;
+    const float my_a = my_i >= 0 ? (float)rd[my_i] : 0.f;
+    const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
+    for (int j = 0; j < cnt; ++j) {
+      const int ii = __shfl(my_i, j, 64);
+      const float av = __shfl(my_a, j, 64);
+      if (ii < 0) continue;               // wave-uniform
+      const unsigned* wr = reinterpret_cast<const unsigned*>(Wd + (int64_t)ii * d_p + c0);
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p)
+        if (p < npair) {
+          const unsigned u = wr[p];
+          acc[2 * p] += av * __uint_as_float(u << 16);
+          acc[2 * p + 1] += av * __uint_as_float(u & 0xFFFF0000u);
+        }
     }
-    float out = 0.f;
-    if (row < M && c < d) {
-      const float xh = bf16_round(acc) + b_dec[c];
-      if (!aux) {
-        out = xh - (float)x[row * d + c];
-        sq += out * out;
-      } else {
-        out = xh - e[row * d_p + c];                               // e_hat - e: the aux decode predicts the residual
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int p = 0; p < 2 * MAXP; ++p)
+    if (p < 2 * npair) {
+      const int c = c0 + p;
+      float out = 0.f;
+      if (row < M && c < d) {
+        const float xh = bf16_round(acc[p]) + b_dec[c];
+        out = aux ? xh - e[row * d_p + c]                     // e_hat - e: the aux decode predicts the residual
+                  : xh - (float)x[row * d + c];
         sq += out * out;
       }
+      if (!aux) e[row * d_p + c] = out;
+      else dh[row * d_p + c] = out;
     }
-    if (!aux) e[row * d_p + c] = out;
-    else dh[row * d_p + c] = out;
-  }
-  const float s = block_sum_256(sq, red);
-  if (t == 0) part[row] = s;
+  sq = wave_sum(sq);
+  if (lane == 0) part[row] = sq;
 }
 
 // tkf: [0] aux scale, [1] total_variance, [2] fvu, [3] auxk*alpha, [4] mse, [5] coef = alpha*scale*2/tv
