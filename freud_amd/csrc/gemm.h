@@ -151,18 +151,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
     }
     const char* sa = smem + cur * GEMM_STAGE_BYTES;
     const char* sb = sa + 16384;
+    // fragments of k-step kk+1 are requested from LDS before the MFMAs of k-step kk issue (hipcc on its own reuses
+    // one register set and serialises read -> wait -> MFMA); sched_barrier pins that order
+    bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[0][i] = frag_read<AMODE>(sa, 64 * wm + 32 * i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = frag_read<BMODE>(sb, 64 * wn + 32 * j, 0, lane);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+      if (kk + 1 < 4) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag_read<AMODE>(sa, 64 * wm + 32 * i, kk, lane);
+        for (int i = 0; i < 2; ++i) fa[(kk + 1) & 1][i] = frag_read<AMODE>(sa, 64 * wm + 32 * i, kk + 1, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = frag_read<BMODE>(sb, 64 * wn + 32 * j, kk, lane);
+        for (int j = 0; j < 2; ++j) fb[(kk + 1) & 1][j] = frag_read<BMODE>(sb, 64 * wn + 32 * j, kk + 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       char* na = smem + (cur ^ 1) * GEMM_STAGE_BYTES;
