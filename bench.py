@@ -196,6 +196,12 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
+    if args.dbg == 65 and rank == 0:     # diagnostic build: cycle shares of one fused-forward iteration
+        st = eng.debug_read(5, (M // 128) * 16).reshape(-1, 4)
+        st = st[st[:, 3] > 0]
+        per = st[:, :3] / st[:, 3:4]
+        print("fwd stamps (cycles/iteration, median over waves): decoder gaps 0-11 %.0f | decoder gaps 12-23 (+barrier, DMA) %.0f | "
+              "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
     if args.variant == "topk":
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "

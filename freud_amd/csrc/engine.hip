@@ -515,7 +515,17 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       attr_done = true;
     }
     ev_begin(c, KID_FWD_FUSED, s);
-    if (full_wgs > 0) {
+    if (full_wgs > 0 && c->cfg.reserved[1] == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
+      static bool sattr = false;
+      if (!sattr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        sattr = true;
+      }
+      a.block_offset = 0;
+      a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
+      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false, true>), dim3(full_wgs), dim3(256), lds, s, a);
+    } else if (full_wgs > 0) {
       a.block_offset = 0;
       hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false>), dim3(full_wgs), dim3(256), lds, s, a);
     }
@@ -920,6 +930,14 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
         memcpy(&f, &u, 4);
         out[r * cols + j] = f;
       }
+    return SAE_OK;
+  }
+  if (which == 5) {   // stamp sums of the diagnostic fused forward: [wg][wave][4] as floats
+    const int64_t nq = (c->last_M / FF_BM) * 4 * 4;
+    if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
+    std::vector<unsigned long long> tmp((size_t)nq);
+    HIP_TRY(hipMemcpy(tmp.data(), c->dpre, tmp.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nq; ++i) out[i] = (float)tmp[(size_t)i];
     return SAE_OK;
   }
   if (which == 2 && c->topk) {

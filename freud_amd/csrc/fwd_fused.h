@@ -42,11 +42,14 @@ struct FwdFusedArgs {
   int64_t M;
   int d, n_p, ntiles;    // ntiles = n_p / 32 (even)
   int block_offset;      // first workgroup index of this launch
+  unsigned long long* stamps;   // STAMP build only
   int64_t c_rows;        // M_p: a dummy 1-KiB line lives at c[M_p][0..] (engine allocates the slack)
 };
 
 // PAD: the workgroup may contain rows >= M (only the last, ragged workgroup is launched with PAD = true).
-template <typename T, bool PAD>
+// STAMP: diagnostic build (bench.py --dbg 65): s_memtime stamps around the halves of an iteration, summed per wave into
+// a.stamps[wg][wave][4]; the production instantiations contain no stamp.
+template <typename T, bool PAD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -165,7 +168,17 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   for (int i = 0; i < DIST; ++i) ring[i] = load_dec(smem + 3 * FF_WT_BYTES, i);
 
   u32x4 dr[2];
+  unsigned long long tsum[4] = {0, 0, 0, 0};
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long tt;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return tt;
+  };
   for (int j = 0; j <= a.ntiles; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (STAMP) t0 = stamp();
     const char* img_d = smem + ((j + 3) & 3) * FF_WT_BYTES;          // tile j-1
     const char* img_dn = smem + (j & 3) * FF_WT_BYTES;               // tile j (next iteration's decoder operand)
     const char* img_e = smem + ((j + 1) & 3) * FF_WT_BYTES;          // tile j+1
@@ -185,6 +198,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
+      if (STAMP && i == 12) t1 = stamp();
+      if (STAMP && i == 24) t2 = stamp();
       // ---- fragment prefetch (ring carried across iterations)
       {
         const int g = i + DIST;
@@ -243,6 +258,14 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     cfp[0] = cfn[0];
     cfp[1] = cfn[1];
     l1_acc += l1_it * live;
+    if (STAMP) {
+      t3 = stamp();
+      tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += 1;
+    }
+  }
+  if (STAMP && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a.stamps[((int64_t)wg * 4 + w) * 4 + q] = tsum[q];
   }
   // drain the second half of the last pair of latent tiles (its first half went out in the final iteration)
   {
