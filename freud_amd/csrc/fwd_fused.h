@@ -18,6 +18,8 @@
 //   - software pipeline across tiles: the encoder MFMAs of tile j+1 run first, with the bias/ReLU/store work of
 //     tile j in their gaps, then the decoder MFMAs of tile j.  W tiles arrive by LDS-DMA two / one tile ahead.
 #pragma once
+#include <type_traits>
+
 #include "bwd_fused.h"
 
 constexpr int FF_D = 384;
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   auto dma_pair = [&](int p, int jt, int st) {     // pieces 2p, 2p+1 of W^T tile `jt` into ring slot `st`
     const bf16_t* src = a.Wt + (int64_t)jt * FF_BN * FF_D;
     const unsigned dst = smem_base + st * FF_WT_BYTES;
-    glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], dst + loff_t[2 * p], dst + loff_t[2 * p + 1]);
+    glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p])),
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p + 1])));
   };
   const int last = a.ntiles - 1;
 #pragma unroll
@@ -144,30 +147,52 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], Sn, 0, 0, 0);
   }
 
-  // ---- skewed software pipeline.  Iteration j (0..ntiles) issues 48 MFMAs:
+  // ---- skewed software pipeline.  Iteration j (0..ntiles-1) issues 48 MFMAs:
   //   i in [ 0,24): decoder of tile j-1:  x_hat^T[dt] += W tile (transposed reads of slot (j-1)%4) . c^T(j-1)
   //   i in [24,48): encoder of tile j+1:  S(j+1)      += W^T tile (row reads of slot (j+1)%4)      . x^T
-  // while the bias/ReLU/L1/staging work that turns S(j) into c(j) is spread over all 48 gaps (one latent element per
+  // while the bias/ReLU/L1/staging work that turns S(j) into c(j) is spread over the 48 gaps (one latent element per
   // ~3 MFMAs).  A-fragments are requested DIST MFMAs ahead through a 12-deep register ring that is carried ACROSS
   // iterations (the next decoder tile is long resident), so no LDS latency is exposed at iteration boundaries.
   // One barrier per iteration at gap 12: by then the DMA of tile j+1 (issued in iteration j-1) has had a full
   // iteration to land (counted vmcnt); the DMA of tile j+2 is issued after it into the slot whose tile j-2 was last
   // read before this barrier.
+  // The loop is unrolled x4 (template parameter PH = j % 4): ring slots, the S / c^T ping-pong registers and the
+  // staging halves are then compile-time constants, every LDS address is a loop-invariant base register plus an
+  // instruction immediate, and no per-iteration address arithmetic or register copies remain (measured with
+  // s_memtime stamps: that loop-top work cost ~300 of ~2560 cycles per iteration).
   constexpr int DIST = 11, RING = 12;
-  constexpr int EGAP[16] = {6, 9, 11, 14, 17, 19, 22, 25, 27, 30, 33, 35, 38, 41, 43, 46};
-  bf16x8 ring[RING];
-  bf16x8 cfp[2], cfn[2];
+  // per-lane LDS base pointers: *_lo serves slots 0,1 and *_hi slots 2,3 (ds_read immediates are 16-bit)
+  const char *rlo[8], *rhi[8], *tlo[8], *thi[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) cfp[0][q] = cfp[1][q] = (bf16_t)0.f;
-  auto load_dec = [&](const char* img, int i) -> bf16x8 {       // decoder fragment of MFMA i (0..23)
+  for (int i = 0; i < 8; ++i) {
+    rlo[i] = smem + roff[i];
+    rhi[i] = smem + 2 * FF_WT_BYTES + roff[i];
+    tlo[i] = smem + toff[i];
+    thi[i] = smem + 2 * FF_WT_BYTES + toff[i];
+  }
+  bf16x8 ring[RING];
+  f32x16 SA = Sn, SB;          // S(j) lives in SA for even j, SB for odd j
+  bf16x8 CA[2], CB[2];         // c^T(j) lives in CA for even j, CB for odd j; c^T(-1) = 0
+#pragma unroll
+  for (int q = 0; q < 8; ++q) CA[0][q] = CA[1][q] = CB[0][q] = CB[1][q] = (bf16_t)0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) SB[r] = 0.f;
+  auto dec_frag = [&](int slot, int i) -> bf16x8 {       // decoder fragment of MFMA i (0..23) from ring slot `slot`
     const int dt = i >> 1, sk = i & 1;
-    const char* b = img + (dt >> 2) * 8192 + sk * 4096;
-    return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
+    const int off = (slot & 1) * FF_WT_BYTES + (dt >> 2) * 8192 + sk * 4096;
+    const char* b0 = (slot < 2 ? tlo : thi)[2 * (dt & 3)] + off;
+    const char* b1 = (slot < 2 ? tlo : thi)[2 * (dt & 3) + 1] + off;
+    return tr_pair(b0, b1);
+  };
+  auto enc_frag = [&](int slot, int kk) -> bf16x8 {      // encoder fragment of k-step kk (0..23)
+    const int off = (slot & 1) * FF_WT_BYTES + (kk >> 3) * 8192;
+    return *reinterpret_cast<const bf16x8*>((slot < 2 ? rlo : rhi)[kk & 7] + off);
   };
 #pragma unroll
-  for (int i = 0; i < DIST; ++i) ring[i] = load_dec(smem + 3 * FF_WT_BYTES, i);
+  for (int i = 0; i < DIST; ++i) ring[i] = dec_frag(3, i);
 
   u32x4 dr[2];
+  bf16_t* const dummy_line = a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
   unsigned long long tsum[4] = {0, 0, 0, 0};
   auto stamp = [&]() -> unsigned long long {
     unsigned long long tt;
@@ -176,25 +201,28 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     return tt;
   };
-  for (int j = 0; j <= a.ntiles; ++j) {
+  auto body = [&](auto ph_tag, int j) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (STAMP) t0 = stamp();
-    const char* img_d = smem + ((j + 3) & 3) * FF_WT_BYTES;          // tile j-1
-    const char* img_dn = smem + (j & 3) * FF_WT_BYTES;               // tile j (next iteration's decoder operand)
-    const char* img_e = smem + ((j + 1) & 3) * FF_WT_BYTES;          // tile j+1
+    constexpr int PH = decltype(ph_tag)::value;          // == j % 4
+    constexpr int SLOT_D = (PH + 3) & 3, SLOT_DN = PH, SLOT_E = (PH + 1) & 3, SLOT_DMA = (PH + 2) & 3;
+    f32x16& Scur = (PH & 1) ? SB : SA;
+    f32x16& Snxt = (PH & 1) ? SA : SB;
+    bf16x8(&cfn)[2] = (PH & 1) ? CB : CA;
+    bf16x8(&cfp)[2] = (PH & 1) ? CA : CB;
     const int jt = j + 2 <= last ? j + 2 : last;                     // DMA source (clamped in the tail)
-    const float* bj = bias_s + (j <= last ? j : a.ntiles) * FF_BN;   // bias slice of tile j (zeros past the end)
-    char* cst_w = cst + ((j >> 1) & 1) * 4096;                       // staging buffer filled by tiles 2t, 2t+1
-    const char* cst_r = cst + (((j >> 1) & 1) ^ 1) * 4096;           // staging buffer drained (tiles 2t-2, 2t-1)
+    const float* bj = bias_s + j * FF_BN;
+    char* cst_w = cst + ((PH >> 1) & 1) * 4096;                      // staging buffer filled by tiles 2t, 2t+1
+    const char* cst_r = cst + (((PH >> 1) & 1) ^ 1) * 4096;          // staging buffer drained (tiles 2t-2, 2t-1)
     // the first two iterations have no finished pair to drain: their two stores go to a dummy line past the latent
     // (keeps the loop branch-free and the number of memory operations per iteration constant for the counted wait)
-    bf16_t* dst_pair = j >= 2 ? cdrain + 64 * ((j >> 1) - 1) : a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
+    bf16_t* dst_pair = j >= 2 ? cdrain + 64 * ((j >> 1) - 1) : dummy_line;
     const int64_t dst_rstride = j >= 2 ? (int64_t)a.n_p : 0;
-    const float live = j <= last ? 1.f : 0.f;                        // the extra tail iteration must not count in l1
-
-    f32x16 S = Sn;                 // S(j), finished in the previous iteration
     f32x4 bq[4];
     float l1_it = 0.f;
+    // a VGPR copy of S(j) taken once at the top: reading the accumulator registers element by element made hipcc
+    // cluster all 16 elements' VALU work (~85 instructions) into a single MFMA gap
+    const f32x16 S = Scur;
 
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
@@ -203,42 +231,43 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       // ---- fragment prefetch (ring carried across iterations)
       {
         const int g = i + DIST;
-        if (g < 24) ring[g % RING] = load_dec(img_d, g);
-        else if (g < 48) ring[g % RING] = *reinterpret_cast<const bf16x8*>(img_e + ((g - 24) >> 3) * 8192 + roff[(g - 24) & 7]);
-        else ring[g % RING] = load_dec(img_dn, g - 48);
+        if (g < 24) ring[g % RING] = dec_frag(SLOT_D, g);
+        else if (g < 48) ring[g % RING] = enc_frag(SLOT_E, g - 24);
+        else ring[g % RING] = dec_frag(SLOT_DN, g - 48);
       }
       if (i < 4) bq[i] = *reinterpret_cast<const f32x4*>(bj + 8 * i + 4 * ah);    // bias of S rows 8 i + 4 h + (0..3)
       if (i == 12) {
-        // everything older than this iteration's (<= 2) latent stores has completed once <= 2 operations are
+        // everything older than the previous iteration's 2 latent stores has completed once <= 2 operations are
         // outstanding: in particular the 6 DMA pieces of tile j+1.  Raw barrier (no fence).
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 15 || i == 19 || i == 23) dma_pair((i - 15) / 4, jt, (j + 2) & 3);
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (EGAP[e] == i) {     // latent element e: S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
-          // pre-activation rounded to bf16 BEFORE the fp32 bias add, as CPU autocast does (l1autoencoder.py:74)
-          float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
-          if (PAD) cv = row_ok ? cv : 0.f;
-          l1_it += cv;
-          cfn[e >> 3][e & 7] = (bf16_t)cv;
-          if ((e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
-            const int k = e >> 2;
-            const bf16x4 o = {cfn[e >> 3][(e & 7) - 3], cfn[e >> 3][(e & 7) - 2], cfn[e >> 3][(e & 7) - 1], cfn[e >> 3][e & 7]};
-            const int chunk = 4 * (j & 1) + k;               // 16-B chunk of the 128-B row; +8 bytes for h = 1
-            *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
-          }
+      if (i == 15 || i == 19 || i == 23) dma_pair((i - 15) / 4, jt, SLOT_DMA);
+      // latent element e at gap 6 + 5 (e >> 1) + 2 (e & 1): gaps 6, 8, 11, 13, ..., 41, 43 (computed from the unrolled
+      // loop index itself: a lookup table made hipcc emit all 16 elements' work in ONE gap)
+      if (i >= 6 && i < 46 && ((i - 6) % 5 == 0 || (i - 6) % 5 == 2)) {
+        const int e = 2 * ((i - 6) / 5) + ((i - 6) % 5 == 2);   // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+        // pre-activation rounded to bf16 BEFORE the fp32 bias add, as CPU autocast does (l1autoencoder.py:74)
+        float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
+        if (PAD) cv = row_ok ? cv : 0.f;
+        l1_it += cv;
+        cfn[e >> 3][e & 7] = (bf16_t)cv;
+        if ((e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
+          const int k = e >> 2;
+          const bf16x4 o = {cfn[e >> 3][(e & 7) - 3], cfn[e >> 3][(e & 7) - 2], cfn[e >> 3][(e & 7) - 1], cfn[e >> 3][e & 7]};
+          const int chunk = 4 * (PH & 1) + k;              // 16-B chunk of the 128-B row; +8 bytes for h = 1
+          *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
         }
+      }
       // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 8 gaps later
       if (i == 29 || i == 34) {
-        const int r = 8 * (2 * (j & 1) + (i == 34)) + drow_l;
+        const int r = 8 * (2 * (PH & 1) + (i == 34)) + drow_l;
         dr[i == 34] = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
       }
       if (i == 37 || i == 42) {
-        const int p = 2 * (j & 1) + (i == 42);
+        const int p = 2 * (PH & 1) + (i == 42);
         *reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride) = dr[i == 42];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -249,29 +278,41 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
         f32x16 zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-        Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[0], zero, 0, 0, 0);
+        Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[0], zero, 0, 0, 0);
       } else {
-        Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i - 24], Sn, 0, 0, 0);
+        Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[i - 24], Snxt, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    cfp[0] = cfn[0];
-    cfp[1] = cfn[1];
-    l1_acc += l1_it * live;
+    l1_acc += l1_it;
     if (STAMP) {
       t3 = stamp();
       tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += 1;
     }
+  };
+  for (int j4 = 0; j4 < a.ntiles; j4 += 4) {            // ntiles is a multiple of 4 (n_p is a multiple of 128)
+    body(std::integral_constant<int, 0>{}, j4);
+    body(std::integral_constant<int, 1>{}, j4 + 1);
+    body(std::integral_constant<int, 2>{}, j4 + 2);
+    body(std::integral_constant<int, 3>{}, j4 + 3);
   }
   if (STAMP && lane == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) a.stamps[((int64_t)wg * 4 + w) * 4 + q] = tsum[q];
   }
-  // drain the second half of the last pair of latent tiles (its first half went out in the final iteration)
+  // ---- final half iteration: decoder of the last tile (slot 3, c^T in CB); its first DIST fragments are in the ring
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    if (i + DIST < 24) ring[(i + DIST) % RING] = dec_frag(3, i + DIST);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i % RING], CB[i & 1], acc[i >> 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // drain the last pair of latent tiles
   {
     const char* cst_r = cst + (((a.ntiles >> 1) - 1) & 1) * 4096;
 #pragma unroll
-    for (int p = 2; p < 4; ++p) {
+    for (int p = 0; p < 4; ++p) {
       const int r = 8 * p + drow_l;
       const u32x4 v = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
       *reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)) = v;
