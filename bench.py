@@ -179,6 +179,17 @@ def main():
         eng.profile(0)
         print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
 
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the value
+    # measured with rocprofv3 (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled
+    # as MI355X_MICROARCH.md prescribes for gfx950) is kept under profiles/ and quoted when the workload matches
+    traffic = None
+    try:
+        if args.variant == "l1" and (M, d, n) == (65536, 384, 3072):
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -187,7 +198,7 @@ def main():
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel": dom,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,
                      "flops_per_launch": dom_flops},
         "step_mfma_frac": (step_flops * world / (ms_per_step * 1e-3) / 1e12) / (PEAK_BF16_TFLOPS * world),
