@@ -33,10 +33,15 @@ import torch
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def make_inputs(M, d, n, seed, dtype):
+def make_inputs(M, d, n, seed, dtype, kind="lowrank"):
     g = torch.Generator().manual_seed(seed)
-    z = torch.relu(torch.randn(M, 64, generator=g)) * 0.1
-    x = (z @ torch.randn(64, d, generator=g)).to(dtype)
+    if kind == "lowrank":      # low-rank, learnable
+        z = torch.relu(torch.randn(M, 64, generator=g)) * 0.1
+        x = (z @ torch.randn(64, d, generator=g)).to(dtype)
+    elif kind == "normal":
+        x = torch.randn(M, d, generator=g).to(dtype)
+    else:                      # "zeros": clock diagnostic only (DVFS: the chip holds a higher clock on trivial operands)
+        x = torch.zeros(M, d, dtype=dtype)
     torch.manual_seed(0)
     W = torch.empty(d, n)
     torch.nn.init.orthogonal_(W)
@@ -74,6 +79,8 @@ def main():
     ap.add_argument("--variant", default="l1", choices=["l1", "topk"], help="topk = BASELINE configs[2] style run")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
+    ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
+                    help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -104,7 +111,7 @@ def main():
 
     M, d, n = args.rows, args.d, args.n
     dtype = getattr(torch, args.x_dtype)
-    x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype)
+    x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype, kind=args.data)
     x = x_cpu.cuda()
     if args.variant == "topk":
         eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
@@ -193,7 +200,8 @@ def main():
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
         "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}"},
@@ -207,12 +215,19 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
-    if args.dbg == 65 and rank == 0:     # diagnostic build: cycle shares of one fused-forward iteration
-        st = eng.debug_read(5, (M // 128) * 16).reshape(-1, 4)
+    if args.dbg == 65 and rank == 0:     # diagnostic build: cycle shares of one fused-forward iteration + in-kernel clock
+        st = eng.debug_read(5, (M // 128) * 32).reshape(-1, 8)
         st = st[st[:, 3] > 0]
         per = st[:, :3] / st[:, 3:4]
         print("fwd stamps (cycles/iteration, median over waves): decoder gaps 0-11 %.0f | decoder gaps 12-23 (+barrier, DMA) %.0f | "
               "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
+        print("fwd in-kernel clock %.0f MHz (median), loop cycles/iteration %.0f" %
+              (np.median(st[:, 4] / st[:, 5]) * 100.0, np.median(st[:, 4] / st[:, 3])), file=sys.stderr)
+    if args.dbg == 66 and rank == 0:     # clock stamps of the fused backward
+        st = eng.debug_read(6, (n // 128 + (1 if n % 128 else 0)) * 40).reshape(-1, 4)
+        st = st[st[:, 3] > 0]
+        print("bwd in-kernel clock %.0f MHz (median), loop cycles/step %.0f (ideal 72 MFMA x 32 = 2304)" %
+              (np.median(st[:, 0] / st[:, 1]) * 100.0, np.median(st[:, 0] / st[:, 2])), file=sys.stderr)
     if args.variant == "topk":
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "

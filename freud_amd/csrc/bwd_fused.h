@@ -49,6 +49,7 @@ struct BwdFusedArgs {
   int splits;
   int steps_total;     // M_p / 32
   int dbg;             // timing experiments only: 4 = skip in-loop DMA
+  unsigned long long* clk;   // diagnostic (bench.py --dbg 66), normally null: [wg][4] = s_memtime / s_memrealtime around the loop
 };
 
 // transposed-read fragment (A or B operand of v_mfma_f32_32x32x16_bf16) from a dual-use image, 32 columns
@@ -197,66 +198,88 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     return __builtin_bit_cast(bf16x8, v);
   };
 
+  // The step loop is rotated: the barrier that hands over the next stage sits DIST MFMAs before the end of a step,
+  // and the gaps after it already request the first fragments (and the c fragments) of the NEXT step from the other
+  // stage, so no step starts with an exposed LDS round trip.  RING divides 72, which keeps every ring slot static.
+  constexpr int RING = 12, DIST = RING - 1;
+  auto load_frag = [&](const char* img_d, int i) -> bf16x8 {
+    // A-operand fragment of MFMA i (0..71) of the step whose stage image starts at img_d:
+    //   i in [ 0,24): dc += dx_hat(rows; ds_read_b128)      . W^T fragment i (registers)
+    //   i in [24,48): dW[dt] += dx_hat^T (transposed reads) . c fragment s      (dt = (i-24)/2, s = i&1)
+    //   i in [48,72): dW[dt] += x^T (transposed reads)      . dpre fragment s   (dpre made from dc in gaps 30..45)
+    if (i < 24) {
+      return *reinterpret_cast<const bf16x8*>(img_d + (i >> 3) * 8192 + roff[i & 7]);
+    } else {
+      const char* img = i < 48 ? img_d : img_d + BF_DXH_BYTES;
+      const int tt = i < 48 ? i - 24 : i - 48, dt = tt >> 1, sk = tt & 1;
+      const char* b = img + (dt >> 2) * 8192 + sk * 4096;
+      return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
+    }
+  };
+  // dc starts at (1/M)/scale: the L1 term sign(c)/M of d loss / d c, so the gate needs no add.  The dc chain is issued
+  // as VGPR-form MFMAs (inline asm): the gate reads dc with plain VALU, and hipcc no longer parks a dW accumulator in
+  // VGPRs to make room for it (that cost 48 v_accvgpr moves per step).
+  f32x16 cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = inv_m;
+
+  bf16x8 ring[RING], cf[2], pf[2];
+#pragma unroll
+  for (int i = 0; i <= DIST; ++i) ring[i] = load_frag(smem, i);     // includes gap 0 of the first step
+  cf[0] = tr_pair(smem + 2 * BF_DXH_BYTES + coff0, smem + 2 * BF_DXH_BYTES + coff1);
+  cf[1] = tr_pair(smem + 2 * BF_DXH_BYTES + 4096 + coff0, smem + 2 * BF_DXH_BYTES + 4096 + coff1);
+
+  unsigned long long clk_t0 = 0, clk_r0 = 0;
+  if (a.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
     // the last step re-copies its own rows into the idle stage instead of branching around the DMA
     const int64_t next_row0 = (int64_t)(step + 1 < step_end ? step + 1 : step) * BF_BM;
     const char* img_d = smem + cur * BF_STAGE_BYTES;
-    const char* img_x = img_d + BF_DXH_BYTES;
-    const char* img_c = img_d + 2 * BF_DXH_BYTES;
-
-    // A-operand fragment of MFMA i (0..71):
-    //   i in [ 0,24): dc += dx_hat(rows; ds_read_b128)      . W^T fragment i (registers)
-    //   i in [24,48): dW[dt] += dx_hat^T (transposed reads) . c fragment s      (dt = (i-24)/2, s = i&1)
-    //   i in [48,72): dW[dt] += x^T (transposed reads)      . dpre fragment s   (dpre made from dc in gaps 30..45)
-    auto load_frag = [&](int i) -> bf16x8 {
-      if (i < 24) {
-        return *reinterpret_cast<const bf16x8*>(img_d + (i >> 3) * 8192 + roff[i & 7]);
-      } else {
-        const char* img = i < 48 ? img_d : img_x;
-        const int tt = i < 48 ? i - 24 : i - 48, dt = tt >> 1, sk = tt & 1;
-        const char* b = img + (dt >> 2) * 8192 + sk * 4096;
-        return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
-      }
-    };
-
-    bf16x8 cf[2], pf[2];
-    cf[0] = tr_pair(img_c + coff0, img_c + coff1);
-    cf[1] = tr_pair(img_c + 4096 + coff0, img_c + 4096 + coff1);
-    f32x16 dc;        // starts at (1/M)/scale: the L1 term sign(c)/M of d loss / d c, so the gate needs no add
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dc[r] = inv_m;
-    constexpr int DIST = 12;         // fragments are requested DIST MFMAs ahead of their use
-    bf16x8 ring[DIST + 1];
-#pragma unroll
-    for (int i = 0; i < DIST; ++i) ring[i] = load_frag(i);
+    const char* nxt_d = smem + (cur ^ 1) * BF_STAGE_BYTES;
+    f32x16 dc;
 
 #pragma unroll
     for (int i = 0; i < 72; ++i) {
-      // ---- gap work (issues while the previous MFMA occupies the matrix pipe)
-      if (i + DIST < 72) ring[(i + DIST) % (DIST + 1)] = load_frag(i + DIST);
-      if (i % 3 == 1 && i / 3 < 7 && !(a.dbg & 4)) dma_pair(i / 3, next_row0, cur ^ 1);
-      if (i >= 30 && i < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
-        const int e = i - 30, s2 = e >> 3, j = e & 7;
-        const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed
-        db_acc += gv;
-        pf[s2][j] = (bf16_t)gv;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 fa = ring[i % (DIST + 1)];
-      if (i < 24) {
-        dc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, wfrag[i], dc, 0, 0, 0);
+      const bf16x8 fa = ring[i % RING];
+      if (i == 0) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(dc) : "v"(fa), "v"(wfrag[0]), "v"(cinit));
+      } else if (i < 24) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dc) : "v"(fa), "v"(wfrag[i]));
       } else if (i < 48) {
         acc[(i - 24) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cf[i & 1], acc[(i - 24) >> 1], 0, 0, 0);
       } else {
         acc[(i - 48) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[i & 1], acc[(i - 48) >> 1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      // ---- gap g = i + 1 (issues while MFMA i occupies the matrix pipe); gap 72 is gap 0 of the next step
+      const int g = i + 1;
+      if (g == 72 - DIST) {
+        // every read of this stage has been issued and returned, this wave's DMA pieces of the next step have landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... and everybody's
+        cf[0] = tr_pair(nxt_d + 2 * BF_DXH_BYTES + coff0, nxt_d + 2 * BF_DXH_BYTES + coff1);
+      }
+      if (g == 72 - DIST + 1) cf[1] = tr_pair(nxt_d + 2 * BF_DXH_BYTES + 4096 + coff0, nxt_d + 2 * BF_DXH_BYTES + 4096 + coff1);
+      if (g + DIST < 72) ring[(g + DIST) % RING] = load_frag(img_d, g + DIST);
+      else ring[(g + DIST) % RING] = load_frag(nxt_d, g + DIST - 72);
+      if (g % 3 == 1 && g / 3 < 7) dma_pair(g / 3, next_row0, cur ^ 1);
+      if (g >= 30 && g < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
+        const int e = g - 30, s2 = e >> 3, j = e & 7;
+        const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed
+        db_acc += gv;
+        pf[s2][j] = (bf16_t)gv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next step have landed
-    __syncthreads();                                    // ... and everybody's; all reads of this stage are done
     cur ^= 1;
+  }
+  if (a.clk) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      unsigned long long* o = a.clk + (int64_t)blockIdx.x * 4;
+      o[0] = t1 - clk_t0; o[1] = r1 - clk_r0; o[2] = (unsigned long long)(step_end - step_begin); o[3] = 1;
+    }
   }
 
   // ---- epilogue: dW slab of this row range (rows d = 32 dt + (r&3) + 8 (r>>2) + 4 h, column nw + lane&31)

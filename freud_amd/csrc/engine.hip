@@ -589,6 +589,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       a.unscaled = c->use_fused_fwd ? 1 : 0;
       a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
       a.dbg = c->cfg.reserved[1];
+      // diagnostic clock stamps go to the second half of the (unused on this path) dpre buffer
+      a.clk = c->cfg.reserved[1] == 66 ? reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16) : nullptr;
       splits = c->bwd_splits;
       if (splits > a.steps_total) splits = a.steps_total;
       a.splits = splits;
@@ -932,8 +934,16 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
       }
     return SAE_OK;
   }
-  if (which == 5) {   // stamp sums of the diagnostic fused forward: [wg][wave][4] as floats
-    const int64_t nq = (c->last_M / FF_BM) * 4 * 4;
+  if (which == 6) {   // clock stamps of the fused backward (reserved[1] == 66): [wg][4] as floats
+    const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4;
+    if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
+    std::vector<unsigned long long> tmp((size_t)nq);
+    HIP_TRY(hipMemcpy(tmp.data(), reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16), tmp.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nq; ++i) out[i] = (float)tmp[(size_t)i];
+    return SAE_OK;
+  }
+  if (which == 5) {   // stamp sums of the diagnostic fused forward: [wg][wave][8] as floats
+    const int64_t nq = (c->last_M / FF_BM) * 4 * 8;
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
     std::vector<unsigned long long> tmp((size_t)nq);
     HIP_TRY(hipMemcpy(tmp.data(), c->dpre, tmp.size() * 8, hipMemcpyDeviceToHost));

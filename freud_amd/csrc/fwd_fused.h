@@ -50,7 +50,7 @@ struct FwdFusedArgs {
 
 // PAD: the workgroup may contain rows >= M (only the last, ragged workgroup is launched with PAD = true).
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime stamps around the halves of an iteration, summed per wave into
-// a.stamps[wg][wave][4]; the production instantiations contain no stamp.
+// a.stamps[wg][wave][8] (+ loop s_memtime / s_memrealtime deltas in [4], [5]); the production instantiations contain no stamp.
 template <typename T, bool PAD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,15 +290,22 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += 1;
     }
   };
+  unsigned long long clk_t0 = 0, clk_r0 = 0;
+  if (STAMP) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int j4 = 0; j4 < a.ntiles; j4 += 4) {            // ntiles is a multiple of 4 (n_p is a multiple of 128)
     body(std::integral_constant<int, 0>{}, j4);
     body(std::integral_constant<int, 1>{}, j4 + 1);
     body(std::integral_constant<int, 2>{}, j4 + 2);
     body(std::integral_constant<int, 3>{}, j4 + 3);
   }
-  if (STAMP && lane == 0) {
+  if (STAMP) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a.stamps[((int64_t)wg * 4 + w) * 4 + q] = tsum[q];
+      for (int q = 0; q < 4; ++q) a.stamps[((int64_t)wg * 4 + w) * 8 + q] = tsum[q];
+      a.stamps[((int64_t)wg * 4 + w) * 8 + 4] = t1 - clk_t0;
+      a.stamps[((int64_t)wg * 4 + w) * 8 + 5] = r1 - clk_r0;
+    }
   }
   // ---- final half iteration: decoder of the last tile (slot 3, c^T in CB); its first DIST fragments are in the ring
 #pragma unroll
