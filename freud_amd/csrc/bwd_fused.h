@@ -87,6 +87,11 @@ __device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1
       : "memory");
 }
 
+// Pair p of the next step's 7 DMA pairs is issued in gap BF_DMA_A * p + BF_DMA_B.  Measured placements (cycles per
+// step at C2, same box): 3p+1 3360, 5p+1 3325 (shipped), 2p+1 3565, p+1 3814 (back-to-back pieces cost more each),
+// 8p+1 3860 and 3p+24 4044 (the last pieces land after the hand-over barrier), one wave per gap (staggered) 3710.
+constexpr int BF_DMA_A = 5, BF_DMA_B = 1;
+
 __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -263,7 +268,8 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       if (g == 72 - DIST + 1) cf[1] = tr_pair(nxt_d + 2 * BF_DXH_BYTES + 4096 + coff0, nxt_d + 2 * BF_DXH_BYTES + 4096 + coff1);
       if (g + DIST < 72) ring[(g + DIST) % RING] = load_frag(img_d, g + DIST);
       else ring[(g + DIST) % RING] = load_frag(nxt_d, g + DIST - 72);
-      if (g % 3 == 1 && g / 3 < 7) dma_pair(g / 3, next_row0, cur ^ 1);
+      if (g >= BF_DMA_B && (g - BF_DMA_B) % BF_DMA_A == 0 && (g - BF_DMA_B) / BF_DMA_A < 7)
+        dma_pair((g - BF_DMA_B) / BF_DMA_A, next_row0, cur ^ 1);
       if (g >= 30 && g < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = g - 30, s2 = e >> 3, j = e & 7;
         const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed

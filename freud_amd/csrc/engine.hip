@@ -578,12 +578,6 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     int splits = c->dw_splits;
     int db_rows = (int)(Mp / 128);
     if (c->use_fused_bwd) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_d384_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES));
-        attr_set = true;
-      }
       BwdFusedArgs a{};
       a.dxh = c->dxh; a.xb = c->xb_cur; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
       a.unscaled = c->use_fused_fwd ? 1 : 0;
@@ -596,7 +590,15 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       a.splits = splits;
       db_rows = splits;
       ev_begin(c, KID_BWD_FUSED, s);
-      hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+      {
+        static bool attr_set = false;
+        if (!attr_set) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_d384_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+      }
       ev_end(c, KID_BWD_FUSED, s);
       HIP_TRY(hipGetLastError());
     } else {
