@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--variant", default="l1", choices=["l1", "topk"], help="topk = BASELINE configs[2] style run")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
+    ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
@@ -115,7 +116,7 @@ def main():
     x = x_cpu.cuda()
     if args.variant == "topk":
         eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
-                        clip_thresh=1.0, device_id=local_rank)
+                        clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128)
         eng.set_topk_options(1e6, 1024)
         g = torch.Generator().manual_seed(0)
         We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
@@ -124,7 +125,7 @@ def main():
                         "b_dec": np.zeros(d, np.float32)})
     else:
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
-                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg)
+                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     grads = eng.grad_tensor() if use_dist else None
     total_steps, base_lr = 100000, 4e-4

@@ -69,24 +69,6 @@ __device__ __forceinline__ bf16x8 tr_frag_perm(const char* img, int col0, int s,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// LDS-DMA issued from inline asm so that hipcc does not track it: with the builtin it waits vmcnt(0) before the
-// next LDS read and the copy of step i+1 cannot overlap the MFMAs of step i.  We wait ourselves
-// (s_waitcnt vmcnt(0) + barrier at the end of the step).  M0 carries the wave-uniform LDS byte address.
-// Two pieces per statement (one M0 save/restore): piece k copies 64 x 16 B from sbase_k + voff (per lane) to
-// LDS [dst_k, dst_k + 1024).
-__device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
-                                          unsigned dst0, unsigned dst1) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
-      : "memory");
-}
-
 // Pair p of the next step's 7 DMA pairs is issued in gap BF_DMA_A * p + BF_DMA_B.  Measured placements (cycles per
 // step at C2, same box): 3p+1 3360, 5p+1 3325 (shipped), 2p+1 3565, p+1 3814 (back-to-back pieces cost more each),
 // 8p+1 3860 and 3p+24 4044 (the last pieces land after the hand-over barrier), one wave per gap (staggered) 3710.

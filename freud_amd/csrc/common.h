@@ -27,14 +27,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// Block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0.
+// Sum over a group of 256 consecutive threads (4 waves); result valid in the group's first thread.  blockDim.x is 256
+// (one group) or 512 (two groups, each with its own `red`); every thread of the block must call it.
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
   v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
+  const int w = (threadIdx.x >> 6) & 3;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
+}
+
+// LDS-DMA issued from inline asm so that hipcc does not track it (with the builtin it waits vmcnt(0) before the next LDS
+// read, and a copy can never overlap the MFMAs that follow it): the caller waits with its own s_waitcnt vmcnt + barrier.
+// M0 carries the wave-uniform LDS byte address.  Two pieces per statement (one M0 save/restore): piece k copies
+// 64 x 16 B from sbase_k + voff_k (per lane) to LDS [dst_k, dst_k + 1024).
+__device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
+                                          unsigned dst0, unsigned dst1) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
+      : "memory");
 }
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

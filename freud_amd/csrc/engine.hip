@@ -11,6 +11,9 @@
 
 #include "../../include/freud_sae.h"
 #include "l1_kernels.h"
+#include "gemm256.h"
+
+static bool g_force_gemm128 = false;   // sae_config.reserved[2] == 1: keep every GEMM on the 128x128 kernel (A/B timing, tests)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
 #include "topk_kernels.h"
@@ -135,15 +138,34 @@ extern "C" int sae_dominant_kernel(sae_ctx* c) { return c ? dominant_kid(c) : KI
 // ------------------------------------------------------------------------------------------
 // TopK variant: buffers
 // ------------------------------------------------------------------------------------------
+// Split-K factor of a weight-gradient GEMM with an [r128 x c128] grid of 128x128 output tiles and `ktiles` K tiles: the
+// launch runs in rounds of one workgroup per CU (256x256 kernel, both dimensions even) or two (128x128 kernel); pick
+// the factor that minimises rounds / factor (plus a small price per slab for the reduction pass).
+static int choose_splits(int r128, int c128, int64_t ktiles) {
+  const bool big = !g_force_gemm128 && r128 % 2 == 0 && c128 % 2 == 0;
+  const int tiles = big ? (r128 / 2) * (c128 / 2) : r128 * c128, slots = big ? 256 : 512;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    if (sp > 1 && ktiles / sp < 8) break;
+    const int rounds = (tiles * sp + slots - 1) / slots;
+    const double cost = (double)rounds / sp + 0.04 * sp;
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  return best;
+}
+
 static int topk_create(sae_ctx* c, int64_t Mp) {
   c->k = c->cfg.k;
   c->k_aux_cap = c->d / 2 > 0 ? c->d / 2 : 1;           // k_aux = x.shape[-1] // 2 (topkautoencoder.py:110)
   if (c->k_aux_cap > 1024) return fail(SAE_ERR_INVALID, "topk: d_model/2 = %d aux latents exceed the 1024 supported", c->k_aux_cap);
   c->nparams = 2 * c->nW + c->n_p + c->d_p;
   const int64_t ntail = SAE_NUM_METRICS + c->n_p;       // metrics + did_fire flags ride in the all-reduced buffer
-  const int tiles = (c->n_p / 128) * (c->d_p / 128);
-  int splits = tiles >= 256 ? 1 : (512 + tiles - 1) / tiles;
-  if (splits > 64) splits = 64;
+  g_force_gemm128 = c->cfg.reserved[2] == 1;
+  const int splits = choose_splits(c->n_p / 128, c->d_p / 128, Mp / 64);
   c->dw_splits = splits;
 #define TALLOC(ptr, bytes)                                                                                   \
   do {                                                                                                       \
@@ -252,12 +274,8 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     *out = c;
     return SAE_OK;
   }
-  const int out_tiles = (c->d_p / 128) * (c->n_p / 128);
-  const int ktiles = (int)(2 * Mp / 64);
-  c->dw_splits = 512 / out_tiles;
-  if (c->dw_splits < 1) c->dw_splits = 1;
-  if (c->dw_splits > ktiles) c->dw_splits = ktiles;
-  if (c->dw_splits > 64) c->dw_splits = 64;
+  g_force_gemm128 = cfg->reserved[2] == 1;
+  c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
@@ -449,6 +467,21 @@ extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
 // ------------------------------------------------------------------------------------------
 template <int AM, int BM_, class Epi>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  if (!g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0) {   // both output dimensions are multiples of 256
+    static bool attr256_set = false;
+    auto kern256 = gemm256_bf16_kernel<AM, BM_, Epi>;
+    if (!attr256_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern256), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  G2_LDS_BYTES));
+      attr256_set = true;
+    }
+    GemmArgs g2 = g;
+    g2.nbm = g.nbm / 2;
+    g2.nbn = g.nbn / 2;
+    hipLaunchKernelGGL(kern256, dim3(g2.nbm * g2.nbn * g2.splits), dim3(512), G2_LDS_BYTES, s, g2, epi);
+    HIP_TRY(hipGetLastError());
+    return SAE_OK;
+  }
   static bool attr_set = false;
   auto kern = gemm_bf16_kernel<AM, BM_, Epi>;
   if (!attr_set) {

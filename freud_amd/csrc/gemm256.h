@@ -1,0 +1,174 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950: the large-shape sibling of gemm.h (same operand modes, K segments, split-K and
+// epilogue functors; used whenever both output dimensions are multiples of 256).
+//
+//   512 threads = 8 waves (2 per SIMD) in a 2 (M) x 4 (N) arrangement, each wave a 128x64 output = 4x2
+//   v_mfma_f32_32x32x16_bf16 tiles (128 accumulator registers, <= 256 registers per wave so two waves share a SIMD and
+//   one covers the other's LDS-DMA issue and barrier stalls).
+//   Per 64-deep K tile a wave issues 32 MFMAs for 24 fragment reads (0.75 LDS reads per MFMA, 1.0 in the 128x128
+//   kernel) and 8 LDS-DMA pieces (0.25 KiB of staging per MFMA, 0.5 there).
+//   Staging: global_load_lds_dwordx4 straight into two 64 KiB stages; the XOR swizzles of gemm.h are applied to the
+//   per-lane SOURCE chunk so that the 1 KiB a piece writes is contiguous in LDS.  The pieces of K tile t+1 are issued
+//   between the MFMA groups of tile t and waited for (vmcnt(0) + barrier) at its end.
+//   Epilogue: the tile leaves as four 128x128 sub-tiles through fp32 LDS, two at a time, one per 256-thread half,
+//   through the same functors as gemm.h (their block reductions are 256-thread-group local).
+#pragma once
+#include "gemm.h"
+
+constexpr int G2_BM = 256, G2_BN = 256;
+constexpr int G2_OPER_BYTES = 256 * GEMM_BK * 2;                      // 32 KiB per operand tile
+constexpr int G2_STAGE_BYTES = 2 * G2_OPER_BYTES;                     // 64 KiB
+constexpr int G2_SUB_FLOATS = 128 * GEMM_EPI_PITCH;                   // one 128x128 fp32 sub-tile
+constexpr int G2_LDS_BYTES = 2 * G2_SUB_FLOATS * 4 > 2 * G2_STAGE_BYTES ? 2 * G2_SUB_FLOATS * 4 : 2 * G2_STAGE_BYTES;
+
+// Source byte offset (relative to the tile origin) of the 16 B that lane `lane` of DMA piece p (0..31) moves; the piece
+// lands at LDS bytes [1024 p, 1024 p + 1024) of the operand image.
+template <int MODE>
+__device__ __forceinline__ unsigned g2_src_off(int p, int lane, int64_t ld) {
+  if constexpr (MODE == OP_ROW) {
+    // image [256 rows][128 B]: piece = rows 8p..8p+7; physical chunk pc of row r holds source chunk pc ^ ((r >> 1) & 7)
+    const int r = 8 * p + (lane >> 3), pc = lane & 7;
+    return (unsigned)((r * ld + ((pc ^ ((r >> 1) & 7)) << 3)) * 2);
+  } else {
+    // two [64 k][128 cols] images of 16 KiB (256-B rows): piece = k rows 4pp..4pp+3 of image p >> 4
+    const int sub = p >> 4, r = 4 * (p & 15) + (lane >> 4), pc = lane & 15;
+    return (unsigned)((r * ld + sub * 128 + ((pc ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3)) * 2);
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ bf16x8 g2_frag(const char* img, int base32, int kk, int lane) {
+  if constexpr (MODE == OP_ROW) return frag_read<OP_ROW>(img, base32, kk, lane);
+  else return frag_read<OP_KMAJOR>(img + (base32 >> 7) * 16384, base32 & 127, kk, lane);
+}
+
+// g.nbm / g.nbn count 256-wide tiles here.
+template <int AMODE, int BMODE, class Epi>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+
+  const int nblk = g.nbm * g.nbn * g.splits;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int split = id / (g.nbm * g.nbn);
+  id -= split * (g.nbm * g.nbn);
+  const int bm = id / g.nbn, bn = id - bm * g.nbn;
+  const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
+  const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto a_ptr = [&](int kt) -> const bf16_t* {
+    const bool s1 = kt >= g.ktiles0;
+    const bf16_t* base = s1 ? g.A1 : g.A0;
+    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    if constexpr (AMODE == OP_ROW) return base + (int64_t)(bm * G2_BM) * g.lda + k;
+    else return base + (int64_t)k * g.lda + bm * G2_BM;
+  };
+  auto b_ptr = [&](int kt) -> const bf16_t* {
+    const bool s1 = kt >= g.ktiles0;
+    const bf16_t* base = s1 ? g.B1 : g.B0;
+    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    if constexpr (BMODE == OP_ROW) return base + (int64_t)(bn * G2_BN) * g.ldb + k;
+    else return base + (int64_t)k * g.ldb + bn * G2_BN;
+  };
+
+  // wave w moves pieces 4w..4w+3 of both operand tiles; pair q = (A piece 4w+q, B piece 4w+q)
+  unsigned voff_a[4], voff_b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    voff_a[q] = g2_src_off<AMODE>(4 * w + q, lane, g.lda);
+    voff_b[q] = g2_src_off<BMODE>(4 * w + q, lane, g.ldb);
+  }
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned piece0 = (unsigned)__builtin_amdgcn_readfirstlane(4 * w * 1024);
+  auto issue = [&](int kt, int stage, int q) {
+    const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
+    glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
+  };
+
+  if (kt_begin < kt_end) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(kt_begin, 0, q);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // the last tile re-copies itself into the idle stage instead of branching around the DMA
+    const int nxt = kt + 1 < kt_end ? kt + 1 : kt;
+    const char* sa = smem + cur * G2_STAGE_BYTES;
+    const char* sb = sa + G2_OPER_BYTES;
+    bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(sa, 128 * wm + 32 * i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(sb, 64 * wn + 32 * j, 0, lane);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 2) {        // all pieces of the next tile leave early: they have the rest of this tile to land
+        issue(nxt, cur ^ 1, 2 * kk);
+        issue(nxt, cur ^ 1, 2 * kk + 1);
+      }
+      if (kk + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[(kk + 1) & 1][i] = g2_frag<AMODE>(sa, 128 * wm + 32 * i, kk + 1, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[(kk + 1) & 1][j] = g2_frag<BMODE>(sb, 64 * wn + 32 * j, kk + 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
+    __syncthreads();                                    // ... and everybody's; all reads of this stage are done
+    cur ^= 1;
+  }
+
+  // ---- epilogue: two passes (sub-tile columns), each pass two 128x128 sub-tiles (rows), one per 256-thread half
+  float* tile = reinterpret_cast<float*>(smem);
+  const int half = t >> 8, tl = t & 255;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((wn >> 1) == pass) {
+      float* dst = tile + wm * G2_SUB_FLOATS;
+      const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[row * GEMM_EPI_PITCH + 64 * (wn & 1) + 32 * j + c] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const float* src = tile + half * G2_SUB_FLOATS;
+    const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
+    epi.tile_begin(row0, col0, split);
+    {
+      const int c4 = (tl & 31) * 4;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = (tl >> 5) + 8 * it;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
+        epi.apply(row0 + row, col0 + c4, v);
+      }
+    }
+    __syncthreads();
+    epi.tile_end(tile + half * G2_SUB_FLOATS);
+    __syncthreads();
+  }
+}

@@ -170,7 +170,7 @@ struct EpiEnc {
   }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256(l1, scratch);
-    if (threadIdx.x == 0) l1_part[tile_id] = s;
+    if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
   }
 };
 
@@ -212,7 +212,7 @@ struct EpiDec {
   __device__ void tile_end(float* scratch) {
     const float a = block_sum_256(sq, scratch);
     const float b = block_sum_256(plain, scratch + 8);
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 255) == 0) {
       sq_part[2 * tile_id] = a;
       sq_part[2 * tile_id + 1] = b;
     }
@@ -248,7 +248,7 @@ struct EpiDpre {
   }
   __device__ void tile_end(float* scratch) {
     // thread t owns columns 4*(t&31).. of row group t>>5: reduce the 8 row groups through LDS
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
     __syncthreads();

@@ -543,7 +543,7 @@ struct EpiTopkDpre {
   }
   __device__ void tile_end(float* scratch) {
     if (!last) return;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
     __syncthreads();
@@ -572,7 +572,7 @@ struct EpiTopkDsaeIn {
     for (int j = 0; j < 4; ++j) colsum[j] += bf16_round(v[j]);
   }
   __device__ void tile_end(float* scratch) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
     __syncthreads();
