@@ -41,6 +41,18 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Output-tile coordinates of (remapped) workgroup id: tiles are walked in groups of GEMM_GROUP_M tile rows, row index
+// fastest, so that the ~32 workgroups an XCD runs at a time form a compact GROUP_M x (32 / GROUP_M) patch and share
+// their A and B tiles in that XCD's L2 (a plain row-major walk shares only A).
+constexpr int GEMM_GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& bm, int& bn) {
+  const int per_group = GEMM_GROUP_M * nbn;
+  const int grp = id / per_group, r = id - grp * per_group;
+  const int rows = nbm - grp * GEMM_GROUP_M < GEMM_GROUP_M ? nbm - grp * GEMM_GROUP_M : GEMM_GROUP_M;
+  bn = r / rows;
+  bm = grp * GEMM_GROUP_M + (r - bn * rows);
+}
+
 template <int MODE>
 __device__ __forceinline__ void tile_load(u32x4 (&regs)[4], const bf16_t* base, int64_t ld, int t) {
   if constexpr (MODE == OP_ROW) {
@@ -106,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   int id = xcd_remap(blockIdx.x, nblk);
   const int split = id / (g.nbm * g.nbn);
   id -= split * (g.nbm * g.nbn);
-  const int bm = id / g.nbn, bn = id - bm * g.nbn;
+  int bm, bn;
+  tile_coords(id, g.nbm, g.nbn, bm, bn);
   const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
   const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
 

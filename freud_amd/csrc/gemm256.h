@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   int id = xcd_remap(blockIdx.x, nblk);
   const int split = id / (g.nbm * g.nbn);
   id -= split * (g.nbm * g.nbn);
-  const int bm = id / g.nbn, bn = id - bm * g.nbn;
+  int bm, bn;
+  tile_coords(id, g.nbm, g.nbn, bm, bn);
   const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
   const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
 
