@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the SAE train step (BASELINE.json metric: SAE train activations/sec).
 
-  python bench.py --gpus 1 --steps 50 --warmup 10
+  python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,6 +16,11 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the tied
 GEMM pair), timed with HIP events on the launch stream inside the timed region; `cpu_baseline` is
 the CPU oracle (oracle/sae_oracle.py, a port of the reference's step) timed on this box's host
 cores on a bounded sample (rank 0, N=1 only).
+
+Before the W warm-up steps the same step is run untimed for --spinup seconds (default 1 s): an idle MI355X starts in a
+low power state and needs some tens of milliseconds of load to reach its sustained clocks; without it a 10 + 50 step
+run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second or more.  The timed region is still
+exactly K steps after W warm-up steps.
 """
 import argparse
 import json
@@ -68,8 +73,9 @@ def cpu_baseline(x, W, b, steps, lr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed steps before the warm-up (clock ramp)")
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--d", type=int, default=384)
     ap.add_argument("--n", type=int, default=3072)
@@ -139,6 +145,12 @@ def main():
         else:
             eng.step(x, lr_of(i))
 
+    if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup:
+            for _ in range(20):
+                one_step(0)
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -200,7 +212,7 @@ def main():
 
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_s": args.spinup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
         "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "

@@ -7,8 +7,8 @@
 //   Per 64-deep K tile a wave issues 32 MFMAs for 24 fragment reads (0.75 LDS reads per MFMA, 1.0 in the 128x128
 //   kernel) and 8 LDS-DMA pieces (0.25 KiB of staging per MFMA, 0.5 there).
 //   Staging: global_load_lds_dwordx4 straight into two 64 KiB stages; the XOR swizzles of gemm.h are applied to the
-//   per-lane SOURCE chunk so that the 1 KiB a piece writes is contiguous in LDS.  The pieces of K tile t+1 are issued
-//   between the MFMA groups of tile t and waited for (vmcnt(0) + barrier) at its end.
+//   per-lane SOURCE chunk so that the 1 KiB a piece writes is contiguous in LDS.  The K loop is rotated around its
+//   barrier (see the loop) so that tile t+1's first fragments and tile t+2's DMA are in flight under tile t's last MFMAs.
 //   Epilogue: the tile leaves as four 128x128 sub-tiles through fp32 LDS, two at a time, one per 256-thread half,
 //   through the same functors as gemm.h (their block reductions are 256-thread-group local).
 #pragma once
@@ -94,35 +94,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
     glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
   };
 
+  // Tile t lives in stage t & 1.  The hand-over barrier B_t sits before the LAST MFMA group of tile t: by then every
+  // fragment of tile t is in registers and tile t+1 has landed, so the gaps after B_t already read tile t+1's first
+  // fragments (no tile starts with an exposed LDS round trip) and refill the freed stage with tile t+2 (half of its
+  // pieces right after B_t, half in the first group of tile t+1: a full tile of lead time).
+  const int kt_last = kt_end - 1;
+  auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
+  bf16x8 fa[2][4], fb[2][2];
   if (kt_begin < kt_end) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) issue(kt_begin, 0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(clampk(kt_begin + 1), 1, q);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (kt_begin < kt_end) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(smem, 128 * wm + 32 * i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+  }
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    // the last tile re-copies itself into the idle stage instead of branching around the DMA
-    const int nxt = kt + 1 < kt_end ? kt + 1 : kt;
     const char* sa = smem + cur * G2_STAGE_BYTES;
     const char* sb = sa + G2_OPER_BYTES;
-    bf16x8 fa[2][4], fb[2][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(sa, 128 * wm + 32 * i, 0, lane);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(sb, 64 * wn + 32 * j, 0, lane);
+    const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
+    const char* nb = na + G2_OPER_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 2) {        // all pieces of the next tile leave early: they have the rest of this tile to land
-        issue(nxt, cur ^ 1, 2 * kk);
-        issue(nxt, cur ^ 1, 2 * kk + 1);
+      if (kk == 0) {          // second half of tile kt+1's pieces (its first half left right after B_{kt-1})
+        issue(clampk(kt + 1), cur ^ 1, 2);
+        issue(clampk(kt + 1), cur ^ 1, 3);
       }
-      if (kk + 1 < 4) {
+      if (kk < 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[(kk + 1) & 1][i] = g2_frag<AMODE>(sa, 128 * wm + 32 * i, kk + 1, lane);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[(kk + 1) & 1][j] = g2_frag<BMODE>(sb, 64 * wn + 32 * j, kk + 1, lane);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+        __syncthreads();                                    // B_kt: ... and everybody's; all reads of this stage are done
+        issue(clampk(kt + 2), cur, 0);
+        issue(clampk(kt + 2), cur, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(na, 128 * wm + 32 * i, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(nb, 64 * wn + 32 * j, 0, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -132,10 +151,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
-    __syncthreads();                                    // ... and everybody's; all reads of this stage are done
     cur ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
+  __syncthreads();
 
   // ---- epilogue: two passes (sub-tile columns), each pass two 128x128 sub-tiles (rows), one per 256-thread half
   float* tile = reinterpret_cast<float*>(smem);

@@ -106,6 +106,28 @@ def test_l1_step_matches_oracle(d, n, M, dtype, opt, generic):
     eng.close()
 
 
+def test_gemm256_matches_gemm128():
+    """The 256x256 LDS-DMA GEMM (taken when both output dimensions are multiples of 256) and the 128x128 kernel compute
+    the same step: same K order per output element, only the split-K partition of the weight gradient may differ."""
+    d, n, M = 512, 1024, 768
+    g = torch.Generator().manual_seed(7)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    b = 0.01 * torch.randn(n, generator=g)
+    x = (torch.relu(torch.randn(M, 64, generator=g)) * 0.1 @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
+    res = []
+    for force128 in (False, True):
+        eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e4, force_gemm128=force128)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        eng.forward_backward(x)
+        res.append((eng.debug_read(2, d * n + n), eng.debug_read(0, M * n), eng.metrics().copy()))
+        eng.close()
+    (g256, c256, m256), (g128, c128, m128) = res
+    assert np.array_equal(c256, c128)                       # latent: bit-identical
+    assert _rel(g256, g128) < 1e-5
+    assert np.allclose(m256[:3], m128[:3], rtol=1e-5)
+
+
 def test_l1_determinism_and_eval():
     """Two identical runs are bitwise equal (fixed-order reductions, no float atomics); eval
     renormalises the decoder columns in place like the reference's encode() (l1autoencoder.py:71-73)."""
