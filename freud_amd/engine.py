@@ -15,7 +15,8 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfreud_sae.so")
+# FREUD_SAE_LIB: development override (A/B timing of two builds of the engine on one GPU box)
+LIB_PATH = os.environ.get("FREUD_SAE_LIB") or os.path.join(_HERE, "lib", "libfreud_sae.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 VARIANT = {"l1": 0, "topk": 1}
