@@ -455,6 +455,26 @@ extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg
   return rc;
 }
 
+extern "C" int sae_get_topk_state(sae_ctx* c, int64_t* out, int64_t n) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->topk) return fail(SAE_ERR_INVALID, "sae_get_topk_state: not a TopK context");
+  if (n != c->n) return fail(SAE_ERR_INVALID, "sae_get_topk_state: n = %lld, context has %d latents", (long long)n, c->n);
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->nfsf, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return SAE_OK;
+}
+
+extern "C" int sae_set_topk_state(sae_ctx* c, const int64_t* in, int64_t n) {
+  if (!c || !in) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->topk) return fail(SAE_ERR_INVALID, "sae_set_topk_state: not a TopK context");
+  if (n != c->n) return fail(SAE_ERR_INVALID, "sae_set_topk_state: n = %lld, context has %d latents", (long long)n, c->n);
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(c->nfsf, in, (size_t)n * 8, hipMemcpyHostToDevice));
+  return SAE_OK;
+}
+
 extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
   if (!c || !dev_ptr || !n_floats) return fail(SAE_ERR_INVALID, "null argument");
   *dev_ptr = c->G;

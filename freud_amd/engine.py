@@ -78,6 +78,8 @@ def load() -> C.CDLL:
         "sae_forward_backward": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_grad_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_optimizer_step": (C.c_int, [vp, dbl, dbl, vp]),
+        "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
+        "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_options": (C.c_int, [vp, dbl, i64]),
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
@@ -100,7 +102,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
-    "sae_set_topk_options",
+    "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
@@ -194,6 +196,16 @@ class SaeEngine:
         """TopK only: autoencoder_config["dead_feature_threshold"] (train_sae.py:438) and T of the [B][T][d] batch."""
         self._dead_threshold, self._rows_per_file = float(dead_feature_threshold), int(rows_per_file)
         _check(self._lib.sae_set_topk_options(self._ctx, float(dead_feature_threshold), int(rows_per_file)))
+
+    def get_topk_state(self) -> np.ndarray:
+        """TopK only: num_frames_since_fired[n_dict] (int64) - train_sae.py:412-415 keeps it in the live process only."""
+        out = np.zeros(self.n, dtype=np.int64)
+        _check(self._lib.sae_get_topk_state(self._ctx, out.ctypes.data_as(C.POINTER(C.c_int64)), self.n))
+        return out
+
+    def set_topk_state(self, num_frames_since_fired) -> None:
+        a = np.ascontiguousarray(np.asarray(num_frames_since_fired, dtype=np.int64).reshape(-1))
+        _check(self._lib.sae_set_topk_state(self._ctx, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size))
 
     def set_dead_feature_threshold(self, v: float) -> None:
         self.set_topk_options(v, getattr(self, "_rows_per_file", 0))

@@ -77,6 +77,7 @@ class MemoryMappedActivationDataLoader:
         self.device = torch.device(device)
         self.rank, self.world_size, self.depth = rank, world_size, max(2, depth)
         self.dl_max_workers = dl_max_workers
+        self.skip_next = 0          # resume (train_sae f4): the next iterator drops this many leading batches unread
 
     def __len__(self) -> int:   # reference quirk kept: floor division even without drop_last (:205-206)
         return (len(self._dataset) // self.world_size) // self.batch_size
@@ -106,6 +107,9 @@ class MemoryMappedActivationDataLoader:
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, List[str]]]:
         batches = self.epoch_batches()
+        if self.skip_next:          # mid-epoch resume: same permutation (the caller restored the RNG), batches already seen dropped
+            batches = batches[self.skip_next:]
+            self.skip_next = 0
         T, d = self._dataset.tensor_shape[-2], self._dataset.tensor_shape[-1]
         names = self._dataset.metadata["filenames"]
         np_dtype = self._dataset.mmap.dtype

@@ -102,6 +102,12 @@ def _torch_state_dicts(param_shapes: Dict[str, tuple], order, optimizer: str, ba
     return opt.state_dict(), sch.state_dict()
 
 
+def _resume_path(checkpoint_path: str) -> str:
+    """<run_dir>/checkpoints/<name> -> <run_dir>/resume/<name>"""
+    ck_dir, name = os.path.split(os.path.abspath(checkpoint_path))
+    return os.path.join(os.path.dirname(ck_dir), "resume", name)
+
+
 def save_checkpoint(state: dict, save_path: str) -> None:
     """train_sae.py:232-251: torch.save of {model, optimizer, scheduler, step, best_val_loss, hparams};
     tensors / plain containers / scalars only (loadable with weights_only=True)."""
@@ -117,6 +123,16 @@ def save_checkpoint(state: dict, save_path: str) -> None:
         "best_val_loss": state["best_val_loss"], "hparams": state["hparams"],
     }
     torch.save(checkpoint, save_path)
+    # Extension: what the reference loses on resume (train_sae.py:396-415) - the data
+    # order position and the TopK dead-latent counters - goes to a side file <run_dir>/resume/<same name>, so that the
+    # checkpoint itself keeps exactly the reference's keys.  Tensors and ints only (weights_only loading works).
+    resume = {"step": int(state["step"]), "epoch_rng_state": state["epoch_rng_state"].clone(),
+              "epoch_batches_done": int(state["epoch_batches_done"]), "world_size": int(state.get("world_size", 1))}
+    if hasattr(eng, "get_topk_state") and state["hparams"]["autoencoder_variant"] == "topk":
+        resume["num_frames_since_fired"] = torch.from_numpy(np.asarray(eng.get_topk_state(), dtype=np.int64).copy())
+    side = _resume_path(save_path)
+    os.makedirs(os.path.dirname(side), exist_ok=True)
+    torch.save(resume, side)
 
 
 def load_checkpoint(state: dict, load_path: str, device=None) -> None:
@@ -133,6 +149,17 @@ def load_checkpoint(state: dict, load_path: str, device=None) -> None:
         eng.set_opt_state(int(float(ost[0]["step"])), m1, m2)
     for k in ("step", "best_val_loss", "hparams"):
         state[k] = checkpoint[k]
+    # a side file written by save_checkpoint carries the data position and the TopK counters; without it (the
+    # reference's own checkpoints) the run restarts its data order from the seed and the counters from zero, exactly
+    # as the reference does
+    side = _resume_path(load_path)
+    if os.path.exists(side):
+        resume = torch.load(side, map_location="cpu")
+        if int(resume.get("step", -1)) == int(state["step"]) and int(resume.get("world_size", 1)) == int(state.get("world_size", 1)):
+            state["resume_rng_state"] = resume["epoch_rng_state"]
+            state["resume_skip"] = int(resume["epoch_batches_done"])
+            if "num_frames_since_fired" in resume and hasattr(eng, "set_topk_state"):
+                eng.set_topk_state(resume["num_frames_since_fired"].numpy())
     del checkpoint
     gc.collect()
 
@@ -314,7 +341,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
 
     state = {"engine": eng, "param_order": param_order, "state_dict_order": state_dict_order, "optimizer": optimizer,
              "scheduler": scheduler, "lr": lr, "weight_decay": weight_decay, "steps": steps,
-             "scheduler_params": scheduler_params, "step": 0, "best_val_loss": float("inf"), "hparams": hparam_dict}
+             "scheduler_params": scheduler_params, "step": 0, "best_val_loss": float("inf"), "hparams": hparam_dict,
+             "world_size": world, "epoch_rng_state": torch.get_rng_state(), "epoch_batches_done": 0}
     if start_checkpoint is not None:
         if is_main:
             print(f"Checkpoint: {start_checkpoint}")
@@ -324,8 +352,14 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
     t_start, rows_done = time.time(), 0
     while state["step"] < steps:
         n_batches = 0
+        if "resume_rng_state" in state:       # continue the interrupted epoch: same permutation, seen batches dropped
+            torch.set_rng_state(state.pop("resume_rng_state"))
+            train_loader.skip_next = n_batches = state.pop("resume_skip")
+        state["epoch_rng_state"] = torch.get_rng_state()      # the state the epoch's permutation is drawn from
+        state["epoch_batches_done"] = n_batches
         for activations, _ in train_loader:
             n_batches += 1
+            state["epoch_batches_done"] = n_batches
             step_lr = lr_at(state["step"], lr, scheduler, steps, scheduler_params)
             if world > 1:
                 eng.forward_backward(activations)

@@ -121,6 +121,13 @@ int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream)
  * (topkautoencoder.py:104); 0 = treat the batch as one file. */
 int sae_set_topk_options(sae_ctx* ctx, double dead_feature_threshold, int64_t rows_per_file);
 
+/* TopK bookkeeping state num_frames_since_fired[n_dict] (int64, train_sae.py:412-415,443-446).  The reference keeps
+ * it only in the live process and restarts it from zero on resume (train_sae.py:396-415 never saves it); these two
+ * calls let the host persist it next to the checkpoint.  Host buffers of n_dict int64.
+ * Synchronous.  SAE_ERR_INVALID on an L1 context. */
+int sae_get_topk_state(sae_ctx* ctx, int64_t* num_frames_since_fired_host, int64_t n);
+int sae_set_topk_state(sae_ctx* ctx, const int64_t* num_frames_since_fired_host, int64_t n);
+
 /* Convenience: sae_forward_backward + sae_optimizer_step(lr, 1). */
 int sae_step(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, double lr, void* stream);
 

@@ -26,6 +26,12 @@ class OracleEngine:
             return {"decoder.weight": (self.d, self.n), "encoder_bias": (self.n,)}
         return {"encoder.weight": (self.n, self.d), "encoder.bias": (self.n,), "W_dec": (self.n, self.d), "b_dec": (self.d,)}
 
+    def get_topk_state(self):
+        return self.nfsf.numpy().copy()
+
+    def set_topk_state(self, a):
+        self.nfsf = torch.as_tensor(a, dtype=torch.long).clone()
+
     def set_dead_feature_threshold(self, v):
         self.dead_threshold = v
 

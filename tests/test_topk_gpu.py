@@ -159,4 +159,19 @@ def test_topk_auxk_and_dead_bookkeeping():
         assert m[1] == pytest.approx(out["auxk_loss"].item(), rel=0.1, abs=1e-7)
         if i >= 1:
             assert m[1] > 0
+    # sae_get_topk_state / sae_set_topk_state (resume fidelity): the device counters follow the
+    # reference's bookkeeping up to boundary ties, and a second context seeded with them reports the same dead fraction
+    got = eng.get_topk_state()
+    assert got.dtype == np.int64 and got.shape == (n,)
+    assert (got != nfsf.numpy()).sum() <= 6
+    eng2 = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=B * T, optimizer="adam", k=k, auxk_alpha=aux)
+    eng2.set_topk_options(thr, T)
+    eng2.set_params(eng.get_params())
+    eng2.set_topk_state(got)
+    assert np.array_equal(eng2.get_topk_state(), got)
+    eng2.forward_backward(xd)
+    assert eng2.metrics()[5] == pytest.approx(float((got > thr).mean()), abs=1e-6)
+    with pytest.raises(Exception):
+        eng2.set_topk_state(got[:-1])
+    eng2.close()
     eng.close()

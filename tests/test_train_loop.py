@@ -79,21 +79,54 @@ def test_checkpoint_consumed_by_reference_key_logic(tmp_path, golden_dir):
 
 
 def test_resume_from_checkpoint_continues_identically(tmp_path, golden_dir):
+    """with the side file save_checkpoint writes (<run_dir>/resume/<name>: RNG state of the
+    epoch's permutation draw + batches consumed) an interrupted run continues on exactly the batches the uninterrupted
+    one saw; without it the behaviour is the reference's (model / optimizer / step restored, data order restarts)."""
     z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_l1")
     train(**cfg, engine_factory=OracleEngine)
     full = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    assert os.path.exists(os.path.join(cfg["run_dir"], "resume", "step4.pth"))
+    side = torch.load(os.path.join(cfg["run_dir"], "resume", "step4.pth"), map_location="cpu", weights_only=True)
+    assert side["step"] == 4 and side["epoch_batches_done"] >= 1
     cfg2 = dict(cfg, run_dir=os.path.join(str(tmp_path), "run2"),
                 start_checkpoint=os.path.join(cfg["run_dir"], "checkpoints", "step4.pth"))
     st = train(**cfg2, engine_factory=OracleEngine)
     assert st["step"] == 7
-    # like the reference, resume restores model/optimizer/step but not the loader position or RNG,
-    # so the continued run sees different batches: parameters stay finite and the step counter,
-    # optimizer step and LR schedule line up.
     ck = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
-    assert float(ck["optimizer"]["state"][0]["step"]) == 7.0
+    for k, v in full["model"].items():                       # identical trajectory: same batches, same arithmetic
+        assert torch.equal(ck["model"][k], v), k
+    for pid in (0, 1):
+        assert torch.equal(ck["optimizer"]["state"][pid]["exp_avg"], full["optimizer"]["state"][pid]["exp_avg"])
     assert ck["scheduler"]["last_epoch"] == 7 == full["scheduler"]["last_epoch"]
-    assert ck["scheduler"]["_last_lr"][0] == pytest.approx(full["scheduler"]["_last_lr"][0], rel=1e-12)
-    assert all(torch.isfinite(v).all() for v in ck["model"].values())
+
+    # reference behaviour when the side file is absent (e.g. a checkpoint written by the reference itself)
+    os.remove(os.path.join(cfg["run_dir"], "resume", "step4.pth"))
+    cfg3 = dict(cfg2, run_dir=os.path.join(str(tmp_path), "run3"))
+    st = train(**cfg3, engine_factory=OracleEngine)
+    assert st["step"] == 7
+    ck3 = torch.load(os.path.join(cfg3["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    assert float(ck3["optimizer"]["state"][0]["step"]) == 7.0
+    assert ck3["scheduler"]["_last_lr"][0] == pytest.approx(full["scheduler"]["_last_lr"][0], rel=1e-12)
+    assert all(torch.isfinite(v).all() for v in ck3["model"].values())
+    assert not all(torch.equal(ck3["model"][k], v) for k, v in full["model"].items())   # different batches were seen
+
+
+def test_topk_resume_restores_dead_latent_counters(tmp_path, golden_dir):
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_topk")
+    st_full = train(**cfg, engine_factory=OracleEngine)
+    nfsf_full = st_full["engine"].get_topk_state()
+    files = sorted(os.listdir(os.path.join(cfg["run_dir"], "resume")))
+    mid = [f for f in files if f != "step7.pth"][0]
+    side = torch.load(os.path.join(cfg["run_dir"], "resume", mid), map_location="cpu", weights_only=True)
+    assert side["num_frames_since_fired"].dtype == torch.int64 and side["num_frames_since_fired"].numel() == nfsf_full.size
+    cfg2 = dict(cfg, run_dir=os.path.join(str(tmp_path), "run2"),
+                start_checkpoint=os.path.join(cfg["run_dir"], "checkpoints", mid))
+    st = train(**cfg2, engine_factory=OracleEngine)
+    assert np.array_equal(st["engine"].get_topk_state(), nfsf_full)          # counters continued, not restarted
+    full = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    ck = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", "step7.pth"), map_location="cpu")
+    for k, v in full["model"].items():
+        assert torch.equal(ck["model"][k], v), k
 
 
 def test_error_conventions(tmp_path, golden_dir):
