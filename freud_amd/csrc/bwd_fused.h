@@ -48,7 +48,6 @@ struct BwdFusedArgs {
   int ntiles;          // n_p / 128
   int splits;
   int steps_total;     // M_p / 32
-  int dbg;             // timing experiments only: 4 = skip in-loop DMA
   unsigned long long* clk;   // diagnostic (bench.py --dbg 66), normally null: [wg][4] = s_memtime / s_memrealtime around the loop
 };
 

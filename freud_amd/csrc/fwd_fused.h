@@ -12,9 +12,9 @@
 //   - its x_hat^T tile [384 x 32] stays in 192 accumulator registers (12 MFMA tiles);
 //   - the dictionary is swept in 32-column tiles.  Per tile, S^T[32 cols x 32 rows] = W^T tile . x^T
 //     (24 MFMAs, A = W^T rows from LDS) -> bias + ReLU on the accumulator registers -> those registers ARE the
-//     B operand of x_hat^T += W tile . c^T (24 MFMAs, A = W rows from LDS in the accumulator's permuted k
-//     order, prepared by normalize_cast_kernel as the `Wp` copy) -- c never round-trips through LDS or HBM
-//     between the two GEMMs; it is written to HBM once, straight from registers, for the backward.
+//     B operand of x_hat^T += W tile . c^T (24 MFMAs, A = W read from the SAME W^T tile image by transposed LDS
+//     reads in the accumulator's permuted k order) -- c never round-trips through LDS or HBM between the two GEMMs;
+//     it is written to HBM once (staged per wave in LDS into full 128-byte lines) for the backward.
 //   - software pipeline across tiles: the encoder MFMAs of tile j+1 run first, with the bias/ReLU/store work of
 //     tile j in their gaps, then the decoder MFMAs of tile j.  W tiles arrive by LDS-DMA two / one tile ahead.
 #pragma once

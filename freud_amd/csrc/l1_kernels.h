@@ -29,8 +29,7 @@ __global__ __launch_bounds__(256) void colnorm_partial_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void normalize_cast_kernel(float* __restrict__ W, const float* __restrict__ part,
                                                               int nslab, bf16_t* __restrict__ Wb,
-                                                              bf16_t* __restrict__ Wt, bf16_t* __restrict__ Wp,
-                                                              int d_p, int n_p) {
+                                                              bf16_t* __restrict__ Wt, int d_p, int n_p) {
   // grid (n_p/64, d_p/64): one 64x64 tile
   __shared__ float denom_s[64];
   __shared__ __attribute__((aligned(16))) bf16_t tT[64][72];
@@ -52,12 +51,6 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(float* __restrict__
     const bf16_t b = (bf16_t)v;
     Wb[o] = b;
     tT[tx][r] = b;
-    if (Wp) {   // [n/32 tile][d][32 n] with the middle 4-column blocks of every 16 swapped: the k order an
-                // accumulator tile has when it is reused as an MFMA operand (fwd_fused.h)
-      const int n16 = col & 15, blk = n16 >> 2;
-      const int p16 = blk == 1 ? n16 + 4 : (blk == 2 ? n16 - 4 : n16);
-      Wp[((int64_t)(col >> 5) * d_p + (r0 + r)) * 32 + ((col & 16) | p16)] = b;
-    }
   }
   __syncthreads();
   // 64 columns x 64 rows -> Wt[col][r0 .. r0+64): 8 pieces of 16 B per column, 512 pieces
