@@ -147,10 +147,17 @@ def main():
 
     if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.spinup:
+        while True:
             for _ in range(20):
                 one_step(0)
             torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t_spin
+            if use_dist:                     # every rank must leave after the same number of (collective) steps
+                te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                elapsed = float(te.item())
+            if elapsed >= args.spinup:
+                break
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
