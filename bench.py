@@ -212,7 +212,9 @@ def main():
     traffic = None
     try:
         if args.variant == "l1" and (M, d, n) == (65536, 384, 3072):
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]   # newest round's pass
+            with open(latest) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
