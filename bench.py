@@ -106,6 +106,7 @@ def main():
         # RCCL writes its NCCL_DEBUG output (version banner, warnings) to STDOUT: send it to a file instead so that
         # stdout carries exactly one JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")   # the gradient buffer is engine memory, not torch's
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":     # the version banner ignores NCCL_DEBUG_FILE
             os.environ.pop("NCCL_DEBUG")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -134,13 +135,18 @@ def main():
                         clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     grads = eng.grad_tensor() if use_dist else None
+    works = []
+    if use_dist:    # ranges of the gradient buffer are all-reduced as soon as the engine reports them final
+        eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     total_steps, base_lr = 100000, 4e-4
     lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
     def one_step(i):
         if use_dist:
             eng.forward_backward(x)
-            dist.all_reduce(grads)
+            for w in works:
+                w.wait()
+            works.clear()
             eng.optimizer_step(lr_of(i), 1.0 / world)
         else:
             eng.step(x, lr_of(i))

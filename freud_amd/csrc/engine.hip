@@ -86,6 +86,10 @@ struct sae_ctx {
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
   float* cn_part = nullptr;
+  sae_grad_ready_fn grad_ready = nullptr;   // data-parallel overlap hook (sae_set_grad_ready_callback)
+  void* grad_ready_user = nullptr;
+  int dw_chunk_rows = 0;       // generic L1 path: rows (of d_p) per weight-gradient GEMM launch when a hook is set
+  int dw_chunk_splits = 1;     // its split-K factor
   float* cnt_part = nullptr;   // fused forward: per-workgroup masked-entry counts
   int gn_blocks = 0;
   bool step_fused_call = false; // set by sae_step: forward_backward and optimizer_step back to back
@@ -276,6 +280,10 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   }
   g_force_gemm128 = cfg->reserved[2] == 1;
   c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
+  // with a gradient-ready hook the weight-gradient GEMM is issued in 512-row chunks (d_p >= 1024 only: smaller
+  // models finish their gradient in one piece); the chunk's split-K factor keeps its launch rounds full
+  c->dw_chunk_rows = c->d_p >= 1024 ? 512 : c->d_p;
+  c->dw_chunk_splits = choose_splits(c->dw_chunk_rows / 128, c->n_p / 128, 2 * Mp / 64);
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
@@ -288,7 +296,11 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     if (sp > steps) sp = steps;
     c->bwd_splits = sp;
   }
-  const int slab_splits = c->use_fused_bwd ? (c->bwd_splits > c->dw_splits ? c->bwd_splits : c->dw_splits) : c->dw_splits;
+  int slab_splits = c->use_fused_bwd ? (c->bwd_splits > c->dw_splits ? c->bwd_splits : c->dw_splits) : c->dw_splits;
+  {   // a chunk launch writes splits x (chunk rows x n_p) floats at the chunk's row offset of each slab
+    const int64_t need = (int64_t)c->dw_chunk_splits;
+    if (need > slab_splits) slab_splits = (int)need;
+  }
   const int64_t db_rows = (Mp / 128) > 64 ? (Mp / 128) : 64;
 
 #define ALLOC(ptr, bytes)                                   \
@@ -452,6 +464,17 @@ extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg
   if (rc) return rc;
   if (exp_avg_sq) rc = xfer_flat(c, c->Var, exp_avg_sq[0], exp_avg_sq[1], 0, is_device);
   return rc;
+}
+
+extern "C" int sae_set_grad_ready_callback(sae_ctx* c, sae_grad_ready_fn fn, void* user) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  c->grad_ready = fn;
+  c->grad_ready_user = user;
+  return SAE_OK;
+}
+
+static inline void notify_grads(sae_ctx* c, int64_t offset, int64_t count, hipStream_t s) {
+  if (c->grad_ready && count > 0) c->grad_ready(c->grad_ready_user, offset, count, (void*)s);
 }
 
 extern "C" int sae_get_topk_state(sae_ctx* c, int64_t* out, int64_t n) {
@@ -626,9 +649,11 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   if (c->use_fused_fwd)   // the fused forward counted the masked entries itself: scal[] and the losses are due now
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)(Mp / 128), c->sq_part,
                        (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128));
+  bool dw_chunked_any = false;
   if (backward) {
     int splits = c->dw_splits;
     int db_rows = (int)(Mp / 128);
+    bool dw_chunked = false;
     if (c->use_fused_bwd) {
       BwdFusedArgs a{};
       a.dxh = c->dxh; a.xb = c->xb_cur; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
@@ -664,19 +689,33 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         ev_end(c, KID_DPRE, s);
         if (rc) return rc;
       }
-      {  // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs)
+      // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs).  With a gradient-ready hook the GEMM is issued in
+      // row chunks of dW (contiguous ranges of the gradient buffer): each chunk is reduced and announced as soon as it
+      // is enqueued, so its all-reduce runs under the GEMM of the next chunk.
+      const bool chunked = c->grad_ready != nullptr && c->dw_chunk_rows < d_p;
+      const int chunk_rows = chunked ? c->dw_chunk_rows : d_p;
+      if (chunked) splits = c->dw_chunk_splits;
+      ev_begin(c, KID_DW, s);
+      for (int r0 = 0; r0 < d_p; r0 += chunk_rows) {
+        const int rows = d_p - r0 < chunk_rows ? d_p - r0 : chunk_rows;
         GemmArgs g{};
-        g.A0 = c->dxh; g.B0 = c->c; g.A1 = c->xb_cur; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
-        g.nbm = d_p / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
+        g.A0 = c->dxh + r0; g.B0 = c->c; g.A1 = c->xb_cur + r0; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
+        g.nbm = rows / 128; g.nbn = n_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
         if (splits > g.ktiles) splits = g.ktiles;
         g.splits = splits;
         EpiSlab e{};
-        e.slab = c->slab; e.slab_stride = c->nW; e.ld = n_p;
-        ev_begin(c, KID_DW, s);
+        e.slab = c->slab + (int64_t)r0 * n_p; e.slab_stride = c->nW; e.ld = n_p;
         rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
-        ev_end(c, KID_DW, s);
         if (rc) return rc;
+        if (chunked) {
+          const int64_t off4 = (int64_t)r0 * n_p / 4, n4 = (int64_t)rows * n_p / 4;
+          hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab + 4 * off4,
+                             c->G + 4 * off4, n4, c->nW / 4, splits);
+          notify_grads(c, 4 * off4, 4 * n4, s);
+        }
       }
+      ev_end(c, KID_DW, s);
+      dw_chunked = dw_chunked_any = chunked;
     }
     ev_begin(c, KID_REDUCE, s);
     if (c->use_fused_bwd) {   // one pass: slabs + db partials -> grads, plus the local gradient sum of squares
@@ -689,8 +728,9 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       c->gn_valid = true;
     } else {
       const int64_t n4 = c->nW / 4;
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
-                         splits);
+      if (!dw_chunked)
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, c->G, n4, n4,
+                           splits);
       hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, c->G + c->nW, db_rows, n_p);
       c->gn_valid = false;
     }
@@ -700,6 +740,11 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
                        c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha,
                        (const float*)nullptr, 0);
+  if (backward) {   // everything that was not announced chunk by chunk: [dW] | db | loss scalars
+    const int64_t total = c->nparams + SAE_NUM_METRICS;
+    if (dw_chunked_any) notify_grads(c, c->nW, total - c->nW, s);
+    else notify_grads(c, 0, total, s);
+  }
   ev_end(c, KID_STEP_TOTAL, s);
   HIP_TRY(hipGetLastError());
   c->last_M = M;
@@ -827,6 +872,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       ev_end(c, KID_TK_DWD, s);
       if (rc) return rc;
+      notify_grads(c, c->nW + c->n_p, c->nW, s);     // d W_dec is final: its all-reduce runs under the d W_enc GEMM
     }
     {  // dW_enc[n][d] = dpre^T sae_in
       GemmArgs g{};
@@ -854,6 +900,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     ev_end(c, KID_TK_DSAE, s);
     hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
     ev_end(c, KID_REDUCE, s);
+    notify_grads(c, 0, c->nW + c->n_p, s);                                                     // d W_enc | d b_enc
+    notify_grads(c, 2 * c->nW + c->n_p, c->d_p + SAE_NUM_METRICS + c->n_p, s);                 // d b_dec | scalars | did_fire
   }
   ev_end(c, KID_STEP_TOTAL, s);
   HIP_TRY(hipGetLastError());

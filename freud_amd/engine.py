@@ -53,6 +53,9 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)   # sae_grad_ready_fn
+
+
 def load() -> C.CDLL:
     """dlopen the engine and declare every symbol of include/freud_sae.h."""
     global _lib
@@ -78,6 +81,7 @@ def load() -> C.CDLL:
         "sae_forward_backward": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_grad_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_optimizer_step": (C.c_int, [vp, dbl, dbl, vp]),
+        "sae_set_grad_ready_callback": (C.c_int, [vp, GRAD_READY_FN, vp]),
         "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_options": (C.c_int, [vp, dbl, i64]),
@@ -102,7 +106,7 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
-    "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_set_grad_ready_callback", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
@@ -240,6 +244,9 @@ class SaeEngine:
         self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_forward_backward(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+        err, self._cb_error = getattr(self, "_cb_error", None), None
+        if err is not None:
+            raise err
 
     def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))
@@ -270,6 +277,25 @@ class SaeEngine:
         p, n = C.c_void_p(), C.c_int64()
         _check(self._lib.sae_grad_buffer(self._ctx, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+    def set_grad_ready_callback(self, fn) -> None:
+        """fn(offset, count) is called from inside forward_backward() each time the range [offset, offset + count) of the
+        gradient buffer is final in stream order (data-parallel overlap: start that range's all-reduce).  None removes
+        it.  Exceptions raised by fn are re-raised by forward_backward()."""
+        self._cb_error = None
+        if fn is None:
+            self._cb = None
+            _check(self._lib.sae_set_grad_ready_callback(self._ctx, C.cast(None, GRAD_READY_FN), None))
+            return
+
+        def tramp(_user, offset, count, _stream):
+            try:
+                fn(int(offset), int(count))
+            except BaseException as e:      # never unwind through the C frames
+                self._cb_error = e
+
+        self._cb = GRAD_READY_FN(tramp)     # keep the thunk alive
+        _check(self._lib.sae_set_grad_ready_callback(self._ctx, self._cb, None))
 
     def grad_tensor(self):
         """The gradient buffer as a torch CUDA tensor aliasing the engine's HBM (no copy)."""

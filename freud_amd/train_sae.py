@@ -265,6 +265,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")   # RCCL logs to stdout otherwise
+            os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")           # gradient buffer = engine memory
             backend = dist_backend or ("nccl" if device.type == "cuda" else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, **kw)
@@ -349,6 +350,12 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         load_checkpoint(state, start_checkpoint, device=device)
 
     grads = eng.grad_tensor() if world > 1 else None
+    works = []
+    overlap = world > 1 and hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
+    if overlap:
+        # every range of the gradient buffer is all-reduced (RCCL, communication stream) as soon as the engine reports
+        # it final, i.e. under the backward kernels that are still to run (sae_set_grad_ready_callback)
+        eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     t_start, rows_done = time.time(), 0
     while state["step"] < steps:
         n_batches = 0
@@ -363,7 +370,12 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             step_lr = lr_at(state["step"], lr, scheduler, steps, scheduler_params)
             if world > 1:
                 eng.forward_backward(activations)
-                dist.all_reduce(grads)                      # RCCL sum of [grads | loss scalars] over ranks
+                if overlap:
+                    for w in works:                         # the compute stream waits for the communication stream
+                        w.wait()
+                    works.clear()
+                else:
+                    dist.all_reduce(grads)                  # sum of [grads | loss scalars] over ranks
                 eng.optimizer_step(step_lr, 1.0 / world)
             else:
                 eng.step(activations, step_lr)

@@ -111,6 +111,16 @@ int sae_forward_backward(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype
  * passes grad_scale = 1/world_size.  Pointer is stable for the life of the context. */
 int sae_grad_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* n_floats);
 
+/* Data-parallel overlap (the reference has no data parallelism; this is what a DDP-style wrapper around
+ * "loss.backward()", train_sae.py:448, needs).  When a callback is set, sae_forward_backward calls it on the calling
+ * thread each time a contiguous range [offset, offset + count) of the gradient buffer has become final in `stream`
+ * order (the kernels that produce it have been enqueued), so that the host can start that range's all-reduce on a
+ * communication stream while the remaining backward kernels run.  The ranges of one call are disjoint and cover the
+ * whole buffer.  The weight-gradient GEMM of the generic L1 path is issued in row chunks for this (one chunk, i.e. no
+ * change, without a callback).  fn == NULL removes the callback. */
+typedef void (*sae_grad_ready_fn)(void* user, int64_t offset, int64_t count, void* stream);
+int sae_set_grad_ready_callback(sae_ctx* ctx, sae_grad_ready_fn fn, void* user);
+
 /* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
 int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream);

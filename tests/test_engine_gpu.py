@@ -128,6 +128,56 @@ def test_gemm256_matches_gemm128():
     assert np.allclose(m256[:3], m128[:3], rtol=1e-5)
 
 
+@pytest.mark.parametrize("variant,d,n,M", [("l1", 384, 3072, 1024), ("l1", 1024, 2048, 512), ("topk", 256, 1024, 512)])
+def test_grad_ready_callback_ranges(variant, d, n, M):
+    """sae_set_grad_ready_callback: the announced ranges are disjoint and cover the gradient buffer; the chunked
+    weight-gradient GEMM of the generic L1 path (d_p >= 1024) yields the same gradients as the single launch."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.relu(torch.randn(M, 64, generator=g)) * 0.1 @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
+    kw = dict(variant=variant, d_model=d, n_dict=n, max_rows=M, optimizer="adam")
+    if variant == "topk":
+        kw.update(k=16, auxk_alpha=0.03125)
+    outs = []
+    for hook in (False, True):
+        eng = _engine(**kw)
+        if variant == "l1":
+            W = torch.empty(d, n)
+            torch.nn.init.orthogonal_(W, generator=torch.Generator().manual_seed(3))
+            eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)})
+        else:
+            We = (torch.rand(n, d, generator=torch.Generator().manual_seed(3)) * 2 - 1) / d ** 0.5
+            eng.set_topk_options(1e9, M)
+            eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32),
+                            "W_dec": (We / We.norm(dim=1, keepdim=True)).numpy(), "b_dec": np.zeros(d, np.float32)})
+        ranges = []
+        if hook:
+            eng.set_grad_ready_callback(lambda off, cnt: ranges.append((off, cnt)))
+        eng.forward_backward(x)
+        torch.cuda.synchronize()
+        grads = eng.grad_tensor().cpu().numpy().copy()
+        if hook:
+            total = grads.size
+            cover = np.zeros(total, np.int32)
+            for off, cnt in ranges:
+                assert 0 <= off and off + cnt <= total and cnt > 0
+                cover[off:off + cnt] += 1
+            assert (cover == 1).all()
+            assert len(ranges) == {"l1": 1 if d < 1024 else 3, "topk": 3}[variant]
+            eng.set_grad_ready_callback(None)
+            ranges.clear()
+            eng.forward_backward(x)
+            assert ranges == []
+
+            def boom(off, cnt):
+                raise RuntimeError("hook failed")
+            eng.set_grad_ready_callback(boom)
+            with pytest.raises(RuntimeError, match="hook failed"):
+                eng.forward_backward(x)
+        outs.append(grads)
+        eng.close()
+    assert _rel(outs[1], outs[0]) < 1e-5
+
+
 def test_l1_determinism_and_eval():
     """Two identical runs are bitwise equal (fixed-order reductions, no float atomics); eval
     renormalises the decoder columns in place like the reference's encode() (l1autoencoder.py:71-73)."""

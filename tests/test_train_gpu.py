@@ -102,13 +102,13 @@ def test_bench_data_parallel_path_single_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                          "--rows", "8192", "--force-dist", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                          "--rows", "8192", "--force-dist", "--no-cpu-baseline", "--spinup", "0"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and np.isfinite(res["loss"]["recon"])
     single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                             "--rows", "8192", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                             "--rows", "8192", "--no-cpu-baseline", "--spinup", "0"], capture_output=True, text=True, timeout=600)
     ref = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][-1])
     assert res["loss"]["recon"] == pytest.approx(ref["loss"]["recon"], rel=1e-5)      # same arithmetic either way
     assert res["loss"]["grad_norm"] == pytest.approx(ref["loss"]["grad_norm"], rel=1e-4)
