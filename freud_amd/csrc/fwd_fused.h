@@ -19,6 +19,12 @@
 //     tile j in their gaps, then the decoder MFMAs of tile j.  W tiles arrive by LDS-DMA two / one tile ahead.
 #pragma once
 #include <type_traits>
+// gaps (of the 48 per iteration, after the barrier at gap 12) in which the three DMA pairs of tile j+2 are issued
+#ifndef FF_DMA_G0
+#define FF_DMA_G0 15
+#define FF_DMA_G1 19
+#define FF_DMA_G2 23
+#endif
 
 #include "bwd_fused.h"
 
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 15 || i == 19 || i == 23) dma_pair((i - 15) / 4, jt, SLOT_DMA);
+      if (i == FF_DMA_G0 || i == FF_DMA_G1 || i == FF_DMA_G2) dma_pair(i == FF_DMA_G0 ? 0 : (i == FF_DMA_G1 ? 1 : 2), jt, SLOT_DMA);
       // latent element e at gap 6 + 5 (e >> 1) + 2 (e & 1): gaps 6, 8, 11, 13, ..., 41, 43 (computed from the unrolled
       // loop index itself: a lookup table made hipcc emit all 16 elements' work in ONE gap)
       if (i >= 6 && i < 46 && ((i - 6) % 5 == 0 || (i - 6) % 5 == 2)) {
