@@ -64,7 +64,7 @@ class MemoryMappedActivationDataLoader:
 
     def __init__(self, data_path: str, layer_name: str, batch_size: int, dl_max_workers: int = 0,
                  subset_size: Optional[int] = None, dl_kwargs: Optional[dict] = None, *,
-                 device: torch.device | str = "cpu", rank: int = 0, world_size: int = 1, depth: int = 2):
+                 device: torch.device | str = "cpu", rank: int = 0, world_size: int = 1, depth: int = 3):
         dl_kwargs = dict(dl_kwargs or {})
         self._dataset = MemoryMappedActivationsDataset(data_path, layer_name, subset_size)
         self.dataset = self._dataset
@@ -77,6 +77,8 @@ class MemoryMappedActivationDataLoader:
         self.device = torch.device(device)
         self.rank, self.world_size, self.depth = rank, world_size, max(2, depth)
         self.dl_max_workers = dl_max_workers
+        self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else min(8, max(1, (os.cpu_count() or 1) // 4))
+        self._pool = None
         self.skip_next = 0          # resume (train_sae f4): the next iterator drops this many leading batches unread
 
     def __len__(self) -> int:   # reference quirk kept: floor division even without drop_last (:205-206)
@@ -101,9 +103,24 @@ class MemoryMappedActivationDataLoader:
 
     # -- iteration -------------------------------------------------------------------------------
     def _gather(self, idxs: Sequence[int], out: np.ndarray) -> None:
+        """Rows idxs of the shard -> out[0 .. len(idxs)).  One row is ~1-8 MB, so the copy is memory-bandwidth work: a
+        single thread moves ~19 GB/s on the MI355X host, well under the PCIe link, hence a small thread pool (numpy
+        releases the GIL in the copy loop).  dl_max_workers > 0 sets the pool size (the reference hands that key to
+        torch's DataLoader as num_workers, train_sae.py:51-63); 0 = automatic."""
         mm = self._dataset.mmap
-        for j, i in enumerate(idxs):
-            out[j] = mm[i]
+        nthreads = self._gather_threads
+        if nthreads <= 1 or len(idxs) < 2 * nthreads:
+            for j, i in enumerate(idxs):
+                out[j] = mm[i]
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="shard-gather")
+
+        def part(t):
+            for j in range(t, len(idxs), nthreads):
+                out[j] = mm[idxs[j]]
+        list(self._pool.map(part, range(nthreads)))
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, List[str]]]:
         batches = self.epoch_batches()
