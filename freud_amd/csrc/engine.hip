@@ -1072,6 +1072,71 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
   return fail(SAE_ERR_INVALID, "unknown debug tensor %d", which);
 }
 
+extern "C" int sae_latent_buffer(sae_ctx* c, void** dev_ptr, int64_t* row_stride) {
+  if (!c || !dev_ptr || !row_stride) return fail(SAE_ERR_INVALID, "null argument");
+  if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  *dev_ptr = c->topk ? (void*)c->dense : (void*)c->c;
+  *row_stride = c->n_p;
+  return SAE_OK;
+}
+
+extern "C" int sae_topk_indices(sae_ctx* c, void** dev_ptr, int* k) {
+  if (!c || !dev_ptr || !k) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->topk) return fail(SAE_ERR_INVALID, "sae_topk_indices: not a TopK context");
+  if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  *dev_ptr = c->top_idx;
+  *k = c->k;
+  return SAE_OK;
+}
+
+extern "C" int sae_decode(sae_ctx* c, const void* latent, int latent_dtype, int64_t ld, int64_t M, float* x_hat, void* stream) {
+  if (!c || !latent || !x_hat) return fail(SAE_ERR_INVALID, "null argument");
+  if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
+  if (ld < c->n) return fail(SAE_ERR_INVALID, "row stride %lld < n_dict %d", (long long)ld, c->n);
+  if (latent_dtype != SAE_DTYPE_F32 && latent_dtype != SAE_DTYPE_BF16) return fail(SAE_ERR_INVALID, "latent dtype must be f32 or bf16");
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  hipStream_t s = (hipStream_t)stream;
+  const int d_p = c->d_p, n_p = c->n_p;
+  const int64_t Mp = round_up(M, 128);
+  bf16_t* lat = c->dpre;                       // [M_p][n_p] scratch that no forward output lives in
+  const int64_t total = Mp * (int64_t)n_p;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (latent_dtype == SAE_DTYPE_F32)
+    hipLaunchKernelGGL(pad_latent_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)latent, ld, M, c->n, lat, Mp, n_p);
+  else
+    hipLaunchKernelGGL(pad_latent_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)latent, ld, M, c->n, lat, Mp, n_p);
+  GemmArgs g{};
+  g.A0 = lat; g.lda = n_p;
+  g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
+  EpiStoreF32 e{};
+  e.out = x_hat; e.M = M; e.d = c->d;
+  int rc;
+  if (c->topk) {
+    // W_dec [n_p][d_p] fp32 -> bf16 (K = n is the slow dimension of this operand: transposed-read mode)
+    float* Wd = c->P + c->nW + c->n_p;
+    const int64_t n8 = c->nW / 8;
+    int cg = (int)((n8 + 255) / 256);
+    if (cg > 2048) cg = 2048;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(cg), dim3(256), 0, s, Wd, c->Wd_b, n8);
+    g.B0 = c->Wd_b; g.ldb = d_p;
+    e.bias = c->P + 2 * c->nW + c->n_p;
+    rc = launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
+  } else {
+    // current W [d_p][n_p] as is (decode() does not renormalise); the copy is refreshed by the next forward anyway
+    const int64_t n8 = c->nW / 8;
+    int cg = (int)((n8 + 255) / 256);
+    if (cg > 2048) cg = 2048;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(cg), dim3(256), 0, s, c->P, c->Wb, n8);
+    g.B0 = c->Wb; g.ldb = n_p;
+    e.bias = nullptr;
+    rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+  }
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
 extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, void* stream) {
   if (!c || !out_host) return fail(SAE_ERR_INVALID, "null argument");
   if (capacity < c->n) return fail(SAE_ERR_INVALID, "capacity too small");

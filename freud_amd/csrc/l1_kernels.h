@@ -479,3 +479,34 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
     reinterpret_cast<f32x4*>(v)[i] = vv;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// inference helpers (sae_decode)
+// ------------------------------------------------------------------------------------------
+// latent [M][ld] (fp32 or bf16) -> zero-padded bf16 GEMM operand dst[M_p][n_p]
+template <typename T>
+__global__ __launch_bounds__(256) void pad_latent_kernel(const T* __restrict__ src, int64_t ld, int64_t M, int n,
+                                                          bf16_t* __restrict__ dst, int64_t M_p, int n_p) {
+  const int64_t total = M_p * (int64_t)n_p;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n_p;
+    const int c = (int)(i - r * n_p);
+    dst[i] = (r < M && c < n) ? (bf16_t)(float)src[r * ld + c] : (bf16_t)0.f;
+  }
+}
+
+// plain fp32 store of a GEMM tile (+ optional per-column bias), rows >= M and columns >= d dropped
+struct EpiStoreF32 {
+  float* out;           // [M][d]
+  const float* bias;    // [d] or null
+  int64_t M;
+  int d;
+  __device__ void tile_begin(int, int, int) {}
+  __device__ void apply(int row, int col, f32x4 v) {
+    if (row >= M) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col + j < d) out[(int64_t)row * d + col + j] = bf16_round(v[j]) + (bias ? bias[col + j] : 0.f);
+  }
+  __device__ void tile_end(float*) {}
+};

@@ -87,6 +87,9 @@ def load() -> C.CDLL:
         "sae_set_topk_options": (C.c_int, [vp, dbl, i64]),
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+        "sae_latent_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
+        "sae_topk_indices": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
+        "sae_decode": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp]),
         "sae_read_metrics": (C.c_int, [vp, fptr, vp]),
         "sae_latent_colmax": (C.c_int, [vp, fptr, i64, vp]),
         "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
@@ -107,6 +110,7 @@ EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
     "sae_set_grad_ready_callback", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_latent_buffer", "sae_topk_indices", "sae_decode",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
@@ -260,6 +264,33 @@ class SaeEngine:
         self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_eval(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    # -- inference ---------------------------------------------------------
+    def latent_buffer(self):
+        """(device pointer, row stride in elements) of the bf16 latent of the last forward."""
+        ptr, ld = C.c_void_p(), C.c_int64()
+        _check(self._lib.sae_latent_buffer(self._ctx, C.byref(ptr), C.byref(ld)))
+        return ptr.value, ld.value
+
+    def topk_indices_tensor(self, rows: int, device):
+        """int32 [rows][k] torch view of the top-k indices of the last forward (TopK contexts)."""
+        import torch
+        ptr, k = C.c_void_p(), C.c_int()
+        _check(self._lib.sae_topk_indices(self._ctx, C.byref(ptr), C.byref(k)))
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (rows, k.value), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
+
+        return torch.as_tensor(_Alias(), device=device)
+
+    def decode(self, latent, out, stream=None) -> None:
+        """out[rows][d_model] (fp32 CUDA tensor) = decode(latent[rows][>= n_dict]) (fp32 or bf16 CUDA tensor, row-major)."""
+        import torch
+        assert latent.is_cuda and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        assert latent.dim() == 2 and latent.stride(1) == 1
+        dt = {torch.float32: DTYPE["float32"], torch.bfloat16: DTYPE["bfloat16"]}[latent.dtype]
+        _check(self._lib.sae_decode(self._ctx, C.c_void_p(latent.data_ptr()), dt, int(latent.stride(0)), int(latent.shape[0]),
+                                    C.c_void_p(out.data_ptr()), self._stream(stream)))
 
     def metrics(self, stream=None) -> np.ndarray:
         out = np.zeros(NUM_METRICS, dtype=np.float32)

@@ -145,6 +145,21 @@ int sae_step(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, double lr,
  * encode() also performs in eval).  Fills the metrics.  Asynchronous. */
 int sae_eval(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stream);
 
+/* ---- inference (the SAE inside FlyActivationDataLoader.__iter__, dataset/activations.py:
+ * 96-108, and manipulate_latent, utils/activations.py:243-268).  sae_eval is encode(): afterwards
+ *   sae_latent_buffer  -> the latent of the last forward, bf16 [M][*row_stride] on the device (columns [0, n_dict)):
+ *                         L1: c = relu(x W + b) (l1autoencoder.py:69-75); TopK: the top-k activations scattered into a
+ *                         dense row, zeros elsewhere (topkautoencoder.py:79-85 + eager_decode's buffer, :15-18);
+ *   sae_topk_indices   -> TopK only: int32 [M][k] top_indices of the last forward (tie order: lowest column first).
+ * Pointers are owned by the context and overwritten by the next forward.
+ * sae_decode: x_hat[M][d_model] (fp32, device, dense) = latent . W^T (L1 decode(), l1autoencoder.py:77-78, with the
+ * CURRENT weights, no renormalisation) or latent_dense . W_dec + b_dec (TopK decode(), topkautoencoder.py:87-91).
+ * latent: device, row-major, `ld` elements per row, SAE_DTYPE_F32 or SAE_DTYPE_BF16; bf16 MFMA arithmetic like the
+ * train step.  M <= max_rows.  Asynchronous on `stream`. */
+int sae_latent_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* row_stride);
+int sae_topk_indices(sae_ctx* ctx, void** dev_ptr, int* k);
+int sae_decode(sae_ctx* ctx, const void* latent_dev, int latent_dtype, int64_t ld, int64_t M, float* x_hat_dev, void* stream);
+
 /* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
 int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);
 
