@@ -85,6 +85,24 @@ def main():
                         best = max(best, nb * nb_bytes / (time.perf_counter() - t0) / 1e9)
                     sweep[f"t{threads}_d{depth}"] = round(best, 1)
             out["loader_GB_per_s_sweep"] = sweep
+        # engine alone on one resident batch of the loader's shape and dtype
+        from freud_amd.engine import SaeEngine
+        xb = next(iter(dl))[0].clone()
+        eng = SaeEngine(variant="l1", d_model=args.d, n_dict=args.d * args.expansion, max_rows=xb.shape[0] * xb.shape[1],
+                        optimizer="radam", recon_alpha=1e4)
+        W = torch.empty(args.d, args.d * args.expansion)
+        torch.nn.init.orthogonal_(W)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(args.d * args.expansion, np.float32)})
+        for _ in range(50):
+            eng.step(xb, 1e-4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            eng.step(xb, 1e-4)
+        torch.cuda.synchronize()
+        out["engine_only_ms_per_step"] = (time.perf_counter() - t0) / 100 * 1e3
+        eng.close()
+
         cfg = {"whisper_config": {"model": "tiny", "layer_name": layer}, "autoencoder_variant": "l1",
                "autoencoder_config": {"expansion_factor": args.expansion, "recon_alpha": 1e4}, "seed": 0,
                "train_folder": folder, "val_folder": folder, "device": "cuda", "run_dir": os.path.join(tmp, "run"),
