@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--variant", default="l1", choices=["l1", "topk"], help="topk = BASELINE configs[2] style run")
     ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--dead-threshold", type=float, default=1e6,
+                    help="TopK dead_feature_threshold in frames (configs use 1e6: AuxK switches on after ~16 steps of 65536 "
+                         "rows once latents stay silent; 1e15 keeps AuxK off)")
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
     ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
@@ -124,7 +127,7 @@ def main():
     if args.variant == "topk":
         eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
                         clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128)
-        eng.set_topk_options(1e6, 1024)
+        eng.set_topk_options(args.dead_threshold, 1024)
         g = torch.Generator().manual_seed(0)
         We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
         Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)

@@ -826,11 +826,20 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   }
   ev_end(c, KID_TK_SELECT, s);
   ev_begin(c, KID_TK_DECODE, s);
-  hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b, bd, c->e,
-                     c->dh, c->e2_part, M, d, d_p, n_p, 0);
-  if (aux)
-    hipLaunchKernelGGL(topk_decode_kernel<T>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx, c->k_aux_cap,
-                       c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1);
+  {
+    auto launch_decode = [&](auto np_tag) {
+      constexpr int NP = decltype(np_tag)::value;
+      hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b,
+                         bd, c->e, c->dh, c->e2_part, M, d, d_p, n_p, 0);
+      if (aux)
+        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx,
+                           c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1);
+    };
+    if (d_p == 384) launch_decode(std::integral_constant<int, 3>{});
+    else if (d_p == 768) launch_decode(std::integral_constant<int, 6>{});
+    else if (d_p == 1280) launch_decode(std::integral_constant<int, 10>{});
+    else launch_decode(std::integral_constant<int, 0>{});
+  }
   const int64_t TD = T_rows * d;
   hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
                      aux ? c->a2_part : (const float*)nullptr, Mp, M, d, alpha, c->tk, c->tkf, metrics, (float)n);

@@ -107,7 +107,8 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int base32, int kk,
 
 // Epi requirements:
 //   __device__ void tile_begin(int row0, int col0, int split);
-//   __device__ void apply(int row, int col, f32x4 v);   // 4 consecutive columns
+//   struct Pre;  __device__ Pre prefetch(int row, int col) const;      // the global loads of apply(), issued early
+//   __device__ void apply(int row, int col, f32x4 v, const Pre&);      // 4 consecutive columns
 //   __device__ void tile_end(float* lds_scratch);        // block-wide reductions (all 256 threads call)
 template <int AMODE, int BMODE, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
@@ -214,11 +215,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   epi.tile_begin(bm * GEMM_BM, bn * GEMM_BN, split);
   {
     const int c4 = (t & 31) * 4;
-#pragma unroll 4
+    typename Epi::Pre pre[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(bm * GEMM_BM + (t >> 5) + 8 * it, bn * GEMM_BN + c4);
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int row = (t >> 5) + 8 * it;
       const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * GEMM_EPI_PITCH + c4]);
-      epi.apply(bm * GEMM_BM + row, bn * GEMM_BN + c4, v);
+      epi.apply(bm * GEMM_BM + row, bn * GEMM_BN + c4, v, pre[it]);
     }
   }
   __syncthreads();

@@ -180,11 +180,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
     epi.tile_begin(row0, col0, split);
     {
       const int c4 = (tl & 31) * 4;
-#pragma unroll 4
+      typename Epi::Pre pre[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * it, col0 + c4);
+#pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = (tl >> 5) + 8 * it;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
-        epi.apply(row0 + row, col0 + c4, v);
+        epi.apply(row0 + row, col0 + c4, v, pre[it]);
       }
     }
     __syncthreads();

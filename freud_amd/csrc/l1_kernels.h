@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
 }
 
 // ------------------------------------------------------------------------------------------
-// GEMM epilogues (row-major over the fp32 tile, 4 consecutive columns per call)
+// GEMM epilogues (row-major over the fp32 tile, 4 consecutive columns per call).  Two phases per thread and tile:
+// prefetch(row, col) -> Pre issues every global LOAD the element needs (all of a thread's 16 prefetches are in flight
+// before the first apply, so an epilogue pass costs about one memory latency instead of 16), apply() computes and stores.
 // ------------------------------------------------------------------------------------------
 // c = relu(bf16(x W) + b)  (l1autoencoder.py:74), rows >= M forced to 0; L1 partial sum per tile.
 struct EpiEnc {
@@ -149,8 +151,10 @@ struct EpiEnc {
     l1 = 0.f;
     tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
   }
-  __device__ void apply(int row, int col, f32x4 v) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col);
+  struct Pre { f32x4 b; };
+  __device__ Pre prefetch(int, int col) const { return Pre{*reinterpret_cast<const f32x4*>(bias + col)}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
+    const f32x4 b = pre.b;
     bf16x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -184,13 +188,20 @@ struct EpiDec {
     scale = scal[1];
     tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
   }
-  __device__ void apply(int row, int col, f32x4 v) {
+  struct Pre { float xv[4]; };
+  __device__ Pre prefetch(int row, int col) const {
+    Pre p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.xv[j] = (row < M && col + j < d) ? load_as_float(x + (int64_t)row * d + col + j) : 0.f;
+    return p;
+  }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
     bf16x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float g = 0.f;
       if (row < M && col + j < d) {
-        const float xv = load_as_float(x + (int64_t)row * d + col + j);
+        const float xv = pre.xv[j];
         const float e = bf16_round(v[j]) - xv;
         plain += e * e;
         if (xv != -1.0f) {
@@ -228,8 +239,10 @@ struct EpiDpre {
     row_tile = row0 / GEMM_BM;
     col0_ = col0;
   }
-  __device__ void apply(int row, int col, f32x4 v) {
-    const bf16x4 cv = *reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col);
+  struct Pre { bf16x4 cv; };
+  __device__ Pre prefetch(int row, int col) const { return Pre{*reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col)}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
+    const bf16x4 cv = pre.cv;
     bf16x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -261,7 +274,9 @@ struct EpiSlab {
   int ld;
   float* base;
   __device__ void tile_begin(int, int, int split) { base = slab + slab_stride * split; }
-  __device__ void apply(int row, int col, f32x4 v) { *reinterpret_cast<f32x4*>(base + (int64_t)row * ld + col) = v; }
+  struct Pre {};
+  __device__ Pre prefetch(int, int) const { return Pre{}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre&) { *reinterpret_cast<f32x4*>(base + (int64_t)row * ld + col) = v; }
   __device__ void tile_end(float*) {}
 };
 
@@ -502,7 +517,9 @@ struct EpiStoreF32 {
   int64_t M;
   int d;
   __device__ void tile_begin(int, int, int) {}
-  __device__ void apply(int row, int col, f32x4 v) {
+  struct Pre {};
+  __device__ Pre prefetch(int, int) const { return Pre{}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre&) {
     if (row >= M) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j)

@@ -89,8 +89,10 @@ struct EpiTopkEnc {
   int64_t M;
   int n_p;
   __device__ void tile_begin(int, int, int) {}
-  __device__ void apply(int row, int col, f32x4 v) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col);
+  struct Pre { f32x4 b; };
+  __device__ Pre prefetch(int, int col) const { return Pre{*reinterpret_cast<const f32x4*>(bias + col)}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pf) {
+    const f32x4 b = pf.b;
     bf16x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -389,16 +391,18 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
 // ------------------------------------------------------------------------------------------
 // One WAVE per activation row (4 rows per workgroup): lane l owns the d_p/64 contiguous columns
 // [l*cpl, (l+1)*cpl), so every gathered W_dec row is read as one contiguous, fully coalesced line by the wave.
-template <typename T>
+// NPAIR > 0: d_p == 128 * NPAIR is a compile-time constant, so a lane's 4 * NPAIR bytes of a W_dec row are fetched with
+// unconditional (mergeable into dwordx2/x4) loads and two gathered rows are kept in flight; NPAIR == 0: any d_p <= 1536.
+template <typename T, int NPAIR = 0>
 __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ dense,
                                                            const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
                                                            const float* __restrict__ b_dec, float* __restrict__ e,
                                                            float* __restrict__ dh, float* __restrict__ part, int64_t M, int d,
                                                            int d_p, int n_p, int aux) {
-  constexpr int MAXP = 12;                 // column pairs per lane: d_p <= 64 * 2 * MAXP = 1536
+  constexpr int MAXP = NPAIR > 0 ? NPAIR : 12;   // column pairs per lane: d_p <= 64 * 2 * MAXP
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
-  const int npair = d_p >> 7;              // (d_p / 64) / 2 column pairs per lane
+  const int npair = NPAIR > 0 ? NPAIR : d_p >> 7;   // (d_p / 64) / 2 column pairs per lane
   const int c0 = lane * 2 * npair;
   float acc[2 * MAXP];
 #pragma unroll
@@ -411,18 +415,44 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
     const int my_i = jj < kcap ? ri[jj] : -1;
     const float my_a = my_i >= 0 ? (float)rd[my_i] : 0.f;
     const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
-    for (int j = 0; j < cnt; ++j) {
-      const int ii = __shfl(my_i, j, 64);
-      const float av = __shfl(my_a, j, 64);
-      if (ii < 0) continue;               // wave-uniform
-      const unsigned* wr = reinterpret_cast<const unsigned*>(Wd + (int64_t)ii * d_p + c0);
+    if constexpr (NPAIR > 0) {
+      // two gathered rows per trip (negative = padding index: row 0 is read and weighted by 0)
+      for (int j = 0; j < cnt; j += 2) {
+        const int i0 = __shfl(my_i, j, 64), i1 = __shfl(my_i, j + 1 < 64 ? j + 1 : j, 64);
+        const float a0 = i0 >= 0 ? __shfl(my_a, j, 64) : 0.f;
+        const float a1 = (j + 1 < cnt && i1 >= 0) ? __shfl(my_a, j + 1 < 64 ? j + 1 : j, 64) : 0.f;
+        const unsigned* w0 = reinterpret_cast<const unsigned*>(Wd + (int64_t)(i0 >= 0 ? i0 : 0) * d_p + c0);
+        const unsigned* w1 = reinterpret_cast<const unsigned*>(Wd + (int64_t)((j + 1 < cnt && i1 >= 0) ? i1 : 0) * d_p + c0);
+        unsigned u0[NPAIR], u1[NPAIR];
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p)
-        if (p < npair) {
-          const unsigned u = wr[p];
-          acc[2 * p] += av * __uint_as_float(u << 16);
-          acc[2 * p + 1] += av * __uint_as_float(u & 0xFFFF0000u);
+        for (int p = 0; p < NPAIR; ++p) u0[p] = w0[p];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) u1[p] = w1[p];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+          acc[2 * p] += a0 * __uint_as_float(u0[p] << 16);
+          acc[2 * p + 1] += a0 * __uint_as_float(u0[p] & 0xFFFF0000u);
         }
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+          acc[2 * p] += a1 * __uint_as_float(u1[p] << 16);
+          acc[2 * p + 1] += a1 * __uint_as_float(u1[p] & 0xFFFF0000u);
+        }
+      }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        const int ii = __shfl(my_i, j, 64);
+        const float av = __shfl(my_a, j, 64);
+        if (ii < 0) continue;               // wave-uniform
+        const unsigned* wr = reinterpret_cast<const unsigned*>(Wd + (int64_t)ii * d_p + c0);
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p)
+          if (p < npair) {
+            const unsigned u = wr[p];
+            acc[2 * p] += av * __uint_as_float(u << 16);
+            acc[2 * p + 1] += av * __uint_as_float(u & 0xFFFF0000u);
+          }
+      }
     }
   }
   float sq = 0.f;
@@ -526,11 +556,18 @@ struct EpiTopkDpre {
     row_tile = row0 / GEMM_BM;
     col0_ = col0;
   }
-  __device__ void apply(int row, int col, f32x4 v) {
+  struct Pre { bf16x4 sv, prev; };
+  __device__ Pre prefetch(int row, int col) const {
     const int64_t o = (int64_t)row * n_p + col;
-    const bf16x4 sv = *reinterpret_cast<const bf16x4*>(sel + o);
-    bf16x4 prev = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    if (accumulate) prev = *reinterpret_cast<const bf16x4*>(dpre + o);
+    Pre p;
+    p.sv = *reinterpret_cast<const bf16x4*>(sel + o);
+    p.prev = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (accumulate) p.prev = *reinterpret_cast<const bf16x4*>(dpre + o);
+    return p;
+  }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
+    const int64_t o = (int64_t)row * n_p + col;
+    const bf16x4 sv = pre.sv, prev = pre.prev;
     bf16x4 out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -567,7 +604,9 @@ struct EpiTopkDsaeIn {
     row_tile = row0 / GEMM_BM;
     col0_ = col0;
   }
-  __device__ void apply(int, int, f32x4 v) {
+  struct Pre {};
+  __device__ Pre prefetch(int, int) const { return Pre{}; }
+  __device__ void apply(int, int, f32x4 v, const Pre&) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) colsum[j] += bf16_round(v[j]);
   }
