@@ -110,6 +110,8 @@ struct sae_ctx {
   int *top_idx = nullptr, *aux_idx = nullptr, *tk = nullptr;
   double* tv_part = nullptr;
   long long* nfsf = nullptr;
+  long long* dbe_fx = nullptr;  // [n_p] fixed-point d b_enc accumulator of the sparse d-activation kernel
+  bool topk_sparse_da = false;  // sparse d pre-activations (topk_dacts_kernel) instead of the dense ddense GEMM + mask
   unsigned char* dead = nullptr;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
@@ -203,6 +205,9 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->aux_idx, Mp * c->k_aux_cap * 4);
   TALLOC(c->tv_part, ((Mp * c->d + 255) / 256 + 1) * 8);
   TALLOC(c->nfsf, (size_t)c->n_p * 8);
+  TALLOC(c->dbe_fx, (size_t)c->n_p * 8);
+  // reserved[3] == 1 keeps the dense ddense GEMM (tests cover both)
+  c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.reserved[3] != 1;
   TALLOC(c->dead, c->n_p);
   TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * c->nW * 4);
   TALLOC(c->gn_part, 1024 * 8);
@@ -228,7 +233,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
-                  c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead};
+                  c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->ev_init)
@@ -849,7 +854,21 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     const int nrb = (int)((Mp + rpb - 1) / rpb);
     hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
                        c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0);
-    {  // dpre = [selected] (de W_dec^T)  (+ aux part)
+    if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row
+      ev_begin(c, KID_TK_DDENSE, s);
+      HIP_TRY(hipMemsetAsync(c->dpre, 0, (size_t)Mp * n_p * 2, s));
+      HIP_TRY(hipMemsetAsync(c->dbe_fx, 0, (size_t)n_p * 8, s));
+      auto launch_dacts = [&](auto np_tag) {
+        constexpr int NP = decltype(np_tag)::value;
+        hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, c->de_b,
+                           aux ? c->dh_b : (const bf16_t*)nullptr, c->dense, c->top_idx, k, c->aux_dense, c->aux_idx,
+                           c->k_aux_cap, c->Wd_b, c->dpre, c->dbe_fx, M, n_p);
+      };
+      if (d_p == 384) launch_dacts(std::integral_constant<int, 3>{});
+      else if (d_p == 768) launch_dacts(std::integral_constant<int, 6>{});
+      else launch_dacts(std::integral_constant<int, 10>{});
+      ev_end(c, KID_TK_DDENSE, s);
+    } else {  // dpre = [selected] (de W_dec^T)  (+ aux part) as a dense GEMM with a masking epilogue
       GemmArgs g{};
       g.A0 = c->de_b; g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
       g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
@@ -900,7 +919,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (rc) return rc;
     }
     ev_begin(c, KID_REDUCE, s);
-    hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
+    if (c->topk_sparse_da)
+      hipLaunchKernelGGL(topk_dbe_from_fx_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->dbe_fx, gbe, n_p);
+    else
+      hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
     // d b_dec also receives -sum_rows(dpre W_enc) through sae_in = x - b_dec; that row sum is a GEMV on d b_enc
     ev_begin(c, KID_TK_DSAE, s);
     const int nchunks = (n_p + 255) / 256;

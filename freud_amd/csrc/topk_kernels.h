@@ -543,6 +543,97 @@ __global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ 
   if (c < d_p) dbd_part[(int64_t)blockIdx.y * d_p + c] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse d pre-activation (replaces the dense [M x n] "ddense" GEMM + mask when d_p == 128 * NPAIR): only the selected
+// latents of a row carry gradient (topkautoencoder.py:79-91), so for every selected latent j of row m
+//     da = de[m] . W_dec[idx_j]      (bf16 operands, fp32 dot, one rounding to bf16 like the GEMM it replaces)
+//     dpre[m][idx_j] (+)= da  if its activation is > 0 (ReLU gate),   d b_enc[idx_j] += da
+// with the same gather as the sparse decode (k rows of W_dec per activation row instead of all n).  The aux selection
+// (dead latents, de_hat) is added into the same dense row afterwards by the same lane, so the result does not depend on
+// scheduling.  d b_enc is accumulated with 64-bit integer atomics in 2^-40 fixed point: exact, hence order-independent
+// (run-to-run deterministic), unlike float atomics.  dpre must be zero-filled before the launch.
+// One wave per activation row; lane l owns the 2 * NPAIR contiguous columns starting at l * 2 * NPAIR.
+// ------------------------------------------------------------------------------------------
+constexpr double TOPK_FX_SCALE = 1099511627776.0;   // 2^40
+
+template <int NPAIR>
+__global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restrict__ de_b, const bf16_t* __restrict__ dh_b,
+                                                          const bf16_t* __restrict__ dense, const int* __restrict__ idx, int k,
+                                                          const bf16_t* __restrict__ aux_dense, const int* __restrict__ aux_idx,
+                                                          int kaux_cap, const bf16_t* __restrict__ Wd, bf16_t* __restrict__ dpre,
+                                                          long long* __restrict__ dbe_fx, int64_t M, int n_p) {
+  constexpr int d_p = 128 * NPAIR;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  if (row >= M) return;                                // wave-uniform
+  const int c0 = lane * 2 * NPAIR;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bf16_t* gsrc = pass == 0 ? de_b : dh_b;
+    if (!gsrc) break;
+    const bf16_t* rd = (pass == 0 ? dense : aux_dense) + row * n_p;
+    const int kcap = pass == 0 ? k : kaux_cap;
+    const int* ri = (pass == 0 ? idx : aux_idx) + row * kcap;
+    float g[2 * NPAIR];
+    {
+      const unsigned* gp = reinterpret_cast<const unsigned*>(gsrc + row * d_p + c0);
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        const unsigned u = gp[p];
+        g[2 * p] = __uint_as_float(u << 16);
+        g[2 * p + 1] = __uint_as_float(u & 0xFFFF0000u);
+      }
+    }
+    bf16_t* out = dpre + row * n_p;
+    for (int j0 = 0; j0 < kcap; j0 += 64) {
+      const int jj = j0 + lane;
+      const int my_i = jj < kcap ? ri[jj] : -1;
+      const float my_a = my_i >= 0 ? (float)rd[my_i] : 0.f;
+      const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
+      for (int j = 0; j < cnt; j += 2) {
+        const int j1 = j + 1 < cnt ? j + 1 : j;
+        const int i0 = __shfl(my_i, j, 64), i1 = __shfl(my_i, j1, 64);
+        const float a0 = __shfl(my_a, j, 64), a1 = j + 1 < cnt ? __shfl(my_a, j1, 64) : 0.f;
+        const unsigned* w0 = reinterpret_cast<const unsigned*>(Wd + (int64_t)(i0 >= 0 ? i0 : 0) * d_p + c0);
+        const unsigned* w1 = reinterpret_cast<const unsigned*>(Wd + (int64_t)(i1 >= 0 ? i1 : 0) * d_p + c0);
+        unsigned u0[NPAIR], u1[NPAIR];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) u0[p] = w0[p];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) u1[p] = w1[p];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+          s0 += g[2 * p] * __uint_as_float(u0[p] << 16) + g[2 * p + 1] * __uint_as_float(u0[p] & 0xFFFF0000u);
+          s1 += g[2 * p] * __uint_as_float(u1[p] << 16) + g[2 * p + 1] * __uint_as_float(u1[p] & 0xFFFF0000u);
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) {
+          if (i0 >= 0 && a0 > 0.f) {
+            float v = bf16_round(s0);
+            if (pass) v += (float)out[i0];
+            out[i0] = (bf16_t)v;
+            atomicAdd(reinterpret_cast<unsigned long long*>(dbe_fx + i0),
+                      (unsigned long long)__double2ll_rn((double)bf16_round(s0) * TOPK_FX_SCALE));
+          }
+          if (j + 1 < cnt && i1 >= 0 && a1 > 0.f) {
+            float v = bf16_round(s1);
+            if (pass) v += (float)out[i1];
+            out[i1] = (bf16_t)v;
+            atomicAdd(reinterpret_cast<unsigned long long*>(dbe_fx + i1),
+                      (unsigned long long)__double2ll_rn((double)bf16_round(s1) * TOPK_FX_SCALE));
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_dbe_from_fx_kernel(const long long* __restrict__ fx, float* __restrict__ gbe, int n_p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_p) gbe[i] = (float)((double)fx[i] / TOPK_FX_SCALE);
+}
+
 // ddense epilogue: dpre = [selected] * bf16(de . W_dec^T) (+ aux part), gated by pre > 0; column sums -> d b_enc
 struct EpiTopkDpre {
   const bf16_t* sel;    // masked dense activations of this pass (selection mask = value > 0)

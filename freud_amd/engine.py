@@ -131,7 +131,8 @@ class SaeEngine:
     def __init__(self, variant: str, d_model: int, n_dict: int, max_rows: int, *, optimizer: str = "radam",
                  recon_alpha: float = 1.0, k: int = 0, auxk_alpha: float = 0.0, clip_thresh: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: Optional[float] = None, device_id: int = 0,
-                 force_generic: bool = False, debug_flags: int = 0, force_gemm128: bool = False):
+                 force_generic: bool = False, debug_flags: int = 0, force_gemm128: bool = False,
+                 topk_dense_backward: bool = False):
         if variant not in VARIANT:
             raise AssertionError(f"Invalid autoencoder variant: {variant}, must be 'l1' or 'topk'")
         if optimizer not in OPTIMIZER:
@@ -147,6 +148,7 @@ class SaeEngine:
         cfg.reserved[1] = debug_flags                 # timing experiments only (results become wrong)
         cfg.reserved[0] = 1 if force_generic else 0   # 1 = generic three-GEMM backward even where a fused kernel exists
         cfg.reserved[2] = 1 if force_gemm128 else 0   # 1 = 128x128 GEMM tiles even where the 256x256 kernel applies
+        cfg.reserved[3] = 1 if topk_dense_backward else 0   # 1 = TopK d pre-activations by the dense GEMM + mask (A/B, tests)
         self.variant, self.d, self.n, self.max_rows, self.device_id = variant, d_model, n_dict, max_rows, device_id
         self._ctx = C.c_void_p()
         _check(self._lib.sae_create(C.byref(cfg), C.byref(self._ctx)))

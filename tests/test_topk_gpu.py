@@ -175,3 +175,38 @@ def test_topk_auxk_and_dead_bookkeeping():
         eng2.set_topk_state(got[:-1])
     eng2.close()
     eng.close()
+
+
+def test_sparse_dacts_matches_dense_ddense():
+    """TopK backward: the sparse d pre-activation kernel (gathered dot products on the selected latents, exact fixed-point
+    d b_enc) and the dense GEMM + mask it replaces give the same gradients, with AuxK active (dead latents) as well."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T, aux = 384, 1024, 16, 2, 64, 0.03125
+    P, x = _make_case(d, n, k, B, T, 9)
+    xd = x.cuda()
+    res = []
+    for dense in (False, True):
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=B * T, optimizer="adam", k=k, auxk_alpha=aux,
+                        topk_dense_backward=dense)
+        eng.set_topk_options(0.5 * B * T, T)
+        eng.set_params({kk: v.numpy() for kk, v in P.items()})
+        grads = []
+        for i in range(2):                      # step 2 has dead latents -> the aux pass runs
+            eng.forward_backward(xd)
+            grads.append(eng.debug_read(2, 2 * n * d + n + d))
+            m = eng.metrics().copy()
+            eng.optimizer_step(1e-4)
+        assert m[1] > 0                         # AuxK was active
+        res.append(grads)
+        eng.close()
+    for gs, gd in zip(*res):
+        s_, d_ = _split(gs, n, d), _split(gd, n, d)
+        for key in KEYS:
+            assert _rel(s_[key], d_[key]) < 2e-3, key
+    # determinism of the fixed-point bias-gradient accumulation: two sparse runs are bitwise equal
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=B * T, optimizer="adam", k=k, auxk_alpha=aux)
+    eng.set_topk_options(0.5 * B * T, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.forward_backward(xd)
+    assert np.array_equal(eng.debug_read(2, 2 * n * d + n + d), res[0][0])
+    eng.close()
