@@ -75,6 +75,7 @@ def test_l1_steps_match_reference_golden(golden_dir, name):
     (384, 3072, 8192 + 96, torch.bfloat16, "adam", False), # several 32-row steps per row range, uneven split
     (768, 1536, 512, torch.float32, "adam", False),
     (1280, 2560, 384, torch.bfloat16, "radam", False),
+    (1280, 5120, 1024, torch.bfloat16, "adam", False),     # every GEMM on the 256x256 kernel (configs[3] proportions)
 ])
 def test_l1_step_matches_oracle(d, n, M, dtype, opt, generic):
     g = torch.Generator().manual_seed(d + n + M)
