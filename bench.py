@@ -36,6 +36,9 @@ import numpy as np
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# what a bare v_mfma_f32_32x32x16_bf16 loop at 100 % issue sustains on random bf16 operands on this chip (power-managed
+# clock 1.68 GHz; tools/mfma_clock_probe.hip, profiles/r01_mfma_clock_probe.jsonl): reported next to the nominal peak
+MEASURED_MFMA_LOOP_TFLOPS = 1700.0
 
 
 def make_inputs(M, d, n, seed, dtype, kind="lowrank"):
@@ -239,7 +242,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,
-                     "flops_per_launch": dom_flops},
+                     "flops_per_launch": dom_flops, "peak_measured_bare_mfma_loop": MEASURED_MFMA_LOOP_TFLOPS,
+                     "frac_of_measured": achieved / MEASURED_MFMA_LOOP_TFLOPS},
         "step_mfma_frac": (step_flops * world / (ms_per_step * 1e-3) / 1e12) / (PEAK_BF16_TFLOPS * world),
         "fwd_bwd_ms": fb_ms / max(fb_cnt, 1),
         "loss": {"recon": float(metrics[0]), "l1": float(metrics[1]), "grad_norm": float(metrics[3])},
