@@ -252,6 +252,9 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
     keyword-only arguments are test hooks and are never present in a config file."""
     device = torch.device(device)
     rank, local_rank, world = _dist_env()
+    # FREUD_FORCE_DIST=1 (test hook, like bench.py --force-dist): take the data-parallel code path - process group,
+    # gradient-ready callback, asynchronous all-reduce, separate optimizer call - with a single rank
+    use_dist = world > 1 or os.environ.get("FREUD_FORCE_DIST") == "1"
     if engine_factory is None:
         if device.type != "cuda":
             raise RuntimeError(f"device={device}: the train step exists only as HIP kernels for MI355X; "
@@ -260,10 +263,13 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         torch.cuda.set_device(device)
         engine_factory = _default_engine_factory
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", str(rank))
+            os.environ.setdefault("WORLD_SIZE", str(world))
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")   # RCCL logs to stdout otherwise
             os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")           # gradient buffer = engine memory
             backend = dist_backend or ("nccl" if device.type == "cuda" else "gloo")
@@ -349,9 +355,9 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             print(f"Checkpoint: {start_checkpoint}")
         load_checkpoint(state, start_checkpoint, device=device)
 
-    grads = eng.grad_tensor() if world > 1 else None
+    grads = eng.grad_tensor() if use_dist else None
     works = []
-    overlap = world > 1 and hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
+    overlap = use_dist and hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
     if overlap:
         # every range of the gradient buffer is all-reduced (RCCL, communication stream) as soon as the engine reports
         # it final, i.e. under the backward kernels that are still to run (sae_set_grad_ready_callback)
@@ -368,7 +374,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             n_batches += 1
             state["epoch_batches_done"] = n_batches
             step_lr = lr_at(state["step"], lr, scheduler, steps, scheduler_params)
-            if world > 1:
+            if use_dist:
                 eng.forward_backward(activations)
                 if overlap:
                     for w in works:                         # the compute stream waits for the communication stream
@@ -445,7 +451,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         if is_main:    # epoch-end checkpoint (train_sae.py:600-602)
             save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
     logger.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     return state
 

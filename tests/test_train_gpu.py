@@ -112,3 +112,33 @@ def test_bench_data_parallel_path_single_rank():
     ref = json.loads([l for l in single.stdout.splitlines() if l.startswith("{")][-1])
     assert res["loss"]["recon"] == pytest.approx(ref["loss"]["recon"], rel=1e-5)      # same arithmetic either way
     assert res["loss"]["grad_norm"] == pytest.approx(ref["loss"]["grad_norm"], rel=1e-4)
+
+
+@pytest.mark.parametrize("fixture", ["trainloop_l1", "trainloop_topk"])
+def test_train_data_parallel_path_single_rank(tmp_path, golden_dir, fixture):
+    """train() through its data-parallel code path (RCCL process group of one rank, gradient-ready callback, asynchronous
+    all-reduce of every announced range, separate optimizer call; FREUD_FORCE_DIST=1) ends with the same weights as the
+    single-process path.  Run in a child process: the process group must not leak into the other tests."""
+    import subprocess
+    import sys
+    z = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
+    meta = json.loads(str(z["meta"]))
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, meta["layer"], z["shard"], [meta["T"], meta["d"]],
+                 [f"/data/audio/file_{i:04d}.flac" for i in range(meta["n_files"])])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    finals = []
+    for force in ("0", "1"):
+        cfg = copy.deepcopy(meta["config"])
+        cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run" + force), device="cuda")
+        cfg_path = os.path.join(str(tmp_path), f"cfg{force}.json")
+        json.dump(cfg, open(cfg_path, "w"))
+        env = dict(os.environ, FREUD_FORCE_DIST=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        out = subprocess.run([sys.executable, "-m", "src.scripts.train_sae", "--config", cfg_path], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        ck = torch.load(os.path.join(cfg["run_dir"], "checkpoints", "step7.pth"), map_location="cpu", weights_only=True)
+        finals.append(ck["model"])
+    for k in finals[0]:
+        a, b = finals[0][k].numpy(), finals[1][k].numpy()
+        assert np.linalg.norm(a - b) <= 1e-6 * max(np.linalg.norm(a), 1e-12), k
