@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
                 buf + BF_DXH_BYTES + loff_d[p]);
     } else {
       const bf16_t* gc = a.c + row0 * a.n_p + n0;
-      glds16_x2(gc, gc, voff_c[0], voff_c[1], buf + loff_c[0], buf + loff_c[1]);
+      // the latent is read exactly once: non-temporal policy, so that it does not displace the dx_hat / x tiles the
+      // 24 column-tile workgroups of a row range share in L2 (same-box A/B: backward -4 %, -9...15 % together with the
+      // forward's non-temporal latent stores)
+      glds16_x2_nt(gc, gc, voff_c[0], voff_c[1], buf + loff_c[0], buf + loff_c[1]);
     }
   };
 

@@ -55,4 +55,18 @@ __device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1
       : "memory");
 }
 
+// Same, with the non-temporal cache policy: for streams that are read exactly once (the latent in the backward)
+__device__ __forceinline__ void glds16_x2_nt(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
+                                             unsigned dst0, unsigned dst1) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
+      : "memory");
+}
+
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
