@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
 }
 
 // ------------------------------------------------------------------------------------------
+// Store of a large output that is next read only after it has left every cache (the [M x n] latent / pre / dpre
+// streams): non-temporal, so that it does not evict the operand tiles the co-resident workgroups share (same-box A/B at
+// d=1280 n=40960: encoder GEMM 7.1 -> 6.4 ms, dpre 7.85 -> 7.55; TopK encoder at d=768 3.03 -> 2.55 ms)
+#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+// ... and the matching read of such a stream inside an epilogue (dpre GEMM reading the latent: 7.6 -> 7.1 ms)
+#define EPI_LOAD(ptr) __builtin_nontemporal_load(ptr)
+
 // GEMM epilogues (row-major over the fp32 tile, 4 consecutive columns per call).  Two phases per thread and tile:
 // prefetch(row, col) -> Pre issues every global LOAD the element needs (all of a thread's 16 prefetches are in flight
 // before the first apply, so an epilogue pass costs about one memory latency instead of 16), apply() computes and stores.
@@ -163,7 +170,7 @@ struct EpiEnc {
       l1 += cv;
       o[j] = (bf16_t)cv;
     }
-    *reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col) = o;
+    EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256(l1, scratch);
@@ -240,7 +247,7 @@ struct EpiDpre {
     col0_ = col0;
   }
   struct Pre { bf16x4 cv; };
-  __device__ Pre prefetch(int row, int col) const { return Pre{*reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col)}; }
+  __device__ Pre prefetch(int row, int col) const { return Pre{EPI_LOAD(reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col))}; }
   __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
     const bf16x4 cv = pre.cv;
     bf16x4 o;
@@ -250,7 +257,7 @@ struct EpiDpre {
       colsum[j] += g;
       o[j] = (bf16_t)g;
     }
-    *reinterpret_cast<bf16x4*>(dpre + (int64_t)row * n_p + col) = o;
+    EPI_STORE(reinterpret_cast<bf16x4*>(dpre + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float* scratch) {
     // thread t owns columns 4*(t&31).. of row group t>>5: reduce the 8 row groups through LDS

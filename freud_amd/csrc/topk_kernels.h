@@ -100,7 +100,7 @@ struct EpiTopkEnc {
       if (row >= M) p = 0.f;
       o[j] = (bf16_t)p;
     }
-    *reinterpret_cast<bf16x4*>(pre + (int64_t)row * n_p + col) = o;
+    EPI_STORE(reinterpret_cast<bf16x4*>(pre + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float*) {}
 };
