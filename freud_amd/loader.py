@@ -77,9 +77,49 @@ class MemoryMappedActivationDataLoader:
         self.device = torch.device(device)
         self.rank, self.world_size, self.depth = rank, world_size, max(2, depth)
         self.dl_max_workers = dl_max_workers
+        # direct mode: the shard mapping is host-registered (pinned in place) so that rows travel to HBM by DMA straight
+        # from the page cache, without a CPU gather into staging buffers (measured on the MI355X host: the whole train()
+        # loop 25.5 M fp16 activations/s against 18-22 M staged, with no gather threads).  Registration faults in and pins
+        # the whole file, so it is automatic only up to 8 GiB; FREUD_LOADER_DIRECT=1 forces it, =0 disables it; any
+        # failure to register (no GPU, locked-memory limit, mapping larger than RAM) silently keeps the staged path.
+        self._direct = False
+        self._registered = None
+        mode = os.environ.get("FREUD_LOADER_DIRECT", "auto")
+        small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= (8 << 30)
+        if self.device.type == "cuda" and (mode == "1" or (mode not in ("0",) and small)):
+            self._try_register()
         self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else min(8, max(1, (os.cpu_count() or 1) // 4))
         self._pool = None
         self.skip_next = 0          # resume (train_sae f4): the next iterator drops this many leading batches unread
+
+    def _try_register(self) -> None:
+        try:
+            mm = self._dataset.mmap
+            if not isinstance(mm, np.memmap) or mm.size == 0 or not mm.flags["C_CONTIGUOUS"]:
+                return
+            base, nbytes, page = mm.ctypes.data, mm.size * mm.itemsize, 4096
+            start = base & ~(page - 1)
+            length = ((base + nbytes + page - 1) & ~(page - 1)) - start
+            torch.cuda.init()
+            rc = torch.cuda.cudart().cudaHostRegister(start, length, 0x08)        # hipHostRegisterReadOnly
+            if int(rc) != 0:
+                return
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                                    # read-only mapping: never written
+                self._mm_t = torch.from_numpy(mm)
+            self._registered = start
+            self._direct = bool(self._mm_t[0].is_pinned())
+        except Exception:
+            self._direct = False
+
+    def __del__(self):
+        try:
+            if self._registered is not None:
+                torch.cuda.cudart().cudaHostUnregister(self._registered)
+                self._registered = None
+        except Exception:
+            pass
 
     def __len__(self) -> int:   # reference quirk kept: floor division even without drop_last (:205-206)
         return (len(self._dataset) // self.world_size) // self.batch_size
@@ -138,7 +178,50 @@ class MemoryMappedActivationDataLoader:
             return
         yield from self._iter_cuda(batches, T, d, names, np_dtype)
 
+    def _iter_cuda_direct(self, batches, T, d, names):
+        """Rows -> HBM by asynchronous copies straight from the registered mapping (one DMA per file), into a ring of
+        `depth` device buffers; the compute stream waits for a batch's copies, the copy stream for the compute work that
+        last used the buffer."""
+        B, depth, dev = self.batch_size, self.depth, self.device
+        hbm = [torch.empty((B, T * d), dtype=self._mm_t.dtype, device=dev) for _ in range(depth)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        consumed = [None] * depth
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemcpyAsync.restype = ctypes.c_int
+        except OSError:
+            hip = None
+        row_bytes = T * d * self._mm_t.element_size()
+        src0 = self._mm_t.data_ptr()
+        for bi, idxs in enumerate(batches):
+            slot = bi % depth
+            compute = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(copy_stream):
+                if consumed[slot] is not None:
+                    copy_stream.wait_event(consumed[slot])
+                if hip is not None:          # one hipMemcpyAsync per file, issued without the per-call torch overhead
+                    dst0, st = hbm[slot].data_ptr(), ctypes.c_void_p(copy_stream.cuda_stream)
+                    for j, i in enumerate(idxs):
+                        rc = hip.hipMemcpyAsync(ctypes.c_void_p(dst0 + j * row_bytes), ctypes.c_void_p(src0 + i * row_bytes),
+                                                ctypes.c_size_t(row_bytes), 1, st)
+                        if rc != 0:
+                            raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
+                else:
+                    for j, i in enumerate(idxs):
+                        hbm[slot][j].copy_(self._mm_t[i], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(copy_stream)
+            compute.wait_event(landed)
+            yield hbm[slot][: len(idxs)].view(len(idxs), T, d), [names[i] for i in idxs]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            consumed[slot] = ev
+
     def _iter_cuda(self, batches, T, d, names, np_dtype):
+        if self._direct:
+            yield from self._iter_cuda_direct(batches, T, d, names)
+            return
         B, depth, dev = self.batch_size, self.depth, self.device
         tdtype = torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
         pinned = [torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)]

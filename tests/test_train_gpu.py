@@ -48,12 +48,17 @@ def test_train_cli_path_matches_reference(tmp_path, golden_dir):
     assert os.path.exists(os.path.join(cfg["run_dir"], "checkpoints", "bestval.pth"))
 
 
-def test_cuda_streamer_delivers_exact_rows(tmp_path):
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_cuda_streamer_delivers_exact_rows(tmp_path, direct, monkeypatch):
+    """Both streaming modes: rows by DMA straight from the host-registered mapping, and the staged path (threaded gather ->
+    pinned ring -> copy stream) that is the fallback when registration is not possible."""
+    monkeypatch.setenv("FREUD_LOADER_DIRECT", direct)
     n_files, T, d = 23, 5, 384
     rows = np.random.default_rng(0).standard_normal((n_files, T * d)).astype(np.float16)
     write_shards(str(tmp_path), "L", rows, [T, d])
     dl = MemoryMappedActivationDataLoader(str(tmp_path), "L", 4, 0, None, {"shuffle": True, "drop_last": False},
                                           device="cuda")
+    assert dl._direct == (direct == "1")
     seen = set()
     for x, names in dl:
         assert x.is_cuda and x.dtype == torch.float16
