@@ -258,6 +258,9 @@ def main():
               "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
         print("fwd in-kernel clock %.0f MHz (median), loop cycles/iteration %.0f" %
               (np.median(st[:, 4] / st[:, 5]) * 100.0, np.median(st[:, 4] / st[:, 3])), file=sys.stderr)
+        print("fwd per-workgroup cycles (median): prologue %.0f | loop %.0f | epilogue %.0f | whole %.0f" %
+              (np.median(st[:, 6]), np.median(st[:, 4]), np.median(st[:, 7] - st[:, 6] - st[:, 4]), np.median(st[:, 7])),
+              file=sys.stderr)
     if args.dbg == 66 and rank == 0:     # clock stamps of the fused backward
         st = eng.debug_read(6, (n // 128 + (1 if n % 128 else 0)) * 40).reshape(-1, 4)
         st = st[st[:, 3] > 0]

@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const bool row_ok = mrow < a.M;
   char* cst = smem + FF_RING_BYTES + w * 8192;                  // this wave's latent staging (2 x 4 KB)
   float* bias_s = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
+  unsigned long long clk_k0 = 0;
+  if (STAMP) clk_k0 = __builtin_amdgcn_s_memtime();
 
   // x fragments: B[k = d][col = m] -> lane (m = lane&31, h) holds xb[m0 + m][16 kk + 8 h ..+8]
   bf16x8 xfrag[24];
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       for (int q = 0; q < 4; ++q) a.stamps[((int64_t)wg * 4 + w) * 8 + q] = tsum[q];
       a.stamps[((int64_t)wg * 4 + w) * 8 + 4] = t1 - clk_t0;
       a.stamps[((int64_t)wg * 4 + w) * 8 + 5] = r1 - clk_r0;
+      a.stamps[((int64_t)wg * 4 + w) * 8 + 6] = clk_t0 - clk_k0;      // prologue cycles
     }
   }
   // ---- final half iteration: decoder of the last tile (slot 3, c^T in CB); its first DIST fragments are in the ring
@@ -346,6 +349,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   typedef __attribute__((ext_vector_type(4))) T Tx4;
   const bool vec_ok = (a.d == FF_D) && ((reinterpret_cast<uintptr_t>(a.x) & (sizeof(T) * 4 - 1)) == 0);
   const float rmask = row_ok ? 1.f : 0.f;
+  constexpr int FF_DXH_PITCH = FF_D * 2 + 16;                    // 784 B: 16-byte aligned rows, at most 2-way bank conflicts
+  char* stg = smem + w * 32768;                                  // per-wave [32 rows][784 B] inside rings + latent staging
+  static_assert(32 * FF_DXH_PITCH <= 32768 && 4 * 32768 <= FF_FIXED_LDS, "dx_hat staging must fit the idle LDS");
   if (vec_ok) {
 #pragma unroll
     for (int dt = 0; dt < 12; ++dt) {
@@ -366,10 +372,19 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
           sq += keep * e2;
           o[q] = (bf16_t)(keep * (e * 2.0f));
         }
-        // default cache policy on purpose: dx_hat is re-read by the 24 column-tile workgroups of the backward, and a
-        // non-temporal store here costs +6 % in the forward and +8 % in the backward (same-box A/B)
-        *reinterpret_cast<bf16x4*>(drow + 32 * dt + 8 * k + 4 * ah) = o;
+        // staged in LDS (rings and latent staging are idle: the barrier above retired every DMA): one row per lane
+        // straight to HBM would be 48 scattered 8-byte stores per lane, a store-ISSUE-bound tail
+        *reinterpret_cast<bf16x4*>(stg + arow * FF_DXH_PITCH + (32 * dt + 8 * k + 4 * ah) * 2) = o;
       }
+    }
+    // the wave's 32 rows are one contiguous 24 KiB block of dx_hat: 24 fully coalesced 16-byte stores per lane.  Default
+    // cache policy on purpose: dx_hat is re-read by the 24 column-tile workgroups of the backward (non-temporal stores
+    // here cost +6 % in the forward and +8 % in the backward, same-box A/B)
+    char* gblk = reinterpret_cast<char*>(a.dxh + m0 * FF_D);
+#pragma unroll
+    for (int pc = 0; pc < 24; ++pc) {
+      const int off = pc * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
+      *reinterpret_cast<u32x4*>(gblk + off) = *reinterpret_cast<const u32x4*>(stg + r * FF_DXH_PITCH + cb);
     }
   } else {
     for (int dt = 0; dt < 12; ++dt)
@@ -402,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   const float sqs = block_sum_256(sq, red + 8);
   const float pls = block_sum_256(plain, red + 16);
   const float nms = block_sum_256(nmask, red + 24);
+  if (STAMP && lane == 0) a.stamps[((int64_t)wg * 4 + w) * 8 + 7] = __builtin_amdgcn_s_memtime() - clk_k0;   // whole kernel
   if (t == 0) {
     a.cnt_part[wg] = nms;
     a.l1_part[wg] = l1s;
