@@ -352,12 +352,32 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   constexpr int FF_DXH_PITCH = FF_D * 2 + 16;                    // 784 B: 16-byte aligned rows, at most 2-way bank conflicts
   char* stg = smem + w * 32768;                                  // per-wave [32 rows][784 B] inside rings + latent staging
   static_assert(32 * FF_DXH_PITCH <= 32768 && 4 * 32768 <= FF_FIXED_LDS, "dx_hat staging must fit the idle LDS");
+  // 2-byte activations of full workgroups: the wave's 32 x rows are ONE contiguous 24 KiB block, fetched with 24
+  // coalesced 16-byte loads per lane into the staging image; each lane then reads its row from LDS and overwrites the
+  // 8 bytes it consumed with the 8 bytes of dx_hat it produced (same position, same size).
+  constexpr bool X_VIA_LDS = !PAD && sizeof(T) == 2;
+  if (X_VIA_LDS && vec_ok) {
+    const char* xblk = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.x) + m0 * FF_D);
+#pragma unroll
+    for (int p0 = 0; p0 < 24; p0 += 8) {        // 8 loads in flight per lane (register budget)
+      u32x4 xr[8];
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) xr[pc] = *reinterpret_cast<const u32x4*>(xblk + (p0 + pc) * 1024 + lane * 16);
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        const int off = (p0 + pc) * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
+        *reinterpret_cast<u32x4*>(stg + r * FF_DXH_PITCH + cb) = xr[pc];
+      }
+    }
+  }
   if (vec_ok) {
 #pragma unroll
     for (int dt = 0; dt < 12; ++dt) {
       Tx4 xv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const Tx4*>(xrow + 32 * dt + 8 * k + 4 * ah);
+      for (int k = 0; k < 4; ++k)
+        xv[k] = X_VIA_LDS ? *reinterpret_cast<const Tx4*>(stg + arow * FF_DXH_PITCH + (32 * dt + 8 * k + 4 * ah) * 2)
+                          : *reinterpret_cast<const Tx4*>(xrow + 32 * dt + 8 * k + 4 * ah);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         bf16x4 o;
