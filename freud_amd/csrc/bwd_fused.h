@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   const int split = id / a.ntiles, ntile = id - split * a.ntiles;
   const int step_begin = (int)((int64_t)a.steps_total * split / a.splits);
   const int step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
+  unsigned long long clk_k0 = 0;
+  if (a.clk) clk_k0 = __builtin_amdgcn_s_memtime();
   const int n0 = ntile * BF_BN;           // first dictionary column of the workgroup
   const int nw = n0 + 32 * w;             // first column of this wave
   // With an unscaled dx_hat everything is computed in units of 1/scale: dpre' = dc' + (1/M)/scale, and the
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
       unsigned long long* o = a.clk + (int64_t)blockIdx.x * 4;
-      o[0] = t1 - clk_t0; o[1] = r1 - clk_r0; o[2] = (unsigned long long)(step_end - step_begin); o[3] = 1;
+      o[0] = t1 - clk_t0; o[1] = r1 - clk_r0; o[2] = (unsigned long long)(step_end - step_begin); o[3] = clk_t0 - clk_k0;
     }
   }
 
@@ -285,5 +287,9 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       }
     db_acc += __shfl_xor(db_acc, 32, 64);
     if (lane < 32) a.db_part[(int64_t)split * a.n_p + nw + lane] = db_acc * scale;
+  }
+  if (a.clk && threadIdx.x == 0) {   // whole-kernel cycles of this workgroup in the upper half of the stamp buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    a.clk[(int64_t)(gridDim.x + blockIdx.x) * 4] = __builtin_amdgcn_s_memtime() - clk_k0;
   }
 }
