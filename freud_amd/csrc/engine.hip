@@ -1067,7 +1067,7 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     return SAE_OK;
   }
   if (which == 6) {   // clock stamps of the fused backward (reserved[1] == 66): [wg][4] as floats
-    const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4;
+    const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4 * 2;   // [0]: loop stamps per workgroup, [1]: whole-kernel cycles
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
     std::vector<unsigned long long> tmp((size_t)nq);
     HIP_TRY(hipMemcpy(tmp.data(), reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16), tmp.size() * 8, hipMemcpyDeviceToHost));
