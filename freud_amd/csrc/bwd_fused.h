@@ -68,10 +68,16 @@ __device__ __forceinline__ bf16x8 tr_frag_perm(const char* img, int col0, int s,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// Pair p of the next step's 7 DMA pairs is issued in gap BF_DMA_A * p + BF_DMA_B.  Measured placements (cycles per
-// step at C2, same box): 3p+1 3360, 5p+1 3325 (shipped), 2p+1 3565, p+1 3814 (back-to-back pieces cost more each),
-// 8p+1 3860 and 3p+24 4044 (the last pieces land after the hand-over barrier), one wave per gap (staggered) 3710.
-constexpr int BF_DMA_A = 5, BF_DMA_B = 1;
+// Pair p of the next step's 7 DMA pairs is issued in gap BF_DMA_A * p + BF_DMA_B (macros so that tools/build_variant.sh
+// can sweep them).  Same-box sweeps of the backward at C2: with the default cache policy on the latent (cycles per step)
+// 3p+1 3360, 5p+1 3325, 2p+1 3565, p+1 3814 (back-to-back pieces cost more each), 8p+1 3860 and 3p+24 4044 (the last
+// pieces land after the hand-over barrier), one wave per gap (staggered) 3710; with the non-temporal latent reads (ms)
+// 4p+1 0.2871 (shipped), 4p+2 0.2874, 3p+2 0.2886, 3p+1 0.2895, 5p+1 0.2925, 2p+1 0.299, 6p+1 0.314, p+1 0.312, 8p+2 0.355.
+#ifndef BF_DMA_A_
+#define BF_DMA_A_ 4
+#define BF_DMA_B_ 1
+#endif
+constexpr int BF_DMA_A = BF_DMA_A_, BF_DMA_B = BF_DMA_B_;
 
 __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
