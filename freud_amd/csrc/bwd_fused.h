@@ -9,14 +9,15 @@
 // and a contiguous range of activation rows; wave w owns columns 32w..32w+31:
 //   - its slice of W^T (32 columns x K=384, 24 MFMA B-fragments) stays in registers for the whole kernel;
 //   - its dW slab [384 x 32] fp32 stays in 192 accumulator registers (12 MFMA tiles) across all rows;
-//   - per 32-row step the dx_hat / x / c tiles are staged global -> registers -> LDS (double buffered);
+//   - per 32-row step the dx_hat / x / c tiles are staged by LDS-DMA (global_load_lds, double buffered; the
+//     latent tile with the non-temporal policy: it is read exactly once);
 //     dc is one 32x32 MFMA tile (24 MFMAs, A = dx_hat rows by ds_read_b128); its accumulator registers are
 //     gated by c and turned into the bf16 B-operand of the x^T dpre product without leaving the register
 //     file (accumulator-as-operand: rows of the 32x32 tile are the next product's K index);
 //     the A-operands dx_hat^T and x^T are read from the SAME row-major LDS images with the hardware
 //     transposing read ds_read_b64_tr_b16, in the permuted k order the accumulator layout dictates.
 // dpre never exists in HBM; c is read exactly once.  Partial dW slabs / db vectors (one per row range)
-// are summed by reduce_slabs_kernel / reduce_db_kernel in a fixed order (deterministic).
+// are summed by reduce_grads_kernel in a fixed order (deterministic).
 #pragma once
 #include "common.h"
 #include "gemm.h"
