@@ -194,25 +194,30 @@ class MemoryMappedActivationDataLoader:
             hip = None
         row_bytes = T * d * self._mm_t.element_size()
         src0 = self._mm_t.data_ptr()
+        nstreams = int(os.environ.get("FREUD_LOADER_STREAMS", "2"))      # copy engines fed in parallel (rows alternate)
+        streams = [copy_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(nstreams, 1) - 1)]
         for bi, idxs in enumerate(batches):
             slot = bi % depth
             compute = torch.cuda.current_stream(dev)
-            with torch.cuda.stream(copy_stream):
+            for st_ in streams:
                 if consumed[slot] is not None:
-                    copy_stream.wait_event(consumed[slot])
-                if hip is not None:          # one hipMemcpyAsync per file, issued without the per-call torch overhead
-                    dst0, st = hbm[slot].data_ptr(), ctypes.c_void_p(copy_stream.cuda_stream)
-                    for j, i in enumerate(idxs):
-                        rc = hip.hipMemcpyAsync(ctypes.c_void_p(dst0 + j * row_bytes), ctypes.c_void_p(src0 + i * row_bytes),
-                                                ctypes.c_size_t(row_bytes), 1, st)
-                        if rc != 0:
-                            raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
-                else:
-                    for j, i in enumerate(idxs):
+                    st_.wait_event(consumed[slot])
+            if hip is not None:          # one hipMemcpyAsync per file, issued without the per-call torch overhead
+                dst0 = hbm[slot].data_ptr()
+                sts = [ctypes.c_void_p(st_.cuda_stream) for st_ in streams]
+                for j, i in enumerate(idxs):
+                    rc = hip.hipMemcpyAsync(ctypes.c_void_p(dst0 + j * row_bytes), ctypes.c_void_p(src0 + i * row_bytes),
+                                            ctypes.c_size_t(row_bytes), 1, sts[j % len(sts)])
+                    if rc != 0:
+                        raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
+            else:
+                for j, i in enumerate(idxs):
+                    with torch.cuda.stream(streams[j % len(streams)]):
                         hbm[slot][j].copy_(self._mm_t[i], non_blocking=True)
+            for st_ in streams:
                 landed = torch.cuda.Event()
-                landed.record(copy_stream)
-            compute.wait_event(landed)
+                landed.record(st_)
+                compute.wait_event(landed)
             yield hbm[slot][: len(idxs)].view(len(idxs), T, d), [names[i] for i in idxs]
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
