@@ -102,13 +102,13 @@ class MemoryMappedActivationDataLoader:
             length = ((base + nbytes + page - 1) & ~(page - 1)) - start
             torch.cuda.init()
             rc = torch.cuda.cudart().cudaHostRegister(start, length, 0x08)        # hipHostRegisterReadOnly
-            if int(rc) != 0:
-                return
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")                                    # read-only mapping: never written
                 self._mm_t = torch.from_numpy(mm)
-            self._registered = start
+            if int(rc) == 0:
+                self._registered = start                                           # ours to unregister
+            # rc != 0 with pinned rows: another loader of this process registered the same mapping - use it as is
             self._direct = bool(self._mm_t[0].is_pinned())
         except Exception:
             self._direct = False
