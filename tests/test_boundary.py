@@ -59,3 +59,15 @@ def test_train_refuses_cpu_device():
               clip_thresh=1.0, batch_size=1, dl_max_workers=0, log_tb_every=1, save_every=1, val_every=1,
               start_checkpoint=None, whisper_config={"model": "tiny", "layer_name": "l"}, optimizer="adam",
               scheduler="cosine", scheduler_params={}, from_disk=True, autoencoder_variant="l1", autoencoder_config={})
+
+
+def test_inference_models_refuse_cpu_device():
+    """freud_amd.models (the mirror of the reference's L1AutoEncoder / TopKAutoEncoder for inference) has no CPU path either."""
+    from freud_amd.config import L1AutoEncoderConfig, TopKAutoEncoderConfig
+    from freud_amd.models import L1AutoEncoder, TopKAutoEncoder, L1ForwardOutput, TopKForwardOutput
+    assert L1ForwardOutput._fields == ("sae_out", "encoded", "l1_loss", "reconstruction_loss")          # l1autoencoder.py:19-26
+    assert TopKForwardOutput._fields == ("sae_out", "encoded", "fvu", "auxk_loss", "multi_topk_fvu")     # topkautoencoder.py:29-41
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L1AutoEncoder(16, L1AutoEncoderConfig(expansion_factor=2), device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TopKAutoEncoder(16, TopKAutoEncoderConfig(expansion_factor=2, k=4), device="cpu")
