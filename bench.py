@@ -210,13 +210,16 @@ def main():
     fb_ms, fb_cnt = times["fwd_bwd_total"]
 
     breakdown = None
-    if args.breakdown and rank == 0:
+    if args.breakdown:        # every rank runs the extra steps (they contain collectives); rank 0 reports
         eng.profile(2)
         for i in range(10):
             one_step(args.warmup + args.steps + i)
         breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in eng.kernel_times().items()}
         eng.profile(0)
-        print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
+        if rank == 0:
+            print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
+        else:
+            breakdown = None
 
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the value
     # measured with rocprofv3 (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled

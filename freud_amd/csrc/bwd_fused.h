@@ -1,7 +1,8 @@
 // Fused backward of the tied-weight L1 SAE for d_model (padded) == 384 on gfx950.
 //
 // Per (row r, dictionary column j):   dc = dx_hat[r,:] . W[:,j]
-//                                     dpre = (bf16(dc) + 1/M) * [c > 0]
+//                                     dpre = bf16(dc + 1/M) * [c > 0]      (the 1/M term rides in the fp32 accumulator: one
+//                                                                           rounding, where CPU autocast rounds dc first)
 // and the single tied weight gradient dW[:, j] += dx_hat[r,:]^T c[r,j] + x[r,:]^T dpre[r,j],  db[j] += dpre[r,j]
 // (reference: autograd of src/models/l1autoencoder.py:69-95).
 //

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../include/freud_sae.h"
@@ -14,6 +15,7 @@
 #include "gemm256.h"
 
 static bool g_force_gemm128 = false;   // sae_config.reserved[2] == 1: keep every GEMM on the 128x128 kernel (A/B timing, tests)
+static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
 #include "topk_kernels.h"
@@ -34,6 +36,21 @@ static int fail(int code, const char* fmt, ...) {
     hipError_t e_ = (expr);                                                                             \
     if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                                       __FILE__, __LINE__);                                              \
+  } while (0)
+
+// dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: remember (function, device) pairs
+static int ensure_lds_attr(const void* fn, int bytes, int device) {
+  static std::vector<std::pair<const void*, int>> done;
+  for (const auto& e : done)
+    if (e.first == fn && e.second == device) return SAE_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.emplace_back(fn, device);
+  return SAE_OK;
+}
+#define LDS_ATTR(fn, bytes, device)                                           \
+  do {                                                                        \
+    int rc_ = ensure_lds_attr(reinterpret_cast<const void*>(fn), (bytes), (device)); \
+    if (rc_) return rc_;                                                      \
   } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -94,6 +111,7 @@ struct sae_ctx {
   int gn_blocks = 0;
   bool step_fused_call = false; // set by sae_step: forward_backward and optimizer_step back to back
   bool gn_valid = false;       // gn_part holds the sum of squares of the UNSCALED local gradient
+  bool metrics_fresh = false;  // the loss scalars were written by a forward and not yet averaged by an optimizer step
   const bf16_t* xb_cur = nullptr;   // bf16 GEMM copy of the current batch (== the caller's x when no copy is needed)
   unsigned int* masked = nullptr;
   int dw_splits = 1;
@@ -121,17 +139,28 @@ struct sae_ctx {
   bool ev_init = false;
 };
 
+static int use_device(const sae_ctx* c) {
+  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  g_device = c->cfg.device_id;
+  return SAE_OK;
+}
+#define USE_DEVICE(c)          \
+  do {                         \
+    int rc_ = use_device(c);   \
+    if (rc_) return rc_;       \
+  } while (0)
+
 static int dominant_kid(const sae_ctx* c) { return c->topk ? KID_TK_ENC : (c->use_fused_bwd ? KID_BWD_FUSED : KID_DW); }
 static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
   if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
     EvRing& r = c->ev[kid];
-    hipEventRecord(r.beg[r.n % EV_RING], s);
+    (void)hipEventRecord(r.beg[r.n % EV_RING], s);   // a failure stays sticky and is reported by the hipGetLastError that ends the call
   }
 }
 static void ev_end(sae_ctx* c, int kid, hipStream_t s) {
   if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
     EvRing& r = c->ev[kid];
-    hipEventRecord(r.end[r.n % EV_RING], s);
+    (void)hipEventRecord(r.end[r.n % EV_RING], s);
     r.n++;
   }
 }
@@ -162,6 +191,18 @@ static int choose_splits(int r128, int c128, int64_t ktiles) {
     }
   }
   return best;
+}
+
+static int create_events(sae_ctx* c) {
+  for (auto& r : c->ev)
+    for (int i = 0; i < EV_RING; ++i) r.beg[i] = r.end[i] = nullptr;
+  c->ev_init = true;               // from here on sae_destroy releases whatever was created
+  for (auto& r : c->ev)
+    for (int i = 0; i < EV_RING; ++i) {
+      HIP_TRY(hipEventCreate(&r.beg[i]));
+      HIP_TRY(hipEventCreate(&r.end[i]));
+    }
+  return SAE_OK;
 }
 
 static int topk_create(sae_ctx* c, int64_t Mp) {
@@ -217,30 +258,26 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   HIP_TRY(hipMemset(c->Var, 0, c->nparams * 4));
   HIP_TRY(hipMemset(c->G, 0, (c->nparams + ntail) * 4));
   HIP_TRY(hipMemset(c->nfsf, 0, (size_t)c->n_p * 8));
-  for (auto& r : c->ev)
-    for (int i = 0; i < EV_RING; ++i) {
-      hipEventCreate(&r.beg[i]);
-      hipEventCreate(&r.end[i]);
-    }
-  c->ev_init = true;
+  int rc_ev = create_events(c);
+  if (rc_ev) return rc_ev;
   HIP_TRY(hipDeviceSynchronize());
   return SAE_OK;
 }
 
 extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->cfg.device_id);
+  (void)hipSetDevice(c->cfg.device_id);   // teardown: nothing useful can be done about a failure here
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx};
   for (void* p : ptrs)
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   if (c->ev_init)
     for (auto& r : c->ev)
       for (int i = 0; i < EV_RING; ++i) {
-        hipEventDestroy(r.beg[i]);
-        hipEventDestroy(r.end[i]);
+        if (r.beg[i]) (void)hipEventDestroy(r.beg[i]);
+        if (r.end[i]) (void)hipEventDestroy(r.end[i]);
       }
   delete c;
 }
@@ -262,6 +299,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(SAE_ERR_INVALID, "device_id %d out of range", cfg->device_id);
   HIP_TRY(hipSetDevice(cfg->device_id));
+  g_device = cfg->device_id;
 
   sae_ctx* c = new sae_ctx();
   c->cfg = *cfg;
@@ -338,18 +376,23 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
 #undef ALLOC
-  hipMemset(c->P, 0, c->nparams * 4);
-  hipMemset(c->Mom, 0, c->nparams * 4);
-  hipMemset(c->Var, 0, c->nparams * 4);
-  hipMemset(c->G, 0, (c->nparams + SAE_NUM_METRICS) * 4);
-  for (auto& r : c->ev)
-    for (int i = 0; i < EV_RING; ++i) {
-      hipEventCreate(&r.beg[i]);
-      hipEventCreate(&r.end[i]);
+  {
+    int rc_init = [&]() -> int {
+      HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
+      HIP_TRY(hipMemset(c->Mom, 0, c->nparams * 4));
+      HIP_TRY(hipMemset(c->Var, 0, c->nparams * 4));
+      HIP_TRY(hipMemset(c->G, 0, (c->nparams + SAE_NUM_METRICS) * 4));
+      int rc_ev = create_events(c);
+      if (rc_ev) return rc_ev;
+      // > 64 KiB dynamic LDS is opted in to lazily at the first launch of every kernel instantiation (LDS_ATTR)
+      HIP_TRY(hipDeviceSynchronize());
+      return SAE_OK;
+    }();
+    if (rc_init) {
+      sae_destroy(c);
+      return rc_init;
     }
-  c->ev_init = true;
-  // opt in to > 64 KiB dynamic LDS for every GEMM instantiation lazily at first launch (see launch_gemm)
-  HIP_TRY(hipDeviceSynchronize());
+  }
   *out = c;
   return SAE_OK;
 }
@@ -405,7 +448,7 @@ static int xfer_flat_topk(sae_ctx* c, float* internal, float* const ext[4], int 
 
 extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, const float* p2, const float* p3, int is_device) {
   if (!c || !p0 || !p1) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
   if (c->topk) {
@@ -418,7 +461,7 @@ extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, cons
 
 extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float* p2, float* p3, int is_device) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   if (c->topk) {
     float* const ext[4] = {p0, p1, p2, p3};
@@ -430,7 +473,7 @@ extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float* p2, float
 extern "C" int sae_set_opt_state(sae_ctx* c, int64_t step, const float* const exp_avg[4], const float* const exp_avg_sq[4],
                                  int is_device) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   c->step = step;
   int rc = SAE_OK;
@@ -455,7 +498,7 @@ extern "C" int sae_set_opt_state(sae_ctx* c, int64_t step, const float* const ex
 extern "C" int sae_get_opt_state(sae_ctx* c, int64_t* step, float* const exp_avg[4], float* const exp_avg_sq[4],
                                  int is_device) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   if (step) *step = c->step;
   int rc = SAE_OK;
@@ -486,7 +529,7 @@ extern "C" int sae_get_topk_state(sae_ctx* c, int64_t* out, int64_t n) {
   if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
   if (!c->topk) return fail(SAE_ERR_INVALID, "sae_get_topk_state: not a TopK context");
   if (n != c->n) return fail(SAE_ERR_INVALID, "sae_get_topk_state: n = %lld, context has %d latents", (long long)n, c->n);
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, c->nfsf, (size_t)n * 8, hipMemcpyDeviceToHost));
   return SAE_OK;
@@ -496,7 +539,7 @@ extern "C" int sae_set_topk_state(sae_ctx* c, const int64_t* in, int64_t n) {
   if (!c || !in) return fail(SAE_ERR_INVALID, "null argument");
   if (!c->topk) return fail(SAE_ERR_INVALID, "sae_set_topk_state: not a TopK context");
   if (n != c->n) return fail(SAE_ERR_INVALID, "sae_set_topk_state: n = %lld, context has %d latents", (long long)n, c->n);
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(c->nfsf, in, (size_t)n * 8, hipMemcpyHostToDevice));
   return SAE_OK;
@@ -515,13 +558,8 @@ extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
 template <int AM, int BM_, class Epi>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   if (!g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0) {   // both output dimensions are multiples of 256
-    static bool attr256_set = false;
     auto kern256 = gemm256_bf16_kernel<AM, BM_, Epi>;
-    if (!attr256_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern256), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  G2_LDS_BYTES));
-      attr256_set = true;
-    }
+    LDS_ATTR(kern256, G2_LDS_BYTES, g_device);
     GemmArgs g2 = g;
     g2.nbm = g.nbm / 2;
     g2.nbn = g.nbn / 2;
@@ -529,13 +567,8 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return SAE_OK;
   }
-  static bool attr_set = false;
   auto kern = gemm_bf16_kernel<AM, BM_, Epi>;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GEMM_LDS_BYTES));
-    attr_set = true;
-  }
+  LDS_ATTR(kern, GEMM_LDS_BYTES, g_device);
   const int grid = g.nbm * g.nbn * g.splits;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, g, epi);
   HIP_TRY(hipGetLastError());
@@ -586,22 +619,12 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     a.c_rows = c->max_rows_p;
     // full workgroups (all 128 rows < M) run the mask-free instantiation; a ragged last workgroup the padded one
     const int full_wgs = (int)(M / FF_BM), all_wgs = (int)(Mp / FF_BM);
-    static bool attr_done = false;
-    if (!attr_done) {   // opt in to > 64 KiB dynamic LDS once per instantiation
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
-    }
+    // opt in to > 64 KiB dynamic LDS once per instantiation and device
+    LDS_ATTR((fwd_fused_d384_kernel<T, false>), 160 * 1024, g_device);
+    LDS_ATTR((fwd_fused_d384_kernel<T, true>), 160 * 1024, g_device);
     ev_begin(c, KID_FWD_FUSED, s);
     if (full_wgs > 0 && c->cfg.reserved[1] == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
-      static bool sattr = false;
-      if (!sattr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_fused_d384_kernel<T, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        sattr = true;
-      }
+      LDS_ATTR((fwd_fused_d384_kernel<T, false, true>), 160 * 1024, g_device);
       a.block_offset = 0;
       a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
       hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false, true>), dim3(full_wgs), dim3(256), lds, s, a);
@@ -671,15 +694,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       a.splits = splits;
       db_rows = splits;
       ev_begin(c, KID_BWD_FUSED, s);
-      {
-        static bool attr_set = false;
-        if (!attr_set) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_d384_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS_BYTES));
-          attr_set = true;
-        }
-        hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
-      }
+      LDS_ATTR(bwd_fused_d384_kernel, BF_LDS_BYTES, g_device);
+      hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
       ev_end(c, KID_BWD_FUSED, s);
       HIP_TRY(hipGetLastError());
     } else {
@@ -754,6 +770,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   HIP_TRY(hipGetLastError());
   c->last_M = M;
   c->last_M_p = Mp;
+  c->metrics_fresh = true;
   return SAE_OK;
 }
 
@@ -780,13 +797,13 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   int rc;
   ev_begin(c, KID_STEP_TOTAL, s);
 
-  // dead mask from num_frames_since_fired; the number of dead latents decides whether the AuxK branch runs
+  // dead mask from num_frames_since_fired.  Whether the AuxK branch runs (num_dead > 0, topkautoencoder.py:109) is decided
+  // ON THE DEVICE: the aux kernels are always enqueued and exit at once when tk[0] == 0, the weight-gradient GEMM drops its
+  // second K segment through GemmArgs::seg1_gate -- no device->host copy, no stream synchronisation in the step.
+  // validate() passes no dead_mask (train_sae.py:168-171): without a backward the AuxK branch is off.
   hipLaunchKernelGGL(dead_mask_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
                      c->tkf);
-  int num_dead = 0;
-  HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  const bool aux = num_dead > 0 && alpha != 0.f;
+  const bool aux = alpha != 0.f && backward;      // "possible": the device gates it on tk[0] > 0
 
   {
     const int64_t n8 = c->nW / 8;
@@ -835,10 +852,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     auto launch_decode = [&](auto np_tag) {
       constexpr int NP = decltype(np_tag)::value;
       hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b,
-                         bd, c->e, c->dh, c->e2_part, M, d, d_p, n_p, 0);
+                         bd, c->e, c->dh, c->e2_part, M, d, d_p, n_p, 0, (const int*)nullptr);
       if (aux)
         hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx,
-                           c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1);
+                           c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1, (const int*)c->tk);
     };
     if (d_p == 384) launch_decode(std::integral_constant<int, 3>{});
     else if (d_p == 768) launch_decode(std::integral_constant<int, 6>{});
@@ -853,7 +870,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     const int rpb = 256;
     const int nrb = (int)((Mp + rpb - 1) / rpb);
     hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
-                       c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0);
+                       c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0, c->tk);
     if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row
       ev_begin(c, KID_TK_DDENSE, s);
       HIP_TRY(hipMemsetAsync(c->dpre, 0, (size_t)Mp * n_p * 2, s));
@@ -862,21 +879,28 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         constexpr int NP = decltype(np_tag)::value;
         hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, c->de_b,
                            aux ? c->dh_b : (const bf16_t*)nullptr, c->dense, c->top_idx, k, c->aux_dense, c->aux_idx,
-                           c->k_aux_cap, c->Wd_b, c->dpre, c->dbe_fx, M, n_p);
+                           c->k_aux_cap, c->Wd_b, c->dpre, c->dbe_fx, M, n_p, c->tk);
       };
       if (d_p == 384) launch_dacts(std::integral_constant<int, 3>{});
       else if (d_p == 768) launch_dacts(std::integral_constant<int, 6>{});
       else launch_dacts(std::integral_constant<int, 10>{});
       ev_end(c, KID_TK_DDENSE, s);
     } else {  // dpre = [selected] (de W_dec^T)  (+ aux part) as a dense GEMM with a masking epilogue
+      // (A/B and test path only, reserved[3] == 1: its second launch is a host decision, so this path reads num_dead back)
+      int num_dead = 0;
+      if (aux) {
+        HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+      }
+      const bool aux_now = aux && num_dead > 0;
       GemmArgs g{};
       g.A0 = c->de_b; g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
       g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
       EpiTopkDpre e{};
-      e.sel = c->dense; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = 0; e.last = aux ? 0 : 1;
+      e.sel = c->dense; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = 0; e.last = aux_now ? 0 : 1;
       ev_begin(c, KID_TK_DDENSE, s);
       rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
-      if (!rc && aux) {
+      if (!rc && aux_now) {
         g.A0 = c->dh_b;
         e.sel = c->aux_dense; e.accumulate = 1; e.last = 1;
         rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
@@ -889,7 +913,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       GemmArgs g{};
       g.A0 = c->dense; g.B0 = c->de_b; g.A1 = c->aux_dense; g.B1 = c->dh_b; g.lda = n_p; g.ldb = d_p;
       g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = aux ? 2 * g.ktiles0 : g.ktiles0;
-      g.splits = splits > g.ktiles ? g.ktiles : splits;
+      g.seg1_gate = aux ? c->tk : nullptr;          // the AuxK pair joins only while latents are dead
+      g.splits = splits > g.ktiles0 ? g.ktiles0 : splits;
       EpiSlab e{};
       e.slab = g.splits > 1 ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
       ev_begin(c, KID_TK_DWD, s);
@@ -938,13 +963,14 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   HIP_TRY(hipGetLastError());
   c->last_M = M;
   c->last_M_p = Mp;
+  c->metrics_fresh = true;
   return SAE_OK;
 }
 
 static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream, bool backward) {
   if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
   if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   c->last_dtype = x_dtype;
   if (c->topk) {
@@ -972,7 +998,7 @@ extern "C" int sae_eval(sae_ctx* c, const void* x, int64_t M, int x_dtype, void*
 
 extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void* stream) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   c->step += 1;
   const double t = (double)c->step, b1 = c->cfg.beta1, b2 = c->cfg.beta2;
@@ -991,6 +1017,8 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   a.bc2_sqrt = (float)sqrt(bc2);
   a.step_size = (float)(lr / bc1);
   a.is_radam = c->cfg.optimizer == SAE_OPT_RADAM;
+  a.scale_metrics = c->metrics_fresh ? 1 : 0;
+  c->metrics_fresh = false;
   if (a.is_radam) {
     const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
     const double rho_t = rho_inf - 2.0 * t * pow(b2, t) / bc2;
@@ -1040,7 +1068,7 @@ extern "C" int sae_step(sae_ctx* c, const void* x, int64_t M, int x_dtype, doubl
 
 extern "C" int sae_read_metrics(sae_ctx* c, float out[SAE_NUM_METRICS], void* stream) {
   if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipMemcpyAsync(out, c->G + c->nparams, SAE_NUM_METRICS * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return SAE_OK;
@@ -1048,7 +1076,7 @@ extern "C" int sae_read_metrics(sae_ctx* c, float out[SAE_NUM_METRICS], void* st
 
 extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
   if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   const int64_t M = c->last_M;
   if (which == 0 || which == 1) {
@@ -1125,7 +1153,7 @@ extern "C" int sae_decode(sae_ctx* c, const void* latent, int latent_dtype, int6
   if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
   if (ld < c->n) return fail(SAE_ERR_INVALID, "row stride %lld < n_dict %d", (long long)ld, c->n);
   if (latent_dtype != SAE_DTYPE_F32 && latent_dtype != SAE_DTYPE_BF16) return fail(SAE_ERR_INVALID, "latent dtype must be f32 or bf16");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   const int d_p = c->d_p, n_p = c->n_p;
   const int64_t Mp = round_up(M, 128);
@@ -1172,7 +1200,7 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   if (!c || !out_host) return fail(SAE_ERR_INVALID, "null argument");
   if (capacity < c->n) return fail(SAE_ERR_INVALID, "capacity too small");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   int* bits = reinterpret_cast<int*>(c->db_part);   // scratch, free outside of a backward pass
   HIP_TRY(hipMemsetAsync(bits, 0, (size_t)c->n_p * 4, s));
@@ -1191,7 +1219,7 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
 
 extern "C" int sae_profile(sae_ctx* c, int level) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   c->profile = level;
   for (auto& r : c->ev) r.n = 0;
@@ -1200,7 +1228,7 @@ extern "C" int sae_profile(sae_ctx* c, int level) {
 
 extern "C" int sae_kernel_times(sae_ctx* c, float* ms_sum, int32_t* launches, int n) {
   if (!c || !ms_sum || !launches) return fail(SAE_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(c->cfg.device_id));
+  USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   for (int k = 0; k < n; ++k) {
     ms_sum[k] = 0.f;

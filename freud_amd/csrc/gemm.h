@@ -28,6 +28,7 @@ struct GemmArgs {
   int ktiles0;       // 64-wide K tiles in segment 0
   int ktiles;        // total K tiles (segment 0 + segment 1)
   int splits;        // split-K factor (grid = nbm*nbn*splits)
+  const int* seg1_gate;  // device flag (may be null): *seg1_gate == 0 drops K segment 1 (the TopK AuxK pair when no latent is dead)
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   id -= split * (g.nbm * g.nbn);
   int bm, bn;
   tile_coords(id, g.nbm, g.nbn, bm, bn);
-  const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
-  const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
+  const int ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
+  const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
+  const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
 
   f32x16 acc[2][2];
 #pragma unroll

@@ -53,8 +53,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   id -= split * (g.nbm * g.nbn);
   int bm, bn;
   tile_coords(id, g.nbm, g.nbn, bm, bn);
-  const int kt_begin = (int)((int64_t)g.ktiles * split / g.splits);
-  const int kt_end = (int)((int64_t)g.ktiles * (split + 1) / g.splits);
+  const int ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
+  const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
+  const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
 
   f32x16 acc[4][2];
 #pragma unroll

@@ -447,6 +447,7 @@ struct OptArgs {
   float rect;               // RAdam rectification term (valid if rectify)
   int rectify;              // RAdam: rho_t > 5
   int is_radam;
+  int scale_metrics;        // 1: the loss scalars in the gradient buffer are a data-parallel SUM that has not been averaged yet
 };
 
 // clip_grad_norm_ (coef = min(1, thresh/(norm+1e-6))) fused with the torch single-tensor
@@ -465,10 +466,11 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
   const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     metrics[3] = total;
-    if (a.grad_scale != 1.0f) {   // after a data-parallel sum the loss scalars become means over ranks
-      metrics[0] *= a.grad_scale;
-      metrics[1] *= a.grad_scale;
+    if (a.scale_metrics && a.grad_scale != 1.0f) {   // after a data-parallel sum the loss scalars become means over ranks
+      metrics[0] *= a.grad_scale;                      // (the host clears scale_metrics after the first optimizer step
+      metrics[1] *= a.grad_scale;                      // that follows a forward_backward: a second call must not rescale)
       metrics[2] *= a.grad_scale;
+      metrics[5] *= a.grad_scale;                      // TopK dead_pct rides in the same summed buffer
     }
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {

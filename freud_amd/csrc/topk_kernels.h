@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
                                                            int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                            const unsigned char* __restrict__ dead, const int* __restrict__ k_ptr,
                                                            int k_fixed, int kcap, int n, int n_p) {
+  if (k_ptr && *k_ptr <= 0) return;     // AuxK pass without dead latents: nothing downstream reads its outputs
   __shared__ int hist[256];
-  __shared__ int sel_hi, need, sel_lo, ngt, ntie;
+  __shared__ int sel_hi, need, sel_lo, ntie;
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
   const int k = k_ptr ? *k_ptr : k_fixed;
@@ -170,7 +171,6 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
     if (b < 0) b = 0;
     sel_lo = b;
     ntie = need - acc;   // how many elements equal to thr to take
-    ngt = 0;
   }
   __syncthreads();
   const int thr = (hi << 8) | sel_lo;
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
   const int k_req = k_ptr ? *k_ptr : k_fixed;
+  if (k_ptr && k_req <= 0) return;      // AuxK pass without dead latents: nothing downstream reads its outputs (block-uniform)
   const int nvec = n_p >> 3;                       // 16-byte vectors in the row
   const u32x4* src = reinterpret_cast<const u32x4*>(pre + row * n_p);
   u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
                                                            const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
                                                            const float* __restrict__ b_dec, float* __restrict__ e,
                                                            float* __restrict__ dh, float* __restrict__ part, int64_t M, int d,
-                                                           int d_p, int n_p, int aux) {
+                                                           int d_p, int n_p, int aux, const int* __restrict__ gate) {
+  if (gate && *gate <= 0) return;                // AuxK pass while no latent is dead (decided on the device: no host sync)
   constexpr int MAXP = NPAIR > 0 ? NPAIR : 12;   // column pairs per lane: d_p <= 64 * 2 * MAXP
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
@@ -521,7 +523,9 @@ __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __rest
 __global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ e, const float* __restrict__ dh,
                                                        const float* __restrict__ tkf, bf16_t* __restrict__ de_b,
                                                        bf16_t* __restrict__ dh_b, float* __restrict__ dbd_part, int64_t Mp,
-                                                       int d_p, int rows_per_block, int use_aux) {
+                                                       int d_p, int rows_per_block, int aux_possible,
+                                                       const int* __restrict__ tk) {
+  const int use_aux = aux_possible && tk[0] > 0;
   // grid (d_p / 256, ceil(Mp / rows_per_block)); thread = one column, fixed row order
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
@@ -561,7 +565,8 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restric
                                                           const bf16_t* __restrict__ dense, const int* __restrict__ idx, int k,
                                                           const bf16_t* __restrict__ aux_dense, const int* __restrict__ aux_idx,
                                                           int kaux_cap, const bf16_t* __restrict__ Wd, bf16_t* __restrict__ dpre,
-                                                          long long* __restrict__ dbe_fx, int64_t M, int n_p) {
+                                                          long long* __restrict__ dbe_fx, int64_t M, int n_p,
+                                                          const int* __restrict__ tk) {
   constexpr int d_p = 128 * NPAIR;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restric
   const int c0 = lane * 2 * NPAIR;
   for (int pass = 0; pass < 2; ++pass) {
     const bf16_t* gsrc = pass == 0 ? de_b : dh_b;
-    if (!gsrc) break;
+    if (!gsrc || (pass == 1 && tk[0] <= 0)) break;      // the AuxK pass needs dead latents (device-side decision)
     const bf16_t* rd = (pass == 0 ? dense : aux_dense) + row * n_p;
     const int kcap = pass == 0 ? k : kaux_cap;
     const int* ri = (pass == 0 ? idx : aux_idx) + row * kcap;

@@ -125,6 +125,15 @@ def _np_f32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
 
+def _shaped(name: str, a, shape) -> np.ndarray:
+    """fp32 contiguous copy of `a` with exactly `shape` elements (the C side copies prod(shape) floats from the pointer:
+    a short buffer would be a host heap over-read)."""
+    arr = _np_f32(a)
+    if arr.size != int(np.prod(shape)):
+        raise EngineError(f"{name}: got {arr.shape} ({arr.size} elements), the engine expects {tuple(shape)}")
+    return arr.reshape(shape)
+
+
 class SaeEngine:
     """One engine context = one SAE on one GPU.  Thin, typed wrapper over the C ABI."""
 
@@ -174,7 +183,7 @@ class SaeEngine:
                 "W_dec": (self.n, self.d), "b_dec": (self.d,)}   # topkautoencoder.py:62-70
 
     def set_params(self, params: Dict[str, np.ndarray]) -> None:
-        arrs = [_np_f32(params[k]).reshape(shape) for k, shape in self.param_shapes().items()]
+        arrs = [_shaped(k, params[k], shape) for k, shape in self.param_shapes().items()]
         ptrs = [a.ctypes.data_as(C.c_void_p) for a in arrs] + [None] * (4 - len(arrs))
         _check(self._lib.sae_set_params(self._ctx, *ptrs, 0))
 
@@ -185,9 +194,9 @@ class SaeEngine:
         return out
 
     def set_opt_state(self, step: int, exp_avg: Dict[str, np.ndarray], exp_avg_sq: Dict[str, np.ndarray]) -> None:
-        keys = list(self.param_shapes())
-        a = [_np_f32(exp_avg[k]) for k in keys]
-        b = [_np_f32(exp_avg_sq[k]) for k in keys]
+        shapes = self.param_shapes()
+        a = [_shaped(f"exp_avg[{k}]", exp_avg[k], s) for k, s in shapes.items()]
+        b = [_shaped(f"exp_avg_sq[{k}]", exp_avg_sq[k], s) for k, s in shapes.items()]
         pa = (C.c_void_p * 4)(*([x.ctypes.data for x in a] + [None] * (4 - len(a))))
         pb = (C.c_void_p * 4)(*([x.ctypes.data for x in b] + [None] * (4 - len(b))))
         _check(self._lib.sae_set_opt_state(self._ctx, int(step), pa, pb, 0))

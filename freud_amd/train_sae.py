@@ -144,6 +144,12 @@ def load_checkpoint(state: dict, load_path: str, device=None) -> None:
     eng.set_params({k: v.detach().cpu().numpy() for k, v in checkpoint["model"].items()})
     ost = checkpoint["optimizer"]["state"]
     if len(ost) > 0:
+        shapes = eng.param_shapes()
+        for i, k in enumerate(order):           # a mis-indexed state (wrong parameter order) must not be copied blindly
+            for mk in ("exp_avg", "exp_avg_sq"):
+                if tuple(ost[i][mk].shape) != tuple(shapes[k]):
+                    raise ValueError(f"checkpoint optimizer state[{i}][{mk}] has shape {tuple(ost[i][mk].shape)}, "
+                                     f"parameter {k} has {tuple(shapes[k])}")
         m1 = {k: ost[i]["exp_avg"].numpy() for i, k in enumerate(order)}
         m2 = {k: ost[i]["exp_avg_sq"].numpy() for i, k in enumerate(order)}
         eng.set_opt_state(int(float(ost[0]["step"])), m1, m2)
@@ -330,7 +336,9 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             W_dec /= torch.norm(W_dec, dim=1, keepdim=True) + eps
         init = {"encoder.weight": enc.weight.detach().numpy(), "encoder.bias": enc.bias.detach().numpy(),
                 "W_dec": W_dec.numpy(), "b_dec": np.zeros(feat_dim, np.float32)}
-        param_order = ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]
+        # nn.Module.parameters() yields the module's own parameters (W_dec, b_dec) before its children's (encoder.*):
+        # that order is the optimizer's parameter indexing (state[0] = W_dec ... state[3] = encoder.bias)
+        param_order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
         state_dict_order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
         eng.set_topk_options(float(autoencoder_config["dead_feature_threshold"]), T)   # raw key (:438); T for x.mean(0)
     eng.set_params(init)

@@ -358,8 +358,9 @@ def topk_train_step(x3: torch.Tensor, P: Dict[str, torch.Tensor], st: OptState, 
                        dead_mask, auxk_alpha, autocast)
     g = topk_backward(x3, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], fwd,
                       auxk_alpha, autocast)
-    order = ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]          # nn.Module.parameters() order
-    raw = [g["W_enc"], g["b_enc"], g["W_dec"], g["b_dec"]]
+    # nn.Module.parameters() order: the module's own parameters (W_dec, b_dec) come before its children's (encoder.*)
+    order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+    raw = [g["W_dec"], g["b_dec"], g["W_enc"], g["b_enc"]]
     gnorm, clipped = clip_grad_norm(raw, clip_thresh)
     params = {kk: P[kk] for kk in order}
     grads = dict(zip(order, clipped))

@@ -99,7 +99,7 @@ class OracleEngine:
             n = int(np.prod(s))
             grads[k] = (self.flat[off:off + n] * grad_scale).reshape(s).clone()
             off += n
-        order = ["encoder_bias", "decoder.weight"] if self.variant == "l1" else ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]
+        order = ["encoder_bias", "decoder.weight"] if self.variant == "l1" else ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
         gn, clipped = O.clip_grad_norm([grads[k] for k in order], self.clip_thresh)
         cg = dict(zip(order, clipped))
         params = {k: self.P[k] for k in order}

@@ -168,3 +168,45 @@ def test_topk_train_loop_matches_reference(tmp_path, golden_dir):
     assert list(ck["model"].keys()) == meta["model_keys"]
     for k in meta["model_keys"]:
         torch.testing.assert_close(ck["model"][k], torch.tensor(z[f"model__{k}"]), rtol=0, atol=5e-6)
+    # optimizer state is indexed in model.parameters() order: W_dec, b_dec, encoder.weight, encoder.bias
+    order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+    for pid, key in enumerate(order):
+        st = ck["optimizer"]["state"][pid]
+        assert tuple(st["exp_avg"].shape) == tuple(z[f"model__{key}"].shape) == tuple(z[f"opt__{pid}__exp_avg"].shape), key
+        assert float(st["step"]) == float(z[f"opt__{pid}__step"])
+        # (the oracle's TopK gradients agree with the reference to bf16 summation order, not bitwise)
+        ref1, ref2 = z[f"opt__{pid}__exp_avg"], z[f"opt__{pid}__exp_avg_sq"]
+        np.testing.assert_allclose(st["exp_avg"].numpy(), ref1, rtol=1e-2, atol=1e-3 * np.abs(ref1).max())
+        np.testing.assert_allclose(st["exp_avg_sq"].numpy(), ref2, rtol=2e-2, atol=1e-3 * np.abs(ref2).max())
+
+
+def test_reference_topk_checkpoint_loads_by_parameter_order(tmp_path, golden_dir):
+    """A checkpoint with the reference's own layout (state[0] = W_dec [n,d], state[1] = b_dec [d], state[2] =
+    encoder.weight, state[3] = encoder.bias; rebuilt from the arrays the reference's train() saved) resumes into the
+    engine with every moment on the right parameter; a mis-ordered one is refused, not copied."""
+    from freud_amd.train_sae import load_checkpoint
+    z, meta, cfg = _setup(tmp_path, golden_dir, "trainloop_topk")
+    d, n = meta["d"], z["model__W_dec"].shape[0]
+    order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+    ck = {"model": {k: torch.tensor(z[f"model__{k}"]) for k in meta["model_keys"]},
+          "optimizer": {"state": {pid: {"step": torch.tensor(float(z[f"opt__{pid}__step"])),
+                                        "exp_avg": torch.tensor(z[f"opt__{pid}__exp_avg"]),
+                                        "exp_avg_sq": torch.tensor(z[f"opt__{pid}__exp_avg_sq"])} for pid in range(4)},
+                        "param_groups": meta["opt_param_groups"]},
+          "scheduler": {}, "step": meta["step"], "best_val_loss": meta["best_val_loss"], "hparams": meta["hparams"]}
+    path = os.path.join(str(tmp_path), "ref_step7.pth")
+    torch.save(ck, path)
+    eng = OracleEngine("topk", d, n, 64, optimizer="adam", k=4)
+    state = {"engine": eng, "param_order": order}
+    load_checkpoint(state, path)
+    step, m1, m2 = eng.get_opt_state()
+    assert step == 7 and state["step"] == 7
+    for pid, key in enumerate(order):
+        assert np.array_equal(m1[key], z[f"opt__{pid}__exp_avg"]), key
+        assert np.array_equal(m2[key], z[f"opt__{pid}__exp_avg_sq"]), key
+        assert np.array_equal(eng.get_params()[key], z[f"model__{key}"]), key
+    bad = {"engine": OracleEngine("topk", d, n, 64, optimizer="adam", k=4),
+           "param_order": ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]}
+    with pytest.raises(ValueError, match="optimizer state"):
+        load_checkpoint(bad, path)
+
