@@ -126,7 +126,7 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
 # --------------------------------------------------------------------------------------
 def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_dec: torch.Tensor,
                  b_dec: torch.Tensor, k: int, dead_mask: Optional[torch.Tensor] = None,
-                 auxk_alpha: float = 0.0, autocast: bool = True) -> Dict[str, torch.Tensor]:
+                 auxk_alpha: float = 0.0, autocast: bool = True, multi_topk: bool = False) -> Dict[str, torch.Tensor]:
     """src/models/topkautoencoder.py:72-151 on x3 = [B, T, d] (B matters for x.mean(0), :104).
 
       pre   = relu( (x - b_dec) @ W_enc^T + b_enc )                   (:72-77)
@@ -134,6 +134,8 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
       x_hat = scatter(top) @ W_dec + b_dec                            (:15-18, :87-91)
       fvu   = sum (x_hat - x)^2 / sum (x - mean_B x)^2                (:104-106, :131-132)
       auxk  = scale * sum (decode(top-k_aux dead) - e)^2 / total_var  (:109-129) times alpha (:146)
+      multi = sum (decode(top-4k) - x)^2 / total_var  if cfg.multi_topk   (:134-140); the returned sae_out / encoded
+              are then the 4k ones (the names are re-bound at :135-136), which is what did_fire sees (train_sae.py:442)
     autocast: ``encoder`` is a Linear -> bf16 addmm (bias included, output bf16); relu keeps bf16;
     top_acts bf16; scatter buffer bf16; decode matmul bf16 -> + b_dec (fp32) -> fp32.
     """
@@ -180,7 +182,16 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
         auxk = torch.tensor(0.0)
     out["fvu"] = (e ** 2).sum() / total_variance
     out["auxk_loss"] = auxk * auxk_alpha
-    out["multi_topk_fvu"] = torch.tensor(0.0)
+    if multi_topk:
+        m_acts, m_idx = pre.topk(4 * k, dim=-1, sorted=False)
+        x_hat_m, m_dense = decode(m_acts, m_idx)
+        e_m = x_hat_m - x
+        out["multi_topk_fvu"] = (e_m ** 2).sum() / total_variance
+        out.update({"multi_acts": m_acts, "multi_indices": m_idx, "multi_dense": m_dense, "e_multi": e_m,
+                    "fire_indices": m_idx, "sae_out": x_hat_m})
+    else:
+        out["multi_topk_fvu"] = torch.tensor(0.0)
+        out.update({"fire_indices": top_idx, "sae_out": x_hat})
     out["mse"] = (e ** 2).mean()
     return out
 
@@ -188,7 +199,7 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
 def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_dec: torch.Tensor,
                   b_dec: torch.Tensor, fwd: Dict[str, torch.Tensor], auxk_alpha: float = 0.0,
                   autocast: bool = True) -> Dict[str, torch.Tensor]:
-    """Backward of loss = fvu + auxk_loss (+ multi_topk/8 = 0) (train_sae.py:442), fp32 or
+    """Backward of loss = fvu + auxk_loss + multi_topk_fvu/8 (train_sae.py:442), fp32 or
     bf16-autocast rounding.  Gradients w.r.t. W_enc [n,d], b_enc [n], W_dec [n,d], b_dec [d].
 
     e is *not* detached in the AuxK term (topkautoencoder.py:127), so
@@ -216,25 +227,32 @@ def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_
             ddense = dy @ W_dec.t()
         return dW, ddense, dy.sum(0)
 
-    dW_dec, ddense, db_dec = dec_bwd(de, fwd["dense"])
-    sel = torch.zeros_like(ddense, dtype=torch.bool).scatter_(1, fwd["top_indices"], True)
-    dpre = torch.where(sel, ddense, torch.zeros_like(ddense))
+    # Three decodes can feed W_dec, b_dec and `pre`: autograd runs them in reverse forward order (multi-TopK, AuxK, main)
+    # and ACCUMULATES each gradient into the buffer of the shared tensor: in bf16 for the bf16 `pre` (one rounding per
+    # addition, in that order); in fp32 for W_dec -- decode() matmuls with the VIEW W_dec.mT.mT, which autocast casts
+    # anew for every decode (only leaf parameters are cached), so each bf16 GEMM output is cast to fp32 before the sum.
+    terms = []
+    if "e_multi" in fwd:                                                 # + multi_topk_fvu / 8 (train_sae.py:442)
+        terms.append(((2.0 / 8.0) * fwd["e_multi"] / tv, fwd["multi_dense"], fwd["multi_indices"]))
     if have_aux:
-        dW2, ddense2, db2 = dec_bwd(de_hat, fwd["aux_dense"])
-        sel2 = torch.zeros_like(ddense2, dtype=torch.bool).scatter_(1, fwd["aux_indices"], True)
-        if autocast:
-            dW_dec = (dW_dec.to(BF16) + dW2.to(BF16)).to(torch.float32)
-        else:
-            dW_dec = dW_dec + dW2
-        db_dec = db_dec + db2
-        dpre = dpre + torch.where(sel2, ddense2, torch.zeros_like(ddense2))
+        terms.append((de_hat, fwd["aux_dense"], fwd["aux_indices"]))
+    terms.append((de, fwd["dense"], fwd["top_indices"]))
+    rnd = _r if autocast else (lambda t: t)
+    dW_dec = db_dec = dpre = None
+    for dy, dense_t, idx_t in terms:
+        dW_t, ddense_t, db_t = dec_bwd(dy, dense_t)
+        sel_t = torch.zeros_like(ddense_t, dtype=torch.bool).scatter_(1, idx_t, True)
+        dpre_t = torch.where(sel_t, ddense_t, torch.zeros_like(ddense_t))
+        dW_dec = dW_t if dW_dec is None else dW_dec + dW_t
+        db_dec = db_t if db_dec is None else db_dec + db_t
+        dpre = dpre_t if dpre is None else rnd(dpre + dpre_t)
     dpre = dpre * (fwd["pre"].to(torch.float32) > 0)
     sae_in = x - b_dec
     if autocast:
         dpb = dpre.to(BF16)
         dW_enc = (dpb.t() @ sae_in.to(BF16)).to(torch.float32)           # [n, d]
         dsae_in = (dpb @ W_enc.to(BF16)).to(torch.float32)               # [M, d]
-        db_enc = dpb.to(torch.float32).sum(0)
+        db_enc = _r(dpb.to(torch.float32).sum(0))                        # Linear's bias is a bf16 cast: bf16 gradient
     else:
         dW_enc = dpre.t() @ sae_in
         dsae_in = dpre @ W_enc
@@ -351,11 +369,11 @@ def l1_train_step(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, st: OptStat
 def topk_train_step(x3: torch.Tensor, P: Dict[str, torch.Tensor], st: OptState, *, k: int, lr: float,
                     clip_thresh: float, dead_mask: Optional[torch.Tensor] = None, auxk_alpha: float = 0.0,
                     optimizer: str = "adam", weight_decay: float = 0.0,
-                    autocast: bool = True) -> Dict[str, torch.Tensor]:
+                    autocast: bool = True, multi_topk: bool = False) -> Dict[str, torch.Tensor]:
     """One iteration of train_sae.py:429-451 for the TopK variant.  P holds the reference's
     state_dict keys W_dec, b_dec, encoder.weight, encoder.bias (updated in place)."""
     fwd = topk_forward(x3, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k,
-                       dead_mask, auxk_alpha, autocast)
+                       dead_mask, auxk_alpha, autocast, multi_topk)
     g = topk_backward(x3, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], fwd,
                       auxk_alpha, autocast)
     # nn.Module.parameters() order: the module's own parameters (W_dec, b_dec) come before its children's (encoder.*)
@@ -369,4 +387,5 @@ def topk_train_step(x3: torch.Tensor, P: Dict[str, torch.Tensor], st: OptState, 
     else:
         adam_step(params, grads, st, lr)
     return {"fvu": fwd["fvu"], "auxk_loss": fwd["auxk_loss"], "mse": fwd["mse"], "grad_norm": gnorm,
+            "multi_topk_fvu": fwd["multi_topk_fvu"], "fire_indices": fwd["fire_indices"],
             "top_indices": fwd["top_indices"], "top_acts": fwd["top_acts"], "grads": dict(zip(order, raw))}

@@ -177,7 +177,7 @@ def run_l1_case(name, d, n, B, T, steps, optimizer, scheduler, lr, recon_alpha, 
     print(f"[{name}] l1={rec['l1']} recon={rec['recon']} gnorm={rec['gnorm']}")
 
 
-def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_threshold, warmup):
+def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_threshold, warmup, multi_topk=False):
     from src.models.config import TopKAutoEncoderConfig
     from src.models.topkautoencoder import TopKAutoEncoder
     from torch.amp import autocast
@@ -186,14 +186,14 @@ def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_thresho
 
     torch.manual_seed(seed)
     cfg = TopKAutoEncoderConfig.from_dict({"n_dict_components": n, "k": k, "auxk_alpha": auxk_alpha,
-                                           "normalize_decoder": True, "multi_topk": False})
+                                           "normalize_decoder": True, "multi_topk": multi_topk})
     model = TopKAutoEncoder(activation_size=d, cfg=cfg)
     sd0 = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
     opt = Adam(model.parameters(), lr=lr)
     sch = get_linear_schedule_with_warmup(opt, num_warmup_steps=warmup, num_training_steps=steps)
     xs = make_batches(seed + 1, steps, B, T, d, plant=False)
     nfsf = torch.zeros(n, dtype=torch.long)
-    rec = {"fvu": [], "auxk": [], "gnorm": [], "lr_used": [], "mse": [], "num_dead": []}
+    rec = {"fvu": [], "auxk": [], "gnorm": [], "lr_used": [], "mse": [], "num_dead": [], "multi": []}
     first = {}
     for i, x in enumerate(xs):
         did_fire = torch.zeros(n, dtype=torch.bool)
@@ -218,6 +218,7 @@ def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_thresho
         sch.step()
         rec["fvu"].append(out.fvu.item())
         rec["auxk"].append(out.auxk_loss.item())
+        rec["multi"].append(out.multi_topk_fvu.item())
         rec["mse"].append(mse.item())
         rec["gnorm"].append(gn.item())
         rec["num_dead"].append(int(dead_mask.sum()))
@@ -234,8 +235,9 @@ def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_thresho
         meta=json.dumps({"variant": "topk", "d": d, "n": n, "k": k, "B": B, "T": T, "steps": steps, "lr": lr,
                          "seed": seed, "auxk_alpha": auxk_alpha, "dead_feature_threshold": dead_threshold,
                          "num_warmup_steps": warmup, "clip_thresh": 1.0, "optimizer": "adam",
-                         "scheduler": "linear"}),
+                         "scheduler": "linear", "multi_topk": multi_topk}),
         x=torch.stack(xs).numpy(), fvu=np.array(rec["fvu"]), auxk=np.array(rec["auxk"]), mse=np.array(rec["mse"]),
+        multi=np.array(rec["multi"]),
         gnorm=np.array(rec["gnorm"]), lr_used=np.array(rec["lr_used"]), num_dead=np.array(rec["num_dead"]),
         nfsf_final=nfsf.numpy(), **arrays)
     print(f"[{name}] fvu={rec['fvu']} auxk={rec['auxk']} dead={rec['num_dead']}")
@@ -337,6 +339,10 @@ def main():
     SummaryWriter = install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "multi":      # only the fixture added in round 2 (the others are unchanged)
+        run_topk_case("topk_multi_d32", d=32, n=256, k=8, B=2, T=16, steps=5, lr=1e-3, seed=6,
+                      auxk_alpha=0.03125, dead_threshold=40.0, warmup=2, multi_topk=True)
+        return
     run_l1_case("l1_radam_cosine_d16", d=16, n=64, B=4, T=8, steps=5, optimizer="radam", scheduler="cosine",
                 lr=4e-4, recon_alpha=1e4, seed=0, total_steps=100)
     run_l1_case("l1_adam_linear_d48", d=48, n=200, B=3, T=20, steps=6, optimizer="adam", scheduler="linear",
@@ -349,6 +355,8 @@ def main():
                   auxk_alpha=0.03125, dead_threshold=40.0, warmup=2)
     run_topk_case("topk_adam_linear_d64", d=64, n=512, k=16, B=2, T=32, steps=4, lr=1e-4, seed=5,
                   auxk_alpha=0.0, dead_threshold=1e6, warmup=2)
+    run_topk_case("topk_multi_d32", d=32, n=256, k=8, B=2, T=16, steps=5, lr=1e-3, seed=6,
+                  auxk_alpha=0.03125, dead_threshold=40.0, warmup=2, multi_topk=True)
     run_train_loop_case(SummaryWriter, "trainloop_l1", "l1")
     run_train_loop_case(SummaryWriter, "trainloop_topk", "topk")
     run_sampler_case()
