@@ -14,7 +14,7 @@
 #include "l1_kernels.h"
 #include "gemm256.h"
 
-static bool g_force_gemm128 = false;   // sae_config.reserved[2] == 1: keep every GEMM on the 128x128 kernel (A/B timing, tests)
+static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
@@ -130,6 +130,12 @@ struct sae_ctx {
   long long* nfsf = nullptr;
   long long* dbe_fx = nullptr;  // [n_p] fixed-point d b_enc accumulator of the sparse d-activation kernel
   bool topk_sparse_da = false;  // sparse d pre-activations (topk_dacts_kernel) instead of the dense ddense GEMM + mask
+  // cfg.multi_topk (topkautoencoder.py:134-140): a second selection of 4k latents, its decode and its FVU / 8 in the loss
+  bool multi = false;
+  int k4 = 0;
+  bf16_t *multi_dense = nullptr, *dm_b = nullptr;
+  int* multi_idx = nullptr;
+  float *em = nullptr, *m2_part = nullptr;
   unsigned char* dead = nullptr;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
@@ -211,7 +217,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   if (c->k_aux_cap > 1024) return fail(SAE_ERR_INVALID, "topk: d_model/2 = %d aux latents exceed the 1024 supported", c->k_aux_cap);
   c->nparams = 2 * c->nW + c->n_p + c->d_p;
   const int64_t ntail = SAE_NUM_METRICS + c->n_p;       // metrics + did_fire flags ride in the all-reduced buffer
-  g_force_gemm128 = c->cfg.reserved[2] == 1;
+  g_force_gemm128 = c->cfg.force_gemm128 == 1;
   const int splits = choose_splits(c->n_p / 128, c->d_p / 128, Mp / 64);
   c->dw_splits = splits;
 #define TALLOC(ptr, bytes)                                                                                   \
@@ -247,10 +253,20 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->tv_part, ((Mp * c->d + 255) / 256 + 1) * 8);
   TALLOC(c->nfsf, (size_t)c->n_p * 8);
   TALLOC(c->dbe_fx, (size_t)c->n_p * 8);
-  // reserved[3] == 1 keeps the dense ddense GEMM (tests cover both)
-  c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.reserved[3] != 1;
+  // topk_dense_backward keeps the dense ddense GEMM (tests cover both)
+  c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.topk_dense_backward != 1;
   TALLOC(c->dead, c->n_p);
-  TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * c->nW * 4);
+  c->multi = c->cfg.multi_topk != 0;
+  c->k4 = 4 * c->k;
+  if (c->multi) {
+    TALLOC(c->multi_dense, Mp * c->n_p * 2);
+    TALLOC(c->multi_idx, Mp * c->k4 * 4);
+    TALLOC(c->em, Mp * c->d_p * 4);
+    TALLOC(c->dm_b, Mp * c->d_p * 2);
+    TALLOC(c->m2_part, Mp * 4);
+  }
+  // the multi-TopK weight gradient is a second GEMM launch into its own split-K slabs
+  TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * (c->multi ? 2 : 1) * c->nW * 4);
   TALLOC(c->gn_part, 1024 * 8);
 #undef TALLOC
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
@@ -270,7 +286,8 @@ extern "C" void sae_destroy(sae_ctx* c) {
   void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
-                  c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx};
+                  c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
+                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->ev_init)
@@ -289,6 +306,10 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     return fail(SAE_ERR_INVALID, "Invalid autoencoder variant: %d, must be 'l1' or 'topk'", cfg->variant);
   if (cfg->variant == SAE_VARIANT_TOPK && (cfg->k <= 0 || cfg->k > cfg->n_dict || cfg->k > 1024))
     return fail(SAE_ERR_INVALID, "topk: k=%d must be in [1, min(n_dict, 1024)]", cfg->k);
+  if (cfg->variant == SAE_VARIANT_TOPK && cfg->multi_topk && (4 * cfg->k > cfg->n_dict || 4 * cfg->k > 1024))
+    return fail(SAE_ERR_INVALID, "topk: multi_topk selects 4k = %d latents, must be <= min(n_dict, 1024)", 4 * cfg->k);
+  if (cfg->variant != SAE_VARIANT_TOPK && cfg->multi_topk)
+    return fail(SAE_ERR_INVALID, "multi_topk is a TopK option");
   if (cfg->variant == SAE_VARIANT_TOPK && cfg->d_model > 1536)
     return fail(SAE_ERR_INVALID, "topk: d_model=%d above the 1536 the sparse decoder is built for", cfg->d_model);
   if (cfg->d_model <= 0 || cfg->n_dict <= 0 || cfg->max_rows <= 0)
@@ -321,16 +342,16 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     *out = c;
     return SAE_OK;
   }
-  g_force_gemm128 = cfg->reserved[2] == 1;
+  g_force_gemm128 = cfg->force_gemm128 == 1;
   c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
   // with a gradient-ready hook the weight-gradient GEMM is issued in 512-row chunks (d_p >= 1024 only: smaller
   // models finish their gradient in one piece); the chunk's split-K factor keeps its launch rounds full
   c->dw_chunk_rows = c->d_p >= 1024 ? 512 : c->d_p;
   c->dw_chunk_splits = choose_splits(c->dw_chunk_rows / 128, c->n_p / 128, 2 * Mp / 64);
-  // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; reserved[0] = 1 forces the
+  // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; force_generic forces the
   // generic three-GEMM path (used by the tests to cover both)
-  c->use_fused_bwd = (c->d_p == BF_D) && cfg->reserved[0] != 1;
-  c->use_fused_fwd = (c->d_p == FF_D) && cfg->reserved[0] != 1 && (FF_FIXED_LDS + (int64_t)(c->n_p + FF_BN) * 4 <= 160 * 1024);
+  c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1;
+  c->use_fused_fwd = (c->d_p == FF_D) && cfg->force_generic != 1 && (FF_FIXED_LDS + (int64_t)(c->n_p + FF_BN) * 4 <= 160 * 1024);
   {
     const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
     int sp = 256 / ntiles;
@@ -623,7 +644,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     LDS_ATTR((fwd_fused_d384_kernel<T, false>), 160 * 1024, g_device);
     LDS_ATTR((fwd_fused_d384_kernel<T, true>), 160 * 1024, g_device);
     ev_begin(c, KID_FWD_FUSED, s);
-    if (full_wgs > 0 && c->cfg.reserved[1] == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
+    if (full_wgs > 0 && c->cfg.debug_flags == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
       LDS_ATTR((fwd_fused_d384_kernel<T, false, true>), 160 * 1024, g_device);
       a.block_offset = 0;
       a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
@@ -688,7 +709,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       a.unscaled = c->use_fused_fwd ? 1 : 0;
       a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
       // diagnostic clock stamps go to the second half of the (unused on this path) dpre buffer
-      a.clk = c->cfg.reserved[1] == 66 ? reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16) : nullptr;
+      a.clk = c->cfg.debug_flags == 66 ? reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16) : nullptr;
       splits = c->bwd_splits;
       if (splits > a.steps_total) splits = a.steps_total;
       a.splits = splits;
@@ -843,7 +864,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire, dead_mask,
                            k_ptr, k_fixed, kcap, n, n_p);
     };
-    launch_select(c->dense, c->top_idx, did_fire, nullptr, nullptr, k, k);
+    // did_fire follows out.encoded.top_indices (train_sae.py:442), which forward() re-binds to the 4k selection when
+    // cfg.multi_topk is set (topkautoencoder.py:135)
+    launch_select(c->dense, c->top_idx, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
+    if (c->multi) launch_select(c->multi_dense, c->multi_idx, did_fire, nullptr, nullptr, c->k4, c->k4);
     if (aux) launch_select(c->aux_dense, c->aux_idx, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
   }
   ev_end(c, KID_TK_SELECT, s);
@@ -856,6 +880,9 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (aux)
         hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx,
                            c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1, (const int*)c->tk);
+      if (c->multi)     // e_multi = decode(top-4k) - x into its own residual buffer
+        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->multi_dense, c->multi_idx,
+                           c->k4, c->Wd_b, bd, c->em, c->dh, c->m2_part, M, d, d_p, n_p, 0, (const int*)nullptr);
     };
     if (d_p == 384) launch_decode(std::integral_constant<int, 3>{});
     else if (d_p == 768) launch_decode(std::integral_constant<int, 6>{});
@@ -864,29 +891,33 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   }
   const int64_t TD = T_rows * d;
   hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
-                     aux ? c->a2_part : (const float*)nullptr, Mp, M, d, alpha, c->tk, c->tkf, metrics, (float)n);
+                     aux ? c->a2_part : (const float*)nullptr, c->multi ? c->m2_part : (const float*)nullptr, Mp, M, d, alpha,
+                     c->tk, c->tkf, metrics, (float)n);
   ev_end(c, KID_TK_DECODE, s);
   if (backward) {
     const int rpb = 256;
     const int nrb = (int)((Mp + rpb - 1) / rpb);
     hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
-                       c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0, c->tk);
+                       c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0, c->tk, c->multi ? c->em : (const float*)nullptr, c->dm_b);
     if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row
       ev_begin(c, KID_TK_DDENSE, s);
       HIP_TRY(hipMemsetAsync(c->dpre, 0, (size_t)Mp * n_p * 2, s));
       HIP_TRY(hipMemsetAsync(c->dbe_fx, 0, (size_t)n_p * 8, s));
+      DactsPasses ps{};
+      if (c->multi) { ps.g[0] = c->dm_b; ps.dense[0] = c->multi_dense; ps.idx[0] = c->multi_idx; ps.kcap[0] = c->k4; }
+      if (aux) { ps.g[1] = c->dh_b; ps.dense[1] = c->aux_dense; ps.idx[1] = c->aux_idx; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
+      ps.g[2] = c->de_b; ps.dense[2] = c->dense; ps.idx[2] = c->top_idx; ps.kcap[2] = k;
       auto launch_dacts = [&](auto np_tag) {
         constexpr int NP = decltype(np_tag)::value;
-        hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, c->de_b,
-                           aux ? c->dh_b : (const bf16_t*)nullptr, c->dense, c->top_idx, k, c->aux_dense, c->aux_idx,
-                           c->k_aux_cap, c->Wd_b, c->dpre, c->dbe_fx, M, n_p, c->tk);
+        hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, ps, c->Wd_b, c->dpre, c->dbe_fx, M,
+                           n_p, c->tk);
       };
       if (d_p == 384) launch_dacts(std::integral_constant<int, 3>{});
       else if (d_p == 768) launch_dacts(std::integral_constant<int, 6>{});
       else launch_dacts(std::integral_constant<int, 10>{});
       ev_end(c, KID_TK_DDENSE, s);
     } else {  // dpre = [selected] (de W_dec^T)  (+ aux part) as a dense GEMM with a masking epilogue
-      // (A/B and test path only, reserved[3] == 1: its second launch is a host decision, so this path reads num_dead back)
+      // (A/B and test path only, topk_dense_backward: its second launch is a host decision, so this path reads num_dead back)
       int num_dead = 0;
       if (aux) {
         HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
@@ -894,34 +925,49 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       const bool aux_now = aux && num_dead > 0;
       GemmArgs g{};
-      g.A0 = c->de_b; g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
+      g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
       g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
-      EpiTopkDpre e{};
-      e.sel = c->dense; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = 0; e.last = aux_now ? 0 : 1;
+      // passes in autograd's execution order (multi-TopK, AuxK, main); each adds into dpre with one bf16 rounding
+      const bf16_t* gsrc[3] = {c->multi ? c->dm_b : nullptr, aux_now ? c->dh_b : nullptr, c->de_b};
+      const bf16_t* sel[3] = {c->multi_dense, c->aux_dense, c->dense};
       ev_begin(c, KID_TK_DDENSE, s);
-      rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
-      if (!rc && aux_now) {
-        g.A0 = c->dh_b;
-        e.sel = c->aux_dense; e.accumulate = 1; e.last = 1;
+      bool first = true;
+      rc = SAE_OK;
+      for (int pass = 0; pass < 3 && !rc; ++pass) {
+        if (!gsrc[pass]) continue;
+        g.A0 = gsrc[pass];
+        EpiTopkDpre e{};
+        e.sel = sel[pass]; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = first ? 0 : 1; e.last = pass == 2;
         rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+        first = false;
       }
       ev_end(c, KID_TK_DDENSE, s);
       if (rc) return rc;
     }
     const int splits = c->dw_splits;
-    {  // dW_dec[n][d] = dense^T de (+ aux_dense^T de_hat)
+    {  // dW_dec[n][d] = dense^T de (+ aux_dense^T de_hat) (+ multi_dense^T dm as a second launch into its own slabs)
       GemmArgs g{};
       g.A0 = c->dense; g.B0 = c->de_b; g.A1 = c->aux_dense; g.B1 = c->dh_b; g.lda = n_p; g.ldb = d_p;
       g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = aux ? 2 * g.ktiles0 : g.ktiles0;
       g.seg1_gate = aux ? c->tk : nullptr;          // the AuxK pair joins only while latents are dead
       g.splits = splits > g.ktiles0 ? g.ktiles0 : splits;
+      const bool slabs = g.splits > 1 || c->multi;
       EpiSlab e{};
-      e.slab = g.splits > 1 ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
+      e.slab = slabs ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
       ev_begin(c, KID_TK_DWD, s);
       rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
-      if (!rc && g.splits > 1) {
+      int nslabs = g.splits;
+      if (!rc && c->multi) {
+        GemmArgs g2 = g;
+        g2.A0 = c->multi_dense; g2.B0 = c->dm_b; g2.A1 = nullptr; g2.B1 = nullptr; g2.ktiles = g2.ktiles0; g2.seg1_gate = nullptr;
+        EpiSlab e2 = e;
+        e2.slab = c->slab + (int64_t)g.splits * c->nW;
+        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g2, e2, s);
+        nslabs = 2 * g.splits;
+      }
+      if (!rc && slabs) {
         const int64_t n4 = c->nW / 4;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWd, n4, n4, g.splits);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWd, n4, n4, nslabs);
       }
       ev_end(c, KID_TK_DWD, s);
       if (rc) return rc;
@@ -945,14 +991,14 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     }
     ev_begin(c, KID_REDUCE, s);
     if (c->topk_sparse_da)
-      hipLaunchKernelGGL(topk_dbe_from_fx_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->dbe_fx, gbe, n_p);
+      hipLaunchKernelGGL(topk_dbe_from_fx_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->dbe_fx, gbe, c->db_part, n_p);
     else
       hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
     // d b_dec also receives -sum_rows(dpre W_enc) through sae_in = x - b_dec; that row sum is a GEMV on d b_enc
     ev_begin(c, KID_TK_DSAE, s);
     const int nchunks = (n_p + 255) / 256;
-    hipLaunchKernelGGL(topk_dsae_colsum_kernel, dim3((d_p + 255) / 256, nchunks), dim3(256), 0, s, gbe, c->We_b, c->ds_part, n_p,
-                       d_p);
+    hipLaunchKernelGGL(topk_dsae_colsum_kernel, dim3((d_p + 255) / 256, nchunks), dim3(256), 0, s,
+                       c->topk_sparse_da ? c->db_part : gbe, c->We_b, c->ds_part, n_p, d_p);
     ev_end(c, KID_TK_DSAE, s);
     hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
     ev_end(c, KID_REDUCE, s);
@@ -1094,7 +1140,7 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
       }
     return SAE_OK;
   }
-  if (which == 6) {   // clock stamps of the fused backward (reserved[1] == 66): [wg][4] as floats
+  if (which == 6) {   // clock stamps of the fused backward (debug_flags == 66): [wg][4] as floats
     const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4 * 2;   // [0]: loop stamps per workgroup, [1]: whole-kernel cycles
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
     std::vector<unsigned long long> tmp((size_t)nq);
@@ -1145,6 +1191,17 @@ extern "C" int sae_topk_indices(sae_ctx* c, void** dev_ptr, int* k) {
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
   *dev_ptr = c->top_idx;
   *k = c->k;
+  return SAE_OK;
+}
+
+extern "C" int sae_multi_topk_buffers(sae_ctx* c, void** dense_dev, int64_t* row_stride, void** idx_dev, int* k4) {
+  if (!c || !dense_dev || !row_stride || !idx_dev || !k4) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->topk || !c->multi) return fail(SAE_ERR_INVALID, "sae_multi_topk_buffers: not a TopK context with multi_topk");
+  if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  *dense_dev = c->multi_dense;
+  *row_stride = c->n_p;
+  *idx_dev = c->multi_idx;
+  *k4 = c->k4;
   return SAE_OK;
 }
 

@@ -476,32 +476,39 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
   if (lane == 0) part[row] = sq;
 }
 
-// tkf: [0] aux scale, [1] total_variance, [2] fvu, [3] auxk*alpha, [4] mse, [5] coef = alpha*scale*2/tv
+// tkf: [0] aux scale, [1] total_variance, [5] coef = alpha*scale*2/tv
+// metrics: [0] fvu, [1] auxk*alpha, [2] mse, [5] dead fraction, [6] multi_topk_fvu
 __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __restrict__ tv_part, int n_tv,
                                                              const float* __restrict__ e2_part, const float* __restrict__ a2_part,
+                                                             const float* __restrict__ m2_part,
                                                              int64_t Mp, int64_t M, int d, float auxk_alpha, const int* tk,
                                                              float* __restrict__ tkf, float* __restrict__ metrics,
                                                              float dead_frac_n) {
-  __shared__ double red[3][4];
-  double a = 0, b = 0, c = 0;
+  __shared__ double red[4][4];
+  double a = 0, b = 0, c = 0, m = 0;
+  const bool have_aux = a2_part != nullptr && tk[0] > 0;     // with no dead latent the AuxK kernels did not run
   for (int i = threadIdx.x; i < n_tv; i += 256) a += tv_part[i];
   for (int64_t i = threadIdx.x; i < Mp; i += 256) {
     b += (double)e2_part[i];
-    if (a2_part) c += (double)a2_part[i];
+    if (have_aux) c += (double)a2_part[i];
+    if (m2_part) m += (double)m2_part[i];
   }
   a = wave_sum_d(a);
   b = wave_sum_d(b);
   c = wave_sum_d(c);
+  m = wave_sum_d(m);
   if ((threadIdx.x & 63) == 0) {
     red[0][threadIdx.x >> 6] = a;
     red[1][threadIdx.x >> 6] = b;
     red[2][threadIdx.x >> 6] = c;
+    red[3][threadIdx.x >> 6] = m;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     double tv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const double e2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double a2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    const double m2 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
     if (tv == 0) tv = 1.0;
     const float tvf = (float)tv;
     const float scale = tkf[0];
@@ -515,16 +522,19 @@ __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __rest
     metrics[3] = 0.f;
     metrics[4] = 0.f;
     metrics[5] = (float)tk[0] / dead_frac_n;   // dead_pct (train/dead_pct, train_sae.py:481-485)
-    metrics[6] = metrics[7] = 0.f;
+    metrics[6] = m2_part ? (float)m2 / tvf : 0.f;   // multi_topk_fvu (topkautoencoder.py:134-140)
+    metrics[7] = 0.f;
   }
 }
 
-// de = 2 e / tv - de_hat,  de_hat = coef (e_hat - e)  -> bf16 GEMM operands; column sums for d b_dec
+// de = 2 e / tv - de_hat,  de_hat = coef (e_hat - e),  dm = (2/8) e_multi / tv (the multi_topk_fvu / 8 loss term,
+// train_sae.py:442)  -> bf16 GEMM operands; column sums for d b_dec
 __global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ e, const float* __restrict__ dh,
                                                        const float* __restrict__ tkf, bf16_t* __restrict__ de_b,
                                                        bf16_t* __restrict__ dh_b, float* __restrict__ dbd_part, int64_t Mp,
                                                        int d_p, int rows_per_block, int aux_possible,
-                                                       const int* __restrict__ tk) {
+                                                       const int* __restrict__ tk, const float* __restrict__ em,
+                                                       bf16_t* __restrict__ dm_b) {
   const int use_aux = aux_possible && tk[0] > 0;
   // grid (d_p / 256, ceil(Mp / rows_per_block)); thread = one column, fixed row order
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -543,6 +553,11 @@ __global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ 
       }
       de_b[r * d_p + c] = (bf16_t)g;
       s += g + gh;                        // d b_dec gets de + de_hat (both decoders add b_dec)
+      if (em) {                           // ... and the multi-TopK decode's gradient
+        const float gm = em[r * d_p + c] * (0.125f * two_over_tv);
+        dm_b[r * d_p + c] = (bf16_t)gm;
+        s += gm;
+      }
     }
   if (c < d_p) dbd_part[(int64_t)blockIdx.y * d_p + c] = s;
 }
@@ -560,11 +575,18 @@ __global__ __launch_bounds__(256) void topk_de_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 constexpr double TOPK_FX_SCALE = 1099511627776.0;   // 2^40
 
+// The decodes that feed `pre` (in autograd's execution order: multi-TopK, AuxK, main -- each adds into the bf16 gradient
+// of `pre` with one rounding, which the read-add-write below reproduces)
+struct DactsPasses {
+  const bf16_t* g[3];       // d output of the decode [M_p][d_p] (null = pass absent)
+  const bf16_t* dense[3];   // its masked dense activations [M_p][n_p]
+  const int* idx[3];        // its index list [M_p][kcap]
+  int kcap[3];
+  int gated[3];             // 1: runs only while tk[0] > 0 (AuxK)
+};
+
 template <int NPAIR>
-__global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restrict__ de_b, const bf16_t* __restrict__ dh_b,
-                                                          const bf16_t* __restrict__ dense, const int* __restrict__ idx, int k,
-                                                          const bf16_t* __restrict__ aux_dense, const int* __restrict__ aux_idx,
-                                                          int kaux_cap, const bf16_t* __restrict__ Wd, bf16_t* __restrict__ dpre,
+__global__ __launch_bounds__(256) void topk_dacts_kernel(DactsPasses ps, const bf16_t* __restrict__ Wd, bf16_t* __restrict__ dpre,
                                                           long long* __restrict__ dbe_fx, int64_t M, int n_p,
                                                           const int* __restrict__ tk) {
   constexpr int d_p = 128 * NPAIR;
@@ -572,12 +594,12 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restric
   const int64_t row = (int64_t)blockIdx.x * 4 + w;
   if (row >= M) return;                                // wave-uniform
   const int c0 = lane * 2 * NPAIR;
-  for (int pass = 0; pass < 2; ++pass) {
-    const bf16_t* gsrc = pass == 0 ? de_b : dh_b;
-    if (!gsrc || (pass == 1 && tk[0] <= 0)) break;      // the AuxK pass needs dead latents (device-side decision)
-    const bf16_t* rd = (pass == 0 ? dense : aux_dense) + row * n_p;
-    const int kcap = pass == 0 ? k : kaux_cap;
-    const int* ri = (pass == 0 ? idx : aux_idx) + row * kcap;
+  for (int pass = 0; pass < 3; ++pass) {
+    const bf16_t* gsrc = ps.g[pass];
+    if (!gsrc || (ps.gated[pass] && tk[0] <= 0)) continue;      // the AuxK pass needs dead latents (device-side decision)
+    const bf16_t* rd = ps.dense[pass] + row * n_p;
+    const int kcap = ps.kcap[pass];
+    const int* ri = ps.idx[pass] + row * kcap;
     float g[2 * NPAIR];
     {
       const unsigned* gp = reinterpret_cast<const unsigned*>(gsrc + row * d_p + c0);
@@ -613,18 +635,14 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restric
         }
         s0 = wave_sum(s0);
         s1 = wave_sum(s1);
-        if (lane == 0) {
+        if (lane == 0) {      // dpre was zero-filled before the launch: every pass adds (bf16, one rounding per addition)
           if (i0 >= 0 && a0 > 0.f) {
-            float v = bf16_round(s0);
-            if (pass) v += (float)out[i0];
-            out[i0] = (bf16_t)v;
+            out[i0] = (bf16_t)(bf16_round(s0) + (float)out[i0]);
             atomicAdd(reinterpret_cast<unsigned long long*>(dbe_fx + i0),
                       (unsigned long long)__double2ll_rn((double)bf16_round(s0) * TOPK_FX_SCALE));
           }
           if (j + 1 < cnt && i1 >= 0 && a1 > 0.f) {
-            float v = bf16_round(s1);
-            if (pass) v += (float)out[i1];
-            out[i1] = (bf16_t)v;
+            out[i1] = (bf16_t)(bf16_round(s1) + (float)out[i1]);
             atomicAdd(reinterpret_cast<unsigned long long*>(dbe_fx + i1),
                       (unsigned long long)__double2ll_rn((double)bf16_round(s1) * TOPK_FX_SCALE));
           }
@@ -634,9 +652,16 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void topk_dbe_from_fx_kernel(const long long* __restrict__ fx, float* __restrict__ gbe, int n_p) {
+// d b_enc: the encoder bias enters the bf16 addmm as a bf16 cast, so its gradient is a bf16 value (one rounding of the
+// column sum); `exact` keeps the unrounded sums for the d b_dec GEMV (topk_dsae_colsum_kernel).
+__global__ __launch_bounds__(256) void topk_dbe_from_fx_kernel(const long long* __restrict__ fx, float* __restrict__ gbe,
+                                                                float* __restrict__ exact, int n_p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_p) gbe[i] = (float)((double)fx[i] / TOPK_FX_SCALE);
+  if (i < n_p) {
+    const float v = (float)((double)fx[i] / TOPK_FX_SCALE);
+    exact[i] = v;
+    gbe[i] = bf16_round(v);
+  }
 }
 
 // ddense epilogue: dpre = [selected] * bf16(de . W_dec^T) (+ aux part), gated by pre > 0; column sums -> d b_enc

@@ -22,8 +22,9 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 VARIANT = {"l1": 0, "topk": 1}
 OPTIMIZER = {"radam": 0, "adam": 1}
 DTYPE = {"float32": 0, "float16": 1, "bfloat16": 2}
+PRECISION = {"bf16": 0, "fp8": 1}
 NUM_METRICS = 8
-M_LOSS_RECON, M_LOSS_L1, M_MSE, M_GRAD_NORM, M_COUNT = 0, 1, 2, 3, 4
+M_LOSS_RECON, M_LOSS_L1, M_MSE, M_GRAD_NORM, M_COUNT, M_DEAD_PCT, M_MULTI_TOPK_FVU = 0, 1, 2, 3, 4, 5, 6
 
 
 class SaeConfig(C.Structure):
@@ -32,7 +33,9 @@ class SaeConfig(C.Structure):
         ("optimizer", C.c_int32), ("device_id", C.c_int32), ("max_rows", C.c_int64),
         ("recon_alpha", C.c_double), ("auxk_alpha", C.c_double), ("clip_thresh", C.c_double),
         ("weight_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-        ("reserved", C.c_int32 * 8),
+        ("force_generic", C.c_int32), ("debug_flags", C.c_int32), ("force_gemm128", C.c_int32),
+        ("topk_dense_backward", C.c_int32), ("multi_topk", C.c_int32), ("precision", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -90,6 +93,7 @@ def load() -> C.CDLL:
         "sae_latent_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_topk_indices": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
         "sae_decode": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp]),
+        "sae_multi_topk_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(C.c_int)]),
         "sae_read_metrics": (C.c_int, [vp, fptr, vp]),
         "sae_latent_colmax": (C.c_int, [vp, fptr, i64, vp]),
         "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
@@ -110,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
     "sae_set_grad_ready_callback", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
-    "sae_latent_buffer", "sae_topk_indices", "sae_decode",
+    "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
@@ -141,7 +145,7 @@ class SaeEngine:
                  recon_alpha: float = 1.0, k: int = 0, auxk_alpha: float = 0.0, clip_thresh: float = 1.0,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: Optional[float] = None, device_id: int = 0,
                  force_generic: bool = False, debug_flags: int = 0, force_gemm128: bool = False,
-                 topk_dense_backward: bool = False):
+                 topk_dense_backward: bool = False, multi_topk: bool = False, precision: str = "bf16"):
         if variant not in VARIANT:
             raise AssertionError(f"Invalid autoencoder variant: {variant}, must be 'l1' or 'topk'")
         if optimizer not in OPTIMIZER:
@@ -154,11 +158,16 @@ class SaeEngine:
         cfg.optimizer, cfg.device_id, cfg.max_rows = OPTIMIZER[optimizer], device_id, max_rows
         cfg.recon_alpha, cfg.auxk_alpha, cfg.clip_thresh = recon_alpha, auxk_alpha, clip_thresh
         cfg.weight_decay, cfg.beta1, cfg.beta2, cfg.eps = weight_decay, betas[0], betas[1], eps
-        cfg.reserved[1] = debug_flags                 # timing experiments only (results become wrong)
-        cfg.reserved[0] = 1 if force_generic else 0   # 1 = generic three-GEMM backward even where a fused kernel exists
-        cfg.reserved[2] = 1 if force_gemm128 else 0   # 1 = 128x128 GEMM tiles even where the 256x256 kernel applies
-        cfg.reserved[3] = 1 if topk_dense_backward else 0   # 1 = TopK d pre-activations by the dense GEMM + mask (A/B, tests)
+        cfg.debug_flags = debug_flags                 # timing experiments only (results become wrong)
+        cfg.force_generic = 1 if force_generic else 0   # 1 = generic three-GEMM backward even where a fused kernel exists
+        cfg.force_gemm128 = 1 if force_gemm128 else 0   # 1 = 128x128 GEMM tiles even where the 256x256 kernel applies
+        cfg.topk_dense_backward = 1 if topk_dense_backward else 0   # 1 = TopK d pre-activations by the dense GEMM + mask
+        cfg.multi_topk = 1 if multi_topk else 0       # TopKAutoEncoderConfig.multi_topk
+        if precision not in PRECISION:
+            raise ValueError(f"Invalid precision: {precision}, must be one of {sorted(PRECISION)}")
+        cfg.precision = PRECISION[precision]
         self.variant, self.d, self.n, self.max_rows, self.device_id = variant, d_model, n_dict, max_rows, device_id
+        self.k, self.multi_topk, self.precision = k, bool(multi_topk), precision
         self._ctx = C.c_void_p()
         _check(self._lib.sae_create(C.byref(cfg), C.byref(self._ctx)))
 
@@ -293,6 +302,21 @@ class SaeEngine:
             __cuda_array_interface__ = {"shape": (rows, k.value), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
 
         return torch.as_tensor(_Alias(), device=device)
+
+    def multi_topk_buffers(self, rows: int, device):
+        """TopK with multi_topk: (bf16 [rows][n_dict] dense 4k activations, int32 [rows][4k] indices) of the last forward."""
+        import torch
+        dptr, ld, iptr, k4 = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int()
+        _check(self._lib.sae_multi_topk_buffers(self._ctx, C.byref(dptr), C.byref(ld), C.byref(iptr), C.byref(k4)))
+
+        class _D:
+            __cuda_array_interface__ = {"shape": (rows, ld.value), "typestr": "<i2", "data": (dptr.value, False), "version": 2}
+
+        class _I:
+            __cuda_array_interface__ = {"shape": (rows, k4.value), "typestr": "<i4", "data": (iptr.value, False), "version": 2}
+
+        dense = torch.as_tensor(_D(), device=device).view(torch.bfloat16)[:, : self.n]
+        return dense, torch.as_tensor(_I(), device=device)
 
     def decode(self, latent, out, stream=None) -> None:
         """out[rows][d_model] (fp32 CUDA tensor) = decode(latent[rows][>= n_dict]) (fp32 or bf16 CUDA tensor, row-major)."""

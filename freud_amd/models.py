@@ -183,7 +183,8 @@ class TopKAutoEncoder(_EngineModel):
     def __init__(self, activation_size: int, cfg: TopKAutoEncoderConfig, device="cuda", max_rows: int = 1500):
         self.cfg = cfg
         n = get_n_dict_components(activation_size, cfg.expansion_factor, cfg.n_dict_components)
-        super().__init__(activation_size, n, device, max_rows, k=cfg.k, auxk_alpha=cfg.auxk_alpha, optimizer="adam")
+        super().__init__(activation_size, n, device, max_rows, k=cfg.k, auxk_alpha=cfg.auxk_alpha, optimizer="adam",
+                         multi_topk=bool(cfg.multi_topk))
         enc = torch.nn.Linear(activation_size, n)                            # topkautoencoder.py:62-70
         enc.bias.data.zero_()
         W_dec = enc.weight.data.clone()
@@ -225,10 +226,14 @@ class TopKAutoEncoder(_EngineModel):
         self._ensure(x2.shape[0]).set_topk_options(float("inf"), self._eng_rows_per_file)   # T of x.mean(0) (:104)
         acts, idx, dense = self._encode_flat(x2)
         m = self._eng.metrics()
+        if self.cfg.multi_topk:        # forward() re-binds sae_out / encoded to the 4k selection (topkautoencoder.py:134-147)
+            dense, idx = self._eng.multi_topk_buffers(x2.shape[0], self.device)
+            idx = idx.long()
+            acts = torch.gather(dense, 1, idx)
         x_hat = self._decode_dense(dense).reshape(*lead, self.activation_size)
         k = idx.shape[1]
         out = TopKForwardOutput(x_hat, TopKEncoderOutput(acts.float().reshape(*lead, k), idx.reshape(*lead, k)),
-                                torch.tensor(float(m[0])), torch.tensor(0.0), torch.tensor(0.0))
+                                torch.tensor(float(m[0])), torch.tensor(0.0), torch.tensor(float(m[6])))
         if return_mse:
             return out, torch.tensor(float(m[2]))
         return out

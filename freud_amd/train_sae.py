@@ -216,20 +216,21 @@ def validate(engine, val_folder: str, device, layer_name: str, from_disk: bool, 
     means of the per-file losses, per-feature max |latent| over time -> maxes / stds over files.
     (The Whisper-transcript part of the reference's validate needs Whisper weights: out of scope.)"""
     loader, _, _ = init_dataloader(from_disk, val_folder, "", None, layer_name, device, 1, 1, None, {"shuffle": False})
-    recon, l1, mses, maxes = [], [], [], []
+    recon, l1, mses, maxes, multi = [], [], [], [], []
     for acts, _names in loader:
         engine.eval(acts)
         m = engine.metrics()
         recon.append(float(m[0]))
         l1.append(float(m[1]))
         mses.append(float(m[2]))
+        multi.append(float(m[6]))
         maxes.append(engine.latent_colmax())
     mag = np.stack(maxes) if maxes else np.zeros((0, engine.n), np.float32)
     losses = {"l1": float(np.mean(l1)) if variant == "l1" and l1 else None,
               "recon": float(np.mean(recon)) if variant == "l1" and recon else None,
               "fvu": float(np.mean(recon)) if variant == "topk" and recon else None,
               "auxk_loss": float(np.mean(l1)) if variant == "topk" and l1 else None,
-              "multi_topk_fvu": 0.0 if variant == "topk" else None,
+              "multi_topk_fvu": (float(np.mean(multi)) if multi else 0.0) if variant == "topk" else None,
               "mse": float(np.mean(mses)) if mses else float("nan")}
     mag_max = mag.max(axis=0) if len(mag) else np.zeros(engine.n, np.float32)
     mag_std = mag.std(axis=0, ddof=1) if len(mag) > 1 else np.zeros(engine.n, np.float32)
@@ -327,6 +328,7 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         n_dict = get_n_dict_components(feat_dim, cfg.expansion_factor, cfg.n_dict_components)
         eng = engine_factory(variant="topk", d_model=feat_dim, n_dict=n_dict, max_rows=max_rows, optimizer=optimizer,
                              k=cfg.k, auxk_alpha=cfg.auxk_alpha, clip_thresh=clip_thresh, weight_decay=weight_decay,
+                             multi_topk=bool(cfg.multi_topk),
                              device_id=(device.index or 0) if device.type == "cuda" else 0)
         enc = torch.nn.Linear(feat_dim, n_dict)                   # topkautoencoder.py:62-70
         enc.bias.data.zero_()
@@ -403,10 +405,11 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                     logger.add_scalar("train/loss_recon", m[0], state["step"])
                     logger.add_scalar("train/loss_l1", m[1], state["step"])
                 else:
-                    logger.add_scalar("train/loss", float(m[0]) + float(m[1]), state["step"])
+                    # loss = out.fvu + out.auxk_loss + out.multi_topk_fvu / 8  (train_sae.py:442)
+                    logger.add_scalar("train/loss", float(m[0]) + float(m[1]) + float(m[6]) / 8, state["step"])
                     logger.add_scalar("train/fvu", m[0], state["step"])
                     logger.add_scalar("train/auxk_loss", m[1], state["step"])
-                    logger.add_scalar("train/multi_topk_fvu", 0.0, state["step"])
+                    logger.add_scalar("train/multi_topk_fvu", m[6], state["step"])
                     logger.add_scalar("train/dead_pct", m[5], state["step"])
                 logger.add_scalar("train/lr", lr_at(state["step"], lr, scheduler, steps, scheduler_params), state["step"])
                 logger.add_scalar("train/grad_norm", m[3], state["step"])

@@ -63,8 +63,22 @@ typedef struct sae_config {
   double weight_decay;    /* RAdam only (train_sae.py:375-377)                           */
   double beta1, beta2;    /* 0.9 / 0.999 (torch defaults the reference relies on)        */
   double eps;             /* 1e-5 RAdam (train_sae.py:376), 1e-8 Adam (torch default)    */
-  int32_t reserved[8];    /* must be zero                                                */
+  /* development / test switches (zero in production): */
+  int32_t force_generic;  /* 1: generic GEMM path even where a fused d=384 kernel exists (tests cover both)          */
+  int32_t debug_flags;    /* kernel timing experiments of bench.py --dbg (results become wrong)                      */
+  int32_t force_gemm128;  /* 1: 128x128 GEMM tiles even where the 256x256 kernel applies (A/B timing, tests)        */
+  int32_t topk_dense_backward; /* 1: TopK d pre-activations by the dense GEMM + mask instead of the sparse kernel   */
+  /* model / numerics options: */
+  int32_t multi_topk;     /* TopK only: cfg.multi_topk (topkautoencoder.py:134-140, loss term train_sae.py:442)     */
+  int32_t precision;      /* SAE_PREC_*: operand type of the L1 encoder / decoder GEMMs                             */
+  int32_t reserved[2];    /* must be zero                                                                           */
 } sae_config;
+
+/* SAE_PREC_BF16: every GEMM on bf16 operands (the reference's CPU autocast precision; the parity configuration).
+ * SAE_PREC_FP8 : BASELINE configs[4] -- encoder and decoder GEMMs on OCP e4m3 operands (x, W and the latent quantised
+ *                with per-tensor power-of-two scales), fp32 MFMA accumulation, outputs rounded to bf16 like the bf16 path;
+ *                the backward GEMMs and the fp32 master weights / optimizer are unchanged. */
+enum { SAE_PREC_BF16 = 0, SAE_PREC_FP8 = 1 };
 
 /* Metrics of the most recent sae_forward_backward / sae_eval (all fp32). */
 enum {
@@ -73,8 +87,8 @@ enum {
   SAE_M_MSE = 2,          /* the return_mse value         (l1autoencoder.py:93-94, topk :149-150)       */
   SAE_M_GRAD_NORM = 3,    /* total_norm returned by clip_grad_norm_ (valid after sae_optimizer_step)    */
   SAE_M_COUNT = 4,        /* number of unmasked elements (x != -1) entering the masked MSE             */
-  SAE_M_RESERVED5 = 5,
-  SAE_M_RESERVED6 = 6,
+  SAE_M_DEAD_PCT = 5,     /* TopK: fraction of dead latents (train/dead_pct, train_sae.py:481-485)                      */
+  SAE_M_MULTI_TOPK_FVU = 6, /* TopK with cfg.multi_topk: out.multi_topk_fvu (topkautoencoder.py:134-140), else 0      */
   SAE_M_RESERVED7 = 7,
   SAE_NUM_METRICS = 8
 };
@@ -159,6 +173,10 @@ int sae_eval(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stre
 int sae_latent_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* row_stride);
 int sae_topk_indices(sae_ctx* ctx, void** dev_ptr, int* k);
 int sae_decode(sae_ctx* ctx, const void* latent_dev, int latent_dtype, int64_t ld, int64_t M, float* x_hat_dev, void* stream);
+/* TopK with cfg.multi_topk only: the second selection of the last forward -- the top 4k activations scattered into a
+ * dense bf16 row [M][*row_stride] and their int32 indices [M][*k4].  TopKAutoEncoder.forward() returns THESE as
+ * out.encoded / out.sae_out when multi_topk is set (topkautoencoder.py:134-147 re-binds the names); encode() keeps k. */
+int sae_multi_topk_buffers(sae_ctx* ctx, void** dense_dev, int64_t* row_stride, void** idx_dev, int* k4);
 
 /* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
 int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);

@@ -9,7 +9,8 @@ from oracle import sae_oracle as O
 
 class OracleEngine:
     def __init__(self, variant, d_model, n_dict, max_rows, *, optimizer="radam", recon_alpha=1.0, k=0, auxk_alpha=0.0,
-                 clip_thresh=1.0, weight_decay=0.0, device_id=0, **_):
+                 clip_thresh=1.0, weight_decay=0.0, device_id=0, multi_topk=False, **_):
+        self.multi_topk = bool(multi_topk)
         self.variant, self.d, self.n, self.max_rows = variant, d_model, n_dict, max_rows
         self.optimizer, self.recon_alpha, self.k, self.auxk_alpha = optimizer, recon_alpha, k, auxk_alpha
         self.clip_thresh, self.weight_decay = clip_thresh, weight_decay
@@ -82,16 +83,17 @@ class OracleEngine:
             P = self.P
             dead = self.nfsf > self.dead_threshold
             f = O.topk_forward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], self.k, dead,
-                               self.auxk_alpha, True)
+                               self.auxk_alpha, True, self.multi_topk)
             g = O.topk_backward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], f,
                                 self.auxk_alpha, True)
             did = torch.zeros(self.n, dtype=torch.bool)
-            did[f["top_indices"].flatten()] = True
+            did[f["fire_indices"].flatten()] = True
             self.nfsf += x.shape[0] * x.shape[1]
             self.nfsf[did] = 0
             self._latent = f["dense"].float()
             self._pack({"encoder.weight": g["W_enc"], "encoder.bias": g["b_enc"], "W_dec": g["W_dec"], "b_dec": g["b_dec"]},
-                       [f["fvu"].item(), f["auxk_loss"].item(), f["mse"].item(), 0.0, 0.0, float(dead.float().mean())])
+                       [f["fvu"].item(), f["auxk_loss"].item(), f["mse"].item(), 0.0, 0.0, float(dead.float().mean()),
+                        f["multi_topk_fvu"].item()])
 
     def optimizer_step(self, lr, grad_scale=1.0, stream=None):
         off, grads = 0, {}

@@ -63,6 +63,45 @@ def test_l1_steps_match_reference_golden(golden_dir, name):
     assert step == meta["steps"]
     assert _rel(m1["decoder.weight"], z["m_W"]) < 1e-2
     assert _rel(m2["decoder.weight"], z["v_W"]) < 2e-2
+    assert _rel(m1["encoder_bias"], z["m_b"]) < 3e-2          # (db sums few rows on these tiny batches: see above)
+    assert _rel(m2["encoder_bias"], z["v_b"]) < 6e-2
+    # validate()-style forward on the last batch (train_sae.py:168-190): the reference's CPU validate runs fp32 without
+    # autocast, the engine's eval runs the bf16 kernels -> rtol 1e-2 on the tiny fixtures; the in-place column
+    # renormalisation of encode() (l1autoencoder.py:71-73) must leave the same weights
+    eng.eval(xs[-1])
+    me = eng.metrics()
+    assert me[0] == pytest.approx(float(z["eval_recon"]), rel=1e-2)
+    assert me[1] == pytest.approx(float(z["eval_l1"]), rel=1e-2)
+    assert me[2] == pytest.approx(float(z["eval_mse"]), rel=1e-2)
+    assert _rel(eng.get_params()["decoder.weight"], z["W_after_eval"]) < 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize("d,n,M,generic", [(384, 3072, 1500, False), (384, 200, 1500, True), (1280, 2560, 700, False)])
+def test_eval_and_latent_colmax_match_oracle(d, n, M, generic):
+    """validate() numerics: sae_eval losses and sae_latent_colmax (torch.max(|latent|, dim=0),
+    train_sae.py:176-178) against the oracle's autocast forward on the same weights: losses rtol 2e-3, per-feature
+    maxima equal to the maxima of the oracle's bf16-rounded latent up to one bf16 ulp, dead features (max == 0) identical."""
+    g = torch.Generator().manual_seed(d + n)
+    W = torch.randn(d, n, generator=g)
+    b = 0.02 * torch.randn(n, generator=g) - 0.05
+    x = ((torch.relu(torch.randn(M, 48, generator=g)) * 0.1) @ torch.randn(48, d, generator=g))
+    x.view(-1)[torch.randint(0, x.numel(), (40,), generator=g)] = -1.0
+    eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4, force_generic=generic)
+    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    eng.eval(x.cuda())
+    m = eng.metrics()
+    cm = eng.latent_colmax()
+    Wn = O.normalize_columns(W)
+    f = O.l1_forward(x, Wn, b, 1e4, autocast=True)
+    assert m[0] == pytest.approx(f["reconstruction_loss"].item(), rel=2e-3)
+    assert m[1] == pytest.approx(f["l1_loss"].item(), rel=2e-3)
+    assert m[2] == pytest.approx(f["mse"].item(), rel=2e-3)
+    assert m[4] == float(f["count"])
+    ref = f["c"].to(torch.bfloat16).float().max(0).values.numpy()      # the engine's latent is stored as bf16
+    assert cm.shape == (n,)
+    np.testing.assert_allclose(cm, ref, rtol=2 ** -7, atol=1e-6)
+    assert np.array_equal(cm == 0, ref == 0) or (np.abs(cm - ref)[(cm == 0) != (ref == 0)] < 1e-3).all()
     eng.close()
 
 
@@ -76,11 +115,16 @@ def test_l1_steps_match_reference_golden(golden_dir, name):
     (768, 1536, 512, torch.float32, "adam", False),
     (1280, 2560, 384, torch.bfloat16, "radam", False),
     (1280, 5120, 1024, torch.bfloat16, "adam", False),     # every GEMM on the 256x256 kernel (configs[3] proportions)
+    (384, 12288, 1024, torch.bfloat16, "radam", False),    # the reference's default expansion_factor 32 (config.py:7)
+    (1280, 40960, 512, torch.bfloat16, "adam", False),     # BASELINE configs[3] at its real dictionary size
 ])
 def test_l1_step_matches_oracle(d, n, M, dtype, opt, generic):
     g = torch.Generator().manual_seed(d + n + M)
-    W = torch.empty(d, n)
-    torch.nn.init.orthogonal_(W, generator=g)
+    if n <= 8192:
+        W = torch.empty(d, n)
+        torch.nn.init.orthogonal_(W, generator=g)
+    else:        # (orthogonal_ of a 40 960 x 1280 matrix takes minutes on the host; parity does not need it)
+        W = torch.randn(d, n, generator=g) / d ** 0.5
     b = 0.01 * torch.randn(n, generator=g)
     z = torch.relu(torch.randn(M, 64, generator=g)) * 0.1
     x = (z @ torch.randn(64, d, generator=g)).to(dtype)

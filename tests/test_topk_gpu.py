@@ -51,15 +51,16 @@ def _check_selection(eng, fwd, M, n, k):
     return ties
 
 
-@pytest.mark.parametrize("name", ["topk_adam_linear_d16", "topk_adam_linear_d64"])
+@pytest.mark.parametrize("name", ["topk_adam_linear_d16", "topk_adam_linear_d64", "topk_multi_d32"])
 def test_topk_steps_match_reference_golden(golden_dir, name):
     from freud_amd.engine import SaeEngine
     z = np.load(os.path.join(golden_dir, f"{name}.npz"))
     meta = json.loads(str(z["meta"]))
     d, n, k, B, T = meta["d"], meta["n"], meta["k"], meta["B"], meta["T"]
     M = B * T
+    multi = bool(meta.get("multi_topk", False))      # topkautoencoder.py:134-140; the fixture's top_indices are the 4k set
     eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k,
-                    auxk_alpha=meta["auxk_alpha"], clip_thresh=1.0)
+                    auxk_alpha=meta["auxk_alpha"], clip_thresh=1.0, multi_topk=multi)
     eng.set_topk_options(meta["dead_feature_threshold"], T)
     eng.set_params({kk: z["init__" + kk] for kk in KEYS})
     P0 = {kk: torch.tensor(z["init__" + kk]) for kk in KEYS}
@@ -69,9 +70,10 @@ def test_topk_steps_match_reference_golden(golden_dir, name):
         lr = O.lr_at(i, meta["lr"], "linear", meta["steps"], meta["num_warmup_steps"])
         eng.forward_backward(xd[i])
         if i == 0:
-            f = O.topk_forward(xs[0], P0["encoder.weight"], P0["encoder.bias"], P0["W_dec"], P0["b_dec"], k)
-            assert torch.equal(f["top_indices"].reshape(M, k).sort(1).values,
-                               torch.tensor(z["first__top_indices"]).reshape(M, k).sort(1).values)   # oracle == reference
+            f = O.topk_forward(xs[0], P0["encoder.weight"], P0["encoder.bias"], P0["W_dec"], P0["b_dec"], k, multi_topk=multi)
+            kf = 4 * k if multi else k
+            assert torch.equal(f["fire_indices"].reshape(M, kf).sort(1).values,
+                               torch.tensor(z["first__top_indices"]).reshape(M, kf).sort(1).values)   # oracle == reference
             _check_selection(eng, f, M, n, k)
             g = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
             for kk in KEYS:
@@ -82,6 +84,10 @@ def test_topk_steps_match_reference_golden(golden_dir, name):
         assert m[0] == pytest.approx(float(z["fvu"][i]), rel=tol)
         assert m[1] == pytest.approx(float(z["auxk"][i]), rel=0.1, abs=1e-6)
         assert m[5] == pytest.approx(float(z["num_dead"][i]) / n, abs=2.0 / n)
+        if multi:
+            assert m[6] == pytest.approx(float(z["multi"][i]), rel=tol)
+        else:
+            assert m[6] == 0.0
     p = eng.get_params()
     for kk in KEYS:   # Adam turns a tie row's different gradient into a full-size step on the few elements it touches
         assert _rel(p[kk], z["final__" + kk]) < (5e-3 if kk in ("encoder.weight", "W_dec") else 0.15), kk
@@ -210,3 +216,159 @@ def test_sparse_dacts_matches_dense_ddense():
     eng.forward_backward(xd)
     assert np.array_equal(eng.debug_read(2, 2 * n * d + n + d), res[0][0])
     eng.close()
+
+
+def _tie_free_case(d, n, k, B, T, seeds=200, k_also=None):
+    for seed in range(seeds):
+        P, x = _make_case(d, n, k, B, T, seed)
+        f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k)
+        pre = f["pre"].reshape(B * T, n)
+        if not _boundary_ties(pre, k).any() and (k_also is None or not _boundary_ties(pre, k_also).any()):
+            return P, x, f
+    pytest.skip("no tie-free batch found")
+
+
+def test_topk_auxk_tie_free_matches_oracle():
+    """AuxK arithmetic at a tight tolerance: a batch without boundary ties in the main selection and FEWER dead latents
+    than k_aux = d/2 (so the aux selection takes every dead latent: no tie possible there either).  AuxK loss to rel 2e-2,
+    raw gradients to rel-Frobenius 1e-2, dead_pct exact."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T, aux = 384, 1024, 8, 2, 6, 0.03125
+    P, x, _ = _tie_free_case(d, n, k, B, T)
+    M = B * T
+    thr = 100.0
+    g = torch.Generator().manual_seed(1)
+    dead_idx = torch.randperm(n, generator=g)[:120]             # 120 < d/2 = 192
+    nfsf = torch.zeros(n, dtype=torch.long)
+    nfsf[dead_idx] = 1000
+    dead = nfsf > thr
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=aux)
+    eng.set_topk_options(thr, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.set_topk_state(nfsf.numpy())
+    eng.forward_backward(x.cuda())
+    graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+    eng.optimizer_step(1e-4)
+    m = eng.metrics()
+    st = O.OptState()
+    out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=dead, auxk_alpha=aux, optimizer="adam")
+    assert out["auxk_loss"].item() > 0
+    assert m[5] == pytest.approx(120.0 / n, abs=1e-7)
+    assert m[0] == pytest.approx(out["fvu"].item(), rel=2e-3)
+    assert m[1] == pytest.approx(out["auxk_loss"].item(), rel=2e-2)
+    assert m[3] == pytest.approx(out["grad_norm"].item(), rel=1e-2)
+    for kk in KEYS:
+        assert _rel(graw[kk], out["grads"][kk].numpy()) < 1e-2, kk
+    eng.close()
+
+
+def test_topk_multi_topk_sparse_path_matches_oracle():
+    """cfg.multi_topk on the sparse-backward path (d_p = 384): the 4k selection, its decode, multi_topk_fvu, the
+    loss / 8 gradient and did_fire from the 4k set (train_sae.py:442-446), on a batch with no boundary tie at k nor at 4k."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T = 384, 1024, 8, 2, 6
+    P, x, _ = _tie_free_case(d, n, k, B, T, k_also=4 * k)
+    M = B * T
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.0, multi_topk=True)
+    eng.set_topk_options(1e9, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.forward_backward(x.cuda())
+    graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+    eng.optimizer_step(1e-4)
+    m = eng.metrics()
+    st = O.OptState()
+    out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=None, auxk_alpha=0.0, optimizer="adam",
+                            multi_topk=True)
+    assert m[0] == pytest.approx(out["fvu"].item(), rel=2e-3)
+    assert m[6] == pytest.approx(out["multi_topk_fvu"].item(), rel=2e-3)
+    assert m[3] == pytest.approx(out["grad_norm"].item(), rel=1e-2)
+    for kk in KEYS:
+        assert _rel(graw[kk], out["grads"][kk].numpy()) < 1e-2, kk
+    fired = np.zeros(n, bool)
+    fired[out["fire_indices"].numpy().ravel()] = True
+    got = eng.get_topk_state()                      # counters: 0 where the 4k set fired, M elsewhere
+    assert np.array_equal(got == 0, fired)
+    assert set(np.unique(got)) <= {0, M}
+    eng.close()
+
+
+@pytest.mark.parametrize("d,n,k,B,T,kernel", [
+    (768, 24576, 64, 2, 256, "reg12"),      # BASELINE configs[2] at its real n and k (register select, 12 vectors / thread)
+    (384, 32768, 32, 2, 64, "reg44"),       # n_p > 24 576: topk_select_reg_kernel<44>
+    (384, 98304, 32, 1, 64, "generic"),     # n_p > 90 112: the radix-select fallback (topk_select_kernel)
+])
+def test_topk_real_dictionary_sizes_match_oracle(d, n, k, B, T, kernel):
+    """The configs[2] shape at full n / k against the oracle (M = 512 rows), and the two select kernels that only large
+    dictionaries reach.  Ties at the k-th value are common with bf16 pre-activations: the selected VALUES must be
+    identical on every row and the index sets on every row without a boundary tie; losses to rtol 5e-3, gradients to
+    rel-Frobenius 0.15 when tie rows exist (they pick different decoder rows) and 1e-2 when none do."""
+    from freud_amd.engine import SaeEngine
+    P, x = _make_case(d, n, k, B, T, 3)
+    M = B * T
+    f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k)
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.0)
+    eng.set_topk_options(1e12, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.forward_backward(x.cuda())
+    ties = _check_selection(eng, f, M, n, k)
+    graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+    eng.optimizer_step(1e-4)
+    m = eng.metrics()
+    st = O.OptState()
+    out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=None, auxk_alpha=0.0, optimizer="adam")
+    assert m[0] == pytest.approx(out["fvu"].item(), rel=5e-3)
+    assert m[2] == pytest.approx(out["mse"].item(), rel=5e-3)
+    gtol = 0.15 if ties.any() else 1e-2
+    assert m[3] == pytest.approx(out["grad_norm"].item(), rel=0.05 if ties.any() else 1e-2)
+    for kk in KEYS:
+        assert _rel(graw[kk], out["grads"][kk].numpy()) < gtol, (kk, int(ties.sum()))
+    eng.close()
+
+
+def test_topk_c3_full_size_properties():
+    """BASELINE configs[2] at full size (d=768, n=24 576, k=64, M=65 536): size-independent properties -- exactly k
+    non-zero latents per row (or fewer only where a row has fewer positive pre-activations), did_fire consistent with the
+    index lists, two identical runs bitwise equal, the loss decreases."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T = 768, 24576, 64, 64, 1024
+    M = B * T
+    g = torch.Generator().manual_seed(0)
+    We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
+    Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
+    x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16).reshape(B, T, d).cuda()
+    runs = []
+    for _ in range(2):
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.03125)
+        eng.set_topk_options(1e6, T)
+        eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
+                        "b_dec": np.zeros(d, np.float32)})
+        fv = []
+        for i in range(4):
+            eng.step(x, 1e-4)
+            fv.append(float(eng.metrics()[0]))
+        idx = eng.topk_indices_tensor(M, "cuda:0")
+        ptr, ld = eng.latent_buffer()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (M, ld), "typestr": "<i2", "data": (ptr, False), "version": 2}
+
+        dense = torch.as_tensor(_Alias(), device="cuda:0").view(torch.bfloat16)
+        nnz = (dense != 0).sum(1)
+        assert int(nnz.max()) <= k
+        assert ((idx >= 0).sum(1) == k).all()                     # k indices per row, all distinct and in range
+        assert int(idx.max()) < n
+        srt = idx.sort(1).values
+        assert (srt[:, 1:] != srt[:, :-1]).all()
+        vals = torch.gather(dense, 1, idx.long())
+        assert torch.equal((vals != 0).sum(1), nnz)               # every non-zero of the dense row is a listed index
+        fired = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+        fired[idx.long().flatten()] = True
+        nf = torch.from_numpy(eng.get_topk_state()).cuda()
+        assert torch.equal(nf == 0, fired)
+        p = eng.get_params()
+        runs.append((fv, p["W_dec"].copy(), p["encoder.bias"].copy()))
+        eng.close()
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert np.isfinite(runs[0][0]).all() and runs[0][0][-1] < runs[0][0][0]
+

@@ -8,7 +8,9 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --no-cpu-baseline --steps 30 --warmup 5 --spinup 0.3"
+# the program itself after "--" (no shell hop), default 1 s spin-up and 200 timed steps, so that the profiler's per-kernel
+# averages are taken on sustained clocks like the HIP-event figures of the un-profiled bench line
+BENCH="python3 $PWD/bench.py --no-cpu-baseline --steps 200 --warmup 20"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
