@@ -36,6 +36,7 @@ import numpy as np
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0    # dense MFMA fp8 (v_mfma_f32_32x32x64_f8f6f4), same guide
 # what a bare v_mfma_f32_32x32x16_bf16 loop at 100 % issue sustains on random bf16 operands on this chip (power-managed
 # clock 1.68 GHz; tools/mfma_clock_probe.hip, profiles/r01_mfma_clock_probe.jsonl): reported next to the nominal peak
 MEASURED_MFMA_LOOP_TFLOPS = 1700.0
@@ -96,6 +97,8 @@ def main():
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = BASELINE configs[4]: e4m3 encoder / decoder GEMMs (L1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +141,8 @@ def main():
                         "b_dec": np.zeros(d, np.float32)})
     else:
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
-                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128)
+                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128,
+                        precision=args.precision)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
     grads = eng.grad_tensor() if use_dist else None
     works = []
@@ -210,7 +214,7 @@ def main():
     fb_ms, fb_cnt = times["fwd_bwd_total"]
 
     breakdown = None
-    if args.breakdown:        # every rank runs the extra steps (they contain collectives); rank 0 reports
+    if args.breakdown or args.precision == "fp8":        # every rank runs the extra steps (they contain collectives); rank 0 reports
         eng.profile(2)
         for i in range(10):
             one_step(args.warmup + args.steps + i)
@@ -253,6 +257,13 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
+    if args.precision == "fp8" and breakdown:
+        # the two fp8 GEMMs against the dense fp8 MFMA peak (2 M d n FLOPs each), next to the (bf16) dominant kernel above
+        out["dtype"] = "fp8 (e4m3 encoder/decoder GEMMs, fp32 accumulate) + bf16 backward"
+        out["fp8_gemms"] = {k: {"ms": breakdown[k], "tflops": 2.0 * M * d * n / (breakdown[k] * 1e-3) / 1e12,
+                                "frac_of_fp8_peak": 2.0 * M * d * n / (breakdown[k] * 1e-3) / 1e12 / PEAK_FP8_TFLOPS}
+                            for k in ("enc_fwd_gemm", "dec_fwd_gemm") if breakdown.get(k)}
+        out["config"]["workload"] = out["config"]["workload"].replace("L1 SAE train step", "L1 SAE train step, fp8 enc/dec GEMMs")
     if args.dbg == 65 and rank == 0:     # diagnostic build: cycle shares of one fused-forward iteration + in-kernel clock
         st = eng.debug_read(5, (M // 128) * 32).reshape(-1, 8)
         st = st[st[:, 3] > 0]

@@ -69,4 +69,16 @@ __device__ __forceinline__ void glds16_x2_nt(const void* sbase0, const void* sba
       : "memory");
 }
 
+// One 256-byte piece: lane l copies 4 B from sbase + voff (per lane) to LDS [dst + 4 l, dst + 4 l + 4).
+__device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %2, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(sbase), "v"(voff), "s"(dst)
+      : "memory");
+}
+
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

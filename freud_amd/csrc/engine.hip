@@ -13,6 +13,8 @@
 #include "../../include/freud_sae.h"
 #include "l1_kernels.h"
 #include "gemm256.h"
+#include "gemm256_fp8.h"
+#include "l1_fp8.h"
 
 static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
@@ -98,6 +100,11 @@ struct sae_ctx {
   float *P = nullptr, *Mom = nullptr, *Var = nullptr;
   float* G = nullptr;  // [grads (nparams) | metrics (8)]
   bf16_t *Wb = nullptr, *Wt = nullptr;
+  // SAE_PREC_FP8: encoder / decoder GEMMs on e4m3 operands (l1_fp8.h); every padded dimension is a multiple of 256 then
+  bool fp8 = false;
+  int row_pad = 128;            // M_p = round_up(M, row_pad)
+  unsigned char *x8 = nullptr, *c8 = nullptr, *W8 = nullptr, *W8t = nullptr;
+  float *scal8 = nullptr, *x8_part = nullptr;
   bool use_fused_fwd = false;
   bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
@@ -287,7 +294,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
-                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part};
+                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->ev_init)
@@ -322,13 +329,21 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   HIP_TRY(hipSetDevice(cfg->device_id));
   g_device = cfg->device_id;
 
+  if (cfg->precision != SAE_PREC_BF16 && cfg->precision != SAE_PREC_FP8)
+    return fail(SAE_ERR_INVALID, "Invalid precision: %d, must be SAE_PREC_BF16 or SAE_PREC_FP8", cfg->precision);
+  if (cfg->precision == SAE_PREC_FP8 && cfg->variant != SAE_VARIANT_L1)
+    return fail(SAE_ERR_INVALID, "fp8 encoder / decoder GEMMs exist for the L1 variant only");
+
   sae_ctx* c = new sae_ctx();
   c->cfg = *cfg;
   c->d = cfg->d_model;
   c->n = cfg->n_dict;
-  c->d_p = (int)round_up(c->d, 128);
-  c->n_p = (int)round_up(c->n, 128);
-  c->max_rows_p = round_up(cfg->max_rows, 128);
+  c->fp8 = cfg->precision == SAE_PREC_FP8;
+  const int pad = c->fp8 ? 256 : 128;      // the fp8 GEMM has 256x256 tiles only
+  c->row_pad = pad;
+  c->d_p = (int)round_up(c->d, pad);
+  c->n_p = (int)round_up(c->n, pad);
+  c->max_rows_p = round_up(cfg->max_rows, pad);
   c->nW = (int64_t)c->d_p * c->n_p;
   c->nparams = c->nW + c->n_p;
   c->topk = cfg->variant == SAE_VARIANT_TOPK;
@@ -350,8 +365,8 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   c->dw_chunk_splits = choose_splits(c->dw_chunk_rows / 128, c->n_p / 128, 2 * Mp / 64);
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; force_generic forces the
   // generic three-GEMM path (used by the tests to cover both)
-  c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1;
-  c->use_fused_fwd = (c->d_p == FF_D) && cfg->force_generic != 1 && (FF_FIXED_LDS + (int64_t)(c->n_p + FF_BN) * 4 <= 160 * 1024);
+  c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1 && !c->fp8;
+  c->use_fused_fwd = (c->d_p == FF_D) && cfg->force_generic != 1 && !c->fp8;
   {
     const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
     int sp = 256 / ntiles;
@@ -396,6 +411,14 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
+  if (c->fp8) {
+    ALLOC(c->x8, Mp * c->d_p);
+    ALLOC(c->c8, Mp * c->n_p);
+    ALLOC(c->W8, c->nW);
+    ALLOC(c->W8t, c->nW);
+    ALLOC(c->scal8, S8_COUNT * 4);
+    ALLOC(c->x8_part, 2 * 1024 * 4);
+  }
 #undef ALLOC
   {
     int rc_init = [&]() -> int {
@@ -596,6 +619,15 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   return SAE_OK;
 }
 
+template <class Epi>
+static int launch_gemm8(const Gemm8Args& g, const Epi& epi, hipStream_t s) {
+  auto kern = gemm256_fp8_kernel<Epi>;
+  LDS_ATTR(kern, G2_LDS_BYTES, g_device);
+  hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn), dim3(512), G2_LDS_BYTES, s, g, epi);
+  HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
 template <typename T> static constexpr bool x_dtype_is_bf16() { return false; }
 template <> constexpr bool x_dtype_is_bf16<bf16_t>() { return true; }
 
@@ -610,6 +642,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 64, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
   hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
                      c->Wt, d_p, n_p);
+  if (c->fp8) hipLaunchKernelGGL(fp8_cast_w_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->W8, c->W8t, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
   ev_begin(c, KID_PREP_X, s);
@@ -629,36 +662,70 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     if (!c->use_fused_fwd)
       hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha);
   }
+  if (c->fp8) {   // per-tensor power-of-two scales from the batch (max |x|, max row norm) and the bias, then x8 = e4m3(xb s_x)
+    const int sgrid = (int)((Mp / 4) < 1024 ? (Mp / 4) : 1024);
+    hipLaunchKernelGGL(fp8_x_stats_kernel, dim3(sgrid), dim3(256), 0, s, c->xb, Mp, d_p, c->x8_part);
+    hipLaunchKernelGGL(fp8_scales_kernel, dim3(1), dim3(256), 0, s, c->x8_part, sgrid, b, c->n, c->scal8);
+    const int64_t n8 = Mp * (d_p / 8);
+    int qgrid = (int)((n8 + 255) / 256);
+    if (qgrid > 2048) qgrid = 2048;
+    hipLaunchKernelGGL(fp8_quant_x_kernel, dim3(qgrid), dim3(256), 0, s, c->xb, c->x8, n8, c->scal8);
+  }
   ev_end(c, KID_PREP_X, s);
 
   int rc;
   if (c->use_fused_fwd) {
-    const int lds = FF_FIXED_LDS + (n_p + FF_BN) * 4;
+    const int lds = FF_LDS_BYTES;
     FwdFusedArgs a{};
     a.xb = c->xb_cur; a.x = x; a.Wt = c->Wt; a.bias = b; a.cnt_part = c->cnt_part; a.c = c->c; a.dxh = c->dxh;
     a.l1_part = c->l1_part; a.sq_part = c->sq_part; a.M = M; a.d = d; a.n_p = n_p; a.ntiles = n_p / FF_BN;
     a.c_rows = c->max_rows_p;
     // full workgroups (all 128 rows < M) run the mask-free instantiation; a ragged last workgroup the padded one
     const int full_wgs = (int)(M / FF_BM), all_wgs = (int)(Mp / FF_BM);
-    // opt in to > 64 KiB dynamic LDS once per instantiation and device
-    LDS_ATTR((fwd_fused_d384_kernel<T, false>), 160 * 1024, g_device);
-    LDS_ATTR((fwd_fused_d384_kernel<T, true>), 160 * 1024, g_device);
+    auto launch = [&](auto kern, int blocks, int block_offset) -> int {
+      LDS_ATTR(kern, 160 * 1024, g_device);     // opt in to > 64 KiB dynamic LDS once per instantiation and device
+      a.block_offset = block_offset;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+      return SAE_OK;
+    };
     ev_begin(c, KID_FWD_FUSED, s);
+    int rcl = SAE_OK;
     if (full_wgs > 0 && c->cfg.debug_flags == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
-      LDS_ATTR((fwd_fused_d384_kernel<T, false, true>), 160 * 1024, g_device);
-      a.block_offset = 0;
       a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
-      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false, true>), dim3(full_wgs), dim3(256), lds, s, a);
+      rcl = launch(fwd_fused_d384_kernel<T, false, true>, full_wgs, 0);
     } else if (full_wgs > 0) {
-      a.block_offset = 0;
-      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, false>), dim3(full_wgs), dim3(256), lds, s, a);
+      rcl = launch(fwd_fused_d384_kernel<T, false, false>, full_wgs, 0);
     }
-    if (all_wgs > full_wgs) {
-      a.block_offset = full_wgs;
-      hipLaunchKernelGGL((fwd_fused_d384_kernel<T, true>), dim3(all_wgs - full_wgs), dim3(256), lds, s, a);
-    }
+    if (!rcl && all_wgs > full_wgs) rcl = launch(fwd_fused_d384_kernel<T, true, false>, all_wgs - full_wgs, full_wgs);
+    if (rcl) return rcl;
     ev_end(c, KID_FWD_FUSED, s);
     HIP_TRY(hipGetLastError());
+    return SAE_OK;
+  }
+  if (c->fp8) {
+    {  // c = relu(bf16((x8 W8t) / (s_x s_w)) + b); also stored as c8 = e4m3(c s_c)
+      Gemm8Args g{};
+      g.A = c->x8; g.B = c->W8t; g.lda = d_p; g.ldb = d_p;
+      g.nbm = (int)(Mp / 256); g.nbn = n_p / 256; g.ktiles = d_p / 128;
+      EpiEnc8 e{};
+      e.c = c->c; e.c8 = c->c8; e.bias = b; e.scal8 = c->scal8; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = n_p / 128;
+      ev_begin(c, KID_ENC_FWD, s);
+      rc = launch_gemm8(g, e, s);
+      ev_end(c, KID_ENC_FWD, s);
+      if (rc) return rc;
+    }
+    {  // x_hat = bf16((c8 W8^T) / (s_c s_w)), residual, dx_hat
+      Gemm8Args g{};
+      g.A = c->c8; g.B = c->W8; g.lda = n_p; g.ldb = n_p;
+      g.nbm = (int)(Mp / 256); g.nbn = d_p / 256; g.ktiles = n_p / 128;
+      EpiDec<T> e{};
+      e.x = x; e.dxh = c->dxh; e.scal = c->scal; e.sq_part = c->sq_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = d_p / 128;
+      e.vscale = c->scal8 + S8_INV_DEC;
+      ev_begin(c, KID_DEC_FWD, s);
+      rc = launch_gemm8(g, e, s);
+      ev_end(c, KID_DEC_FWD, s);
+      if (rc) return rc;
+    }
     return SAE_OK;
   }
   {  // c = relu(x W + b)
@@ -690,7 +757,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
 template <typename T>
 static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool backward) {
   const int d = c->d, d_p = c->d_p, n_p = c->n_p;
-  const int64_t Mp = round_up(M, 128);
+  const int64_t Mp = round_up(M, c->row_pad);
   const float alpha = (float)c->cfg.recon_alpha;
   ev_begin(c, KID_STEP_TOTAL, s);
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
@@ -856,13 +923,13 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
                              int k_fixed, int kcap) {
       if (n_p <= 2048 * 12)
         hipLaunchKernelGGL(topk_select_reg_kernel<12>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M);
       else if (n_p <= 2048 * 44)
         hipLaunchKernelGGL(topk_select_reg_kernel<44>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M);
       else
         hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire, dead_mask,
-                           k_ptr, k_fixed, kcap, n, n_p);
+                           k_ptr, k_fixed, kcap, n, n_p, M);
     };
     // did_fire follows out.encoded.top_indices (train_sae.py:442), which forward() re-binds to the 4k selection when
     // cfg.multi_topk is set (topkautoencoder.py:135)
@@ -1140,6 +1207,26 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
       }
     return SAE_OK;
   }
+  if (which >= 7 && which <= 9) {   // fp8 path: 7 = the scales scal8[8]; 8 = x8 [M][d], 9 = c8 [M][n] decoded (still scaled)
+    if (!c->fp8) return fail(SAE_ERR_INVALID, "not an fp8 context");
+    if (which == 7) {
+      if (cap < S8_COUNT) return fail(SAE_ERR_INVALID, "capacity too small");
+      HIP_TRY(hipMemcpy(out, c->scal8, S8_COUNT * 4, hipMemcpyDeviceToHost));
+      return SAE_OK;
+    }
+    const int cols = which == 8 ? c->d : c->n, ld = which == 8 ? c->d_p : c->n_p;
+    if (cap < M * cols) return fail(SAE_ERR_INVALID, "capacity too small");
+    std::vector<unsigned char> tmp((size_t)M * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), which == 8 ? c->x8 : c->c8, tmp.size(), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < M; ++r)
+      for (int j = 0; j < cols; ++j) {      // OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities
+        const unsigned b = tmp[(size_t)r * ld + j], e = (b >> 3) & 15, m = b & 7;
+        float v = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m / 8.0f, (int)e - 7);
+        if (e == 15 && m == 7) v = NAN;
+        out[r * cols + j] = (b & 0x80) ? -v : v;
+      }
+    return SAE_OK;
+  }
   if (which == 6) {   // clock stamps of the fused backward (debug_flags == 66): [wg][4] as floats
     const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4 * 2;   // [0]: loop stamps per workgroup, [1]: whole-kernel cycles
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
@@ -1213,7 +1300,7 @@ extern "C" int sae_decode(sae_ctx* c, const void* latent, int latent_dtype, int6
   USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   const int d_p = c->d_p, n_p = c->n_p;
-  const int64_t Mp = round_up(M, 128);
+  const int64_t Mp = round_up(M, c->row_pad);
   bf16_t* lat = c->dpre;                       // [M_p][n_p] scratch that no forward output lives in
   const int64_t total = Mp * (int64_t)n_p;
   int grid = (int)((total + 255) / 256);

@@ -35,7 +35,10 @@ constexpr int FF_WT_BYTES = FF_BN * FF_D * 2;     // 24576: W^T tile [32 n][384 
 constexpr int FF_DEPTH = 4;                       // W^T ring: tile j (decoder), j+1 (encoder), j+2 / j+3 landing
 constexpr int FF_RING_BYTES = FF_DEPTH * FF_WT_BYTES;          // 98304
 constexpr int FF_CST_BYTES = 4 * 2 * 4096;        // per wave two [32 rows][64 cols] bf16 latent staging buffers
-constexpr int FF_FIXED_LDS = FF_RING_BYTES + FF_CST_BYTES;     // + 4 * (n_p + 32) bytes of bias
+constexpr int FF_FIXED_LDS = FF_RING_BYTES + FF_CST_BYTES;     // + the 1 KiB bias ring
+constexpr int FF_BIAS_RING_TILES = 8;                          // bias of tiles j .. j+7 (32 floats each)
+constexpr int FF_BIAS_RING_BYTES = FF_BIAS_RING_TILES * FF_BN * 4;
+constexpr int FF_LDS_BYTES = FF_FIXED_LDS + FF_BIAS_RING_BYTES;
 
 struct FwdFusedArgs {
   const bf16_t* xb;      // [M_p][384]  bf16 GEMM operand
@@ -57,6 +60,10 @@ struct FwdFusedArgs {
 // PAD: the workgroup may contain rows >= M (only the last, ragged workgroup is launched with PAD = true).
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime stamps around the halves of an iteration, summed per wave into
 // a.stamps[wg][wave][8] (+ loop s_memtime / s_memrealtime deltas in [4], [5]); the production instantiations contain no stamp.
+// The encoder bias streams through an 8-tile LDS ring (any dictionary size, e.g. the reference's default expansion_factor
+// 32 = 12 288 latents at d = 384; holding all of it in LDS capped n_p at 8160 and was not faster): two tiles (one 256-byte
+// LDS-DMA piece, issued by wave 0 right after the W^T pieces of the same iteration, i.e. older than the two latent
+// stores the counted vmcnt leaves open) every second iteration, two iterations ahead of their use.
 template <typename T, bool PAD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
   }
-  for (int i = t; i < a.n_p + FF_BN; i += 256) bias_s[i] = i < a.n_p ? a.bias[i] : 0.f;
+  if (t < 2 * FF_BN) bias_s[t] = a.bias[t];                     // tiles 0 and 1; the loop brings tiles j+2, j+3 at even j
   // ring slot 3 is read (times zero) by the first iteration's decoder phase: make it finite
   for (int i = t; i < FF_WT_BYTES / 16; i += 256)
     reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -168,7 +175,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
   // staging halves are then compile-time constants, every LDS address is a loop-invariant base register plus an
   // instruction immediate, and no per-iteration address arithmetic or register copies remain (measured with
   // s_memtime stamps: that loop-top work cost ~300 of ~2560 cycles per iteration).
-  constexpr int DIST = 11, RING = 12;
+  // (an 8-deep fragment ring: with the bias ring's extra live values a 12-deep one spills 7 registers to scratch, and 8
+  // measured the same at the C2 shape)
+  constexpr int RING = 8, DIST = RING - 1;
   // per-lane LDS base pointers: *_lo serves slots 0,1 and *_hi slots 2,3 (ds_read immediates are 16-bit)
   const char *rlo[8], *rhi[8], *tlo[8], *thi[8];
 #pragma unroll
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
     bf16x8(&cfn)[2] = (PH & 1) ? CB : CA;
     bf16x8(&cfp)[2] = (PH & 1) ? CA : CB;
     const int jt = j + 2 <= last ? j + 2 : last;                     // DMA source (clamped in the tail)
-    const float* bj = bias_s + j * FF_BN;
+    const float* bj = bias_s + (j & (FF_BIAS_RING_TILES - 1)) * FF_BN;
     char* cst_w = cst + ((PH >> 1) & 1) * 4096;                      // staging buffer filled by tiles 2t, 2t+1
     const char* cst_r = cst + (((PH >> 1) & 1) ^ 1) * 4096;          // staging buffer drained (tiles 2t-2, 2t-1)
     // the first two iterations have no finished pair to drain: their two stores go to a dummy line past the latent
@@ -253,6 +262,12 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
       if (i == FF_DMA_G0 || i == FF_DMA_G1 || i == FF_DMA_G2) dma_pair(i == FF_DMA_G0 ? 0 : (i == FF_DMA_G1 ? 1 : 2), jt, SLOT_DMA);
+      if ((PH & 1) == 0 && i == FF_DMA_G2 + 2 && w == 0) {
+        // bias of tiles j+2, j+3 (64 floats) -> ring slots (j+2) % 8, (j+3) % 8; past the end the last pair is re-copied
+        const int jb = j + 2 <= a.ntiles - 2 ? j + 2 : a.ntiles - 2;
+        glds4(a.bias + (int64_t)jb * FF_BN, (unsigned)(lane * 4),
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + FF_FIXED_LDS + ((j + 2) & (FF_BIAS_RING_TILES - 1)) * FF_BN * 4)));
+      }
       // latent element e at gap 6 + 5 (e >> 1) + 2 (e & 1): gaps 6, 8, 11, 13, ..., 41, 43 (computed from the unrolled
       // loop index itself: a lookup table made hipcc emit all 16 elements' work in ONE gap)
       if (i >= 6 && i < 46 && ((i - 6) % 5 == 0 || (i - 6) % 5 == 2)) {

@@ -41,6 +41,50 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* img, int base32, int kk, i
   else return frag_read<OP_KMAJOR>(img + (base32 >> 7) * 16384, base32 & 127, kk, lane);
 }
 
+// Epilogue shared by the bf16 and fp8 256x256 kernels: the tile leaves as two passes (sub-tile columns), each pass two
+// 128x128 sub-tiles (rows), one per 256-thread half, through fp32 LDS and the row-major functor.
+template <class Epi>
+__device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+  float* tile = reinterpret_cast<float*>(smem);
+  const int half = t >> 8, tl = t & 255;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((wn >> 1) == pass) {
+      float* dst = tile + wm * G2_SUB_FLOATS;
+      const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[row * GEMM_EPI_PITCH + 64 * (wn & 1) + 32 * j + c] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const float* src = tile + half * G2_SUB_FLOATS;
+    const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
+    epi.tile_begin(row0, col0, split);
+    {
+      const int c4 = (tl & 31) * 4;
+      typename Epi::Pre pre[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * it, col0 + c4);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = (tl >> 5) + 8 * it;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
+        epi.apply(row0 + row, col0 + c4, v, pre[it]);
+      }
+    }
+    __syncthreads();
+    epi.tile_end(tile + half * G2_SUB_FLOATS);
+    __syncthreads();
+  }
+}
+
 // g.nbm / g.nbn count 256-wide tiles here.
 template <int AMODE, int BMODE, class Epi>
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
@@ -157,42 +201,5 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
   __syncthreads();
 
-  // ---- epilogue: two passes (sub-tile columns), each pass two 128x128 sub-tiles (rows), one per 256-thread half
-  float* tile = reinterpret_cast<float*>(smem);
-  const int half = t >> 8, tl = t & 255;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if ((wn >> 1) == pass) {
-      float* dst = tile + wm * G2_SUB_FLOATS;
-      const int h = lane >> 5, c = lane & 31;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-            dst[row * GEMM_EPI_PITCH + 64 * (wn & 1) + 32 * j + c] = acc[i][j][r];
-          }
-    }
-    __syncthreads();
-    const float* src = tile + half * G2_SUB_FLOATS;
-    const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
-    epi.tile_begin(row0, col0, split);
-    {
-      const int c4 = (tl & 31) * 4;
-      typename Epi::Pre pre[16];
-#pragma unroll
-      for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * it, col0 + c4);
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = (tl >> 5) + 8 * it;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
-        epi.apply(row0 + row, col0 + c4, v, pre[it]);
-      }
-    }
-    __syncthreads();
-    epi.tile_end(tile + half * G2_SUB_FLOATS);
-    __syncthreads();
-  }
+  g2_epilogue(acc, smem, bm, bn, split, epi);
 }

@@ -1,0 +1,135 @@
+// 256x256x128 OCP-e4m3 MFMA GEMM for gfx950 (BASELINE configs[4]: fp8 encoder / decoder GEMMs of the L1 SAE).
+//
+//   C[256*bm .., 256*bn ..] = sum_k A(m,k) * B(n,k)          both operands K-contiguous bytes (fp8 e4m3fn), fp32 accumulate
+//
+// Same skeleton as gemm256.h (8 waves = 2 (M) x 4 (N), each a 128x64 output = 4x2 tiles of 32x32, LDS-DMA staging into
+// two 64 KiB stages, K loop rotated around its barrier, epilogue through the row-major functors), with the K tile kept
+// at 128 BYTES per row, i.e. 128 fp8 elements: one tile is two v_mfma_f32_32x32x64_f8f6f4 steps (64 cycles each, twice
+// the cycles of the bf16 32x32x16 at four times the K: 2x the bf16 rate) instead of four bf16 steps, so staging bytes,
+// LDS reads and barriers per MFMA CYCLE are those of the bf16 kernel while the FLOPs double.
+//   Fragment of the 32x32x64 fp8 MFMA: lane (row = lane & 31, half h = lane >> 5) holds the 32 bytes k = 32 h .. 32 h + 31
+//   of its row -- two ds_read_b128 of the chunks 4 s + 2 h, 4 s + 2 h + 1 of the XOR-swizzled [256][128 B] image (the
+//   swizzle of gemm.h is conflict-free for any logical chunk: the 16 lanes of a ds_read_b128 group differ in (row & 1,
+//   (row >> 1) & 7)).  A and B use the same lane -> k map, so the hardware's internal k order does not matter.
+//   Registers: the A fragments are single-buffered (A fragment i of the next step is requested right after its last
+//   MFMA of this step issued: 8 MFMAs = 512 cycles of lead), the B fragments double-buffered: 64 fragment registers
+//   next to 128 accumulators keep two waves per SIMD.
+// The unscaled instruction is reached through the scaled builtin with zero scales (hipcc selects v_mfma_f32_32x32x64_f8f6f4).
+#pragma once
+#include "gemm256.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+struct Gemm8Args {
+  const unsigned char* A;   // [rows_a][lda] fp8, K contiguous
+  const unsigned char* B;   // [rows_b][ldb] fp8, K contiguous
+  int64_t lda, ldb;         // bytes (= elements)
+  int nbm, nbn;             // 256-wide output tiles
+  int ktiles;               // 128-element K tiles
+};
+
+// source byte offset of the 16 B that lane `lane` of DMA piece p (0..31) moves (piece = rows 8p..8p+7 of the image)
+__device__ __forceinline__ unsigned g8_src_off(int p, int lane, int64_t ld) {
+  const int r = 8 * p + (lane >> 3), pc = lane & 7;
+  return (unsigned)(r * ld + ((pc ^ ((r >> 1) & 7)) << 4));
+}
+
+// 32-byte fragment: rows base32 .. base32+31, K step s (0, 1) of the 128-byte tile
+__device__ __forceinline__ i32x8 g8_frag(const char* img, int base32, int s, int lane) {
+  const int r = base32 + (lane & 31), c0 = 4 * s + 2 * (lane >> 5), sw = (r >> 1) & 7;
+  const u32x4 lo = *reinterpret_cast<const u32x4*>(img + r * 128 + ((c0 ^ sw) << 4));
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(img + r * 128 + (((c0 + 1) ^ sw) << 4));
+  i32x8 v;
+  v[0] = (int)lo[0]; v[1] = (int)lo[1]; v[2] = (int)lo[2]; v[3] = (int)lo[3];
+  v[4] = (int)hi[0]; v[5] = (int)hi[1]; v[6] = (int)hi[2]; v[7] = (int)hi[3];
+  return v;
+}
+
+template <class Epi>
+__global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+  const int nblk = g.nbm * g.nbn;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  int bm, bn;
+  tile_coords(id, g.nbm, g.nbn, bm, bn);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned char* a_base = g.A + (int64_t)(bm * G2_BM) * g.lda;
+  const unsigned char* b_base = g.B + (int64_t)(bn * G2_BN) * g.ldb;
+  unsigned voff_a[4], voff_b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    voff_a[q] = g8_src_off(4 * w + q, lane, g.lda);
+    voff_b[q] = g8_src_off(4 * w + q, lane, g.ldb);
+  }
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned piece0 = (unsigned)__builtin_amdgcn_readfirstlane(4 * w * 1024);
+  auto issue = [&](int kt, int stage, int q) {
+    const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
+    glds16_x2(a_base + (int64_t)kt * 128, b_base + (int64_t)kt * 128, voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
+  };
+
+  const int kt_last = g.ktiles - 1;
+  auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(clampk(1), 1, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  i32x8 fa[4], fb[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = g8_frag(smem, 128 * wm + 32 * i, 0, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+
+  int cur = 0;
+  for (int kt = 0; kt < g.ktiles; ++kt) {
+    const char* sa = smem + cur * G2_STAGE_BYTES;
+    const char* sb = sa + G2_OPER_BYTES;
+    const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
+    const char* nb = na + G2_OPER_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // where the NEXT step's fragments come from: step 1 of this tile, or step 0 of the next tile (other stage)
+      const char* xa = s == 0 ? sa : na;
+      const char* xb = s == 0 ? sb : nb;
+      const int xs = s == 0 ? 1 : 0;
+      if (s == 0) {            // second half of tile kt+1's pieces (its first half left right after the last hand-over)
+        issue(clampk(kt + 1), cur ^ 1, 2);
+        issue(clampk(kt + 1), cur ^ 1, 3);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+        __syncthreads();                                    // ... and everybody's; every read of this stage has returned
+        issue(clampk(kt + 2), cur, 0);
+        issue(clampk(kt + 2), cur, 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[xs][j] = g8_frag(xb, 64 * wn + 32 * j, xs, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[s][j], acc[i][j], 0, 0, 0, 0, 0, 0);
+        fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);     // its registers are free: next step's fragment i
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
+  __syncthreads();
+
+  g2_epilogue(acc, smem, bm, bn, 0, epi);
+}

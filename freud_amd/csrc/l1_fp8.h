@@ -1,0 +1,188 @@
+// fp8 (OCP e4m3fn) operand preparation and epilogues for the encoder / decoder GEMMs of the L1 SAE
+// (BASELINE configs[4]: "fp8 MFMA enc/dec with bf16 accumulate"; reference arithmetic being replaced:
+// src/models/l1autoencoder.py:74,84).
+//
+// Quantisation is per tensor with POWER-OF-TWO scales (exact to apply and to undo):
+//   W8 = e4m3(W * 2^8)            column-normalised |w| <= 1, so 256 |w| <= 256 < 448 (e4m3 max): never saturates;
+//   x8 = e4m3(bf16(x) * s_x)      s_x = 2^floor(log2(448 / max|x|)) from an amax pass over the batch;
+//   c8 = e4m3(c * s_c)            s_c = 2^floor(log2(448 / bound)), bound = max_row ||x_row||_2 + max(0, max_j b_j) >= every
+//                                 c_mj (Cauchy-Schwarz with unit-norm columns): known BEFORE the encoder GEMM runs, so the
+//                                 latent is quantised in that GEMM's epilogue, and it cannot saturate either.
+// The MFMA accumulates the scaled products in fp32; the epilogue multiplies by 1 / (s_a s_b) and rounds to bf16 where the
+// bf16 path rounds (pre-activation before the fp32 bias add; x_hat).  The latent is stored twice: bf16 for the (bf16)
+// backward GEMMs, e4m3 for the decoder GEMM.  The backward, the fp32 master weights and the optimizer are unchanged.
+#pragma once
+#include "l1_kernels.h"
+
+constexpr float FP8_E4M3_MAX = 448.0f;
+constexpr float FP8_W_SCALE = 256.0f;
+
+// scal8: [0] s_x  [1] 1/(s_x s_w)  [2] s_c  [3] 1/(s_c s_w)  [4] max|x|  [5] latent bound
+enum { S8_SX = 0, S8_INV_ENC = 1, S8_SC = 2, S8_INV_DEC = 3, S8_AMAX_X = 4, S8_C_BOUND = 5, S8_COUNT = 8 };
+
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+  unsigned r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return r;
+}
+
+// largest power of two p with p * v <= 448 (v > 0), i.e. 2^floor(log2(448 / v)); exact (frexp, no libm log)
+__device__ __forceinline__ float fp8_pow2_scale(float v) {
+  if (!(v > 0.f)) return 1.0f;
+  int e;
+  (void)frexpf(FP8_E4M3_MAX / v, &e);        // 448 / v = m 2^e, m in [0.5, 1)  ->  floor(log2) = e - 1
+  e -= 1;
+  if (e > 100) e = 100;
+  if (e < -100) e = -100;
+  return ldexpf(1.0f, e);
+}
+
+// per-block partials of max |x| and max row sum of squares over the bf16 GEMM copy xb[M_p][d_p] (padding is zero);
+// one wave per row, 4 rows per block pass
+__global__ __launch_bounds__(256) void fp8_x_stats_kernel(const bf16_t* __restrict__ xb, int64_t M_p, int d_p,
+                                                          float* __restrict__ part /* [grid][2] */) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float amax = 0.f, rmax = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < M_p; row += (int64_t)gridDim.x * 4) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(xb + row * d_p);
+    float ss = 0.f;
+    for (int i = lane; i < d_p / 8; i += 64) {
+      const bf16x8 v = p[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        amax = fmaxf(amax, fabsf(f));
+        ss += f * f;
+      }
+    }
+    ss = wave_sum(ss);
+    rmax = fmaxf(rmax, ss);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if (lane == 0) {
+    red[0][w] = amax;
+    red[1][w] = rmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    part[2 * blockIdx.x + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void fp8_scales_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ bias,
+                                                         int n, float* __restrict__ scal8) {
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float amax = 0.f, rmax = 0.f, bmax = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    amax = fmaxf(amax, part[2 * i]);
+    rmax = fmaxf(rmax, part[2 * i + 1]);
+  }
+  for (int i = threadIdx.x; i < n; i += 256) bmax = fmaxf(bmax, bias[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, o, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+  }
+  if (lane == 0) {
+    red[0][w] = amax;
+    red[1][w] = rmax;
+    red[2][w] = bmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    rmax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    bmax = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    // the GEMM sees the QUANTISED operands: every |x8| / s_x and |w8| / s_w may exceed its source by 2^-4 relative, so
+    // the product of the two norms by up to 1.0625^2 = 1.13 (plus the bf16 rounding of the result): 15 % headroom
+    const float bound = (sqrtf(rmax) + bmax) * 1.15f;
+    const float sx = fp8_pow2_scale(amax), sc = fp8_pow2_scale(bound);
+    scal8[S8_SX] = sx;
+    scal8[S8_INV_ENC] = 1.0f / (sx * FP8_W_SCALE);
+    scal8[S8_SC] = sc;
+    scal8[S8_INV_DEC] = 1.0f / (sc * FP8_W_SCALE);
+    scal8[S8_AMAX_X] = amax;
+    scal8[S8_C_BOUND] = bound;
+  }
+}
+
+// x8[M_p][d_p] = e4m3(xb * s_x)
+__global__ __launch_bounds__(256) void fp8_quant_x_kernel(const bf16_t* __restrict__ xb, unsigned char* __restrict__ x8, int64_t n8,
+                                                          const float* __restrict__ scal8) {
+  const float sx = scal8[S8_SX];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(xb)[i];
+    uint2 o;
+    o.x = pack4_fp8((float)v[0] * sx, (float)v[1] * sx, (float)v[2] * sx, (float)v[3] * sx);
+    o.y = pack4_fp8((float)v[4] * sx, (float)v[5] * sx, (float)v[6] * sx, (float)v[7] * sx);
+    reinterpret_cast<uint2*>(x8)[i] = o;
+  }
+}
+
+// fp8 copies of the (already normalised) fp32 master weights: W8[d_p][n_p] (K = n contiguous, decoder operand) and
+// W8t[n_p][d_p] (K = d contiguous, encoder operand), both e4m3(W * 2^8).  Grid (n_p/64, d_p/64), one 64x64 tile.
+__global__ __launch_bounds__(256) void fp8_cast_w_kernel(const float* __restrict__ W, unsigned char* __restrict__ W8,
+                                                         unsigned char* __restrict__ W8t, int d_p, int n_p) {
+  __shared__ __attribute__((aligned(16))) unsigned char tT[64][80];   // [col][row] of the tile
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;                 // thread -> 4 columns 4 tx.., rows ty, ty+16, ...
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 16 * i;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(r0 + r) * n_p + c0 + 4 * tx);
+    const unsigned pk = pack4_fp8(v[0] * FP8_W_SCALE, v[1] * FP8_W_SCALE, v[2] * FP8_W_SCALE, v[3] * FP8_W_SCALE);
+    *reinterpret_cast<unsigned*>(W8 + (int64_t)(r0 + r) * n_p + c0 + 4 * tx) = pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tT[4 * tx + j][r] = (unsigned char)(pk >> (8 * j));
+  }
+  __syncthreads();
+  // 64 columns x 64 rows -> W8t[col][r0 .. r0+64): 4 pieces of 16 B per column, 256 pieces
+  const int c = t >> 2, sgm = t & 3;
+  *reinterpret_cast<u32x4*>(W8t + (int64_t)(c0 + c) * d_p + r0 + sgm * 16) = *reinterpret_cast<const u32x4*>(&tT[c][sgm * 16]);
+}
+
+// encoder epilogue: c = relu(bf16(acc / (s_x s_w)) + b) (l1autoencoder.py:74), rows >= M forced to 0;
+// stored as bf16 (backward) and as e4m3(c s_c) (decoder operand); L1 partial sum per tile.
+struct EpiEnc8 {
+  bf16_t* c;            // [M_p][n_p]
+  unsigned char* c8;    // [M_p][n_p]
+  const float* bias;    // [n_p]
+  const float* scal8;
+  float* l1_part;       // [tiles]
+  int64_t M;
+  int n_p, nbn;
+  float l1, inv, sc;
+  int tile_id;
+  __device__ void tile_begin(int row0, int col0, int) {
+    l1 = 0.f;
+    inv = scal8[S8_INV_ENC];
+    sc = scal8[S8_SC];
+    tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
+  }
+  struct Pre { f32x4 b; };
+  __device__ Pre prefetch(int, int col) const { return Pre{*reinterpret_cast<const f32x4*>(bias + col)}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
+    const f32x4 b = pre.b;
+    bf16x4 o;
+    float cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cv[j] = fmaxf(bf16_round(v[j] * inv) + b[j], 0.f);
+      if (row >= M) cv[j] = 0.f;
+      l1 += cv[j];
+      o[j] = (bf16_t)cv[j];
+    }
+    EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
+    EPI_STORE(reinterpret_cast<unsigned*>(c8 + (int64_t)row * n_p + col), pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc));
+  }
+  __device__ void tile_end(float* scratch) {
+    const float s = block_sum_256(l1, scratch);
+    if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
+  }
+};

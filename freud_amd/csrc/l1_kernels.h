@@ -188,11 +188,13 @@ struct EpiDec {
   float* sq_part;       // [tiles][2]
   int64_t M;
   int d, d_p, nbn;
-  float sq, plain, scale;
+  const float* vscale;  // fp8 decoder GEMM: *vscale = 1 / (s_c s_w) undoes the operand scales (null: 1)
+  float sq, plain, scale, vs;
   int tile_id;
   __device__ void tile_begin(int row0, int col0, int) {
     sq = plain = 0.f;
     scale = scal[1];
+    vs = vscale ? *vscale : 1.0f;
     tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
   }
   struct Pre { float xv[4]; };
@@ -209,7 +211,7 @@ struct EpiDec {
       float g = 0.f;
       if (row < M && col + j < d) {
         const float xv = pre.xv[j];
-        const float e = bf16_round(v[j]) - xv;
+        const float e = bf16_round(v[j] * vs) - xv;
         plain += e * e;
         if (xv != -1.0f) {
           sq += e * e;

@@ -115,7 +115,7 @@ struct EpiTopkEnc {
 __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
                                                            int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                            const unsigned char* __restrict__ dead, const int* __restrict__ k_ptr,
-                                                           int k_fixed, int kcap, int n, int n_p) {
+                                                           int k_fixed, int kcap, int n, int n_p, int64_t M) {
   if (k_ptr && *k_ptr <= 0) return;     // AuxK pass without dead latents: nothing downstream reads its outputs
   __shared__ int hist[256];
   __shared__ int sel_hi, need, sel_lo, ntie;
@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
   const unsigned short* p = reinterpret_cast<const unsigned short*>(pre + row * n_p);
   unsigned short* o = reinterpret_cast<unsigned short*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
-  if (k <= 0) {
+  if (k <= 0 || row >= M) {             // padding rows select nothing (and must not mark any latent as fired)
     for (int i = t; i < n_p; i += 256) o[i] = 0;
+    for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
   auto key = [&](int i) -> int {       // 16-bit key; -1 = not a candidate
@@ -220,9 +221,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
 // value; non-candidates -- padding columns, or living latents in the AuxK pass -- become key 0).  The k-th largest
 // key is found by a binary search on the key value; each probe counts "key >= T" on two packed keys per
 // instruction: ((w | 0x80008000) - T*0x00010001) has bit 15 / 31 set exactly where the half is >= T.
-// Elements > T are selected; ties at T are taken in (thread, register) order up to k; exact zeros only enter the
-// selection when fewer than k positive candidates exist (then in the same order).  Writes the masked dense row,
-// the index list and did_fire.  Deterministic.
+// Elements > T are selected; ties at T are taken in increasing column order up to k (like the radix kernel above: the
+// engine's tie rule is "lowest column first", what a stable descending sort takes); exact zeros only enter the selection
+// when fewer than k positive candidates exist (then in the same order).  Writes the masked dense row, the index list
+// (in (thread, register) order -- the list is a set) and did_fire.  Deterministic.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int block_excl_scan_256(int v, int* wave_tot /* >= 4 ints LDS */, int* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
-                                                               int n_p) {
+                                                               int n_p, int64_t M) {
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
@@ -257,6 +259,11 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   const u32x4* src = reinterpret_cast<const u32x4*>(pre + row * n_p);
   u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
+  if (row >= M) {                       // padding rows (all-zero pre) select nothing and must not mark any latent as fired
+    for (int g = t; g < nvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
+    for (int j = t; j < kcap; j += 256) ti[j] = -1;
+    return;
+  }
 
   // ---- load + candidate filter.  keys[v][q] packs columns 8 g + 2 q (low half) and 8 g + 2 q + 1 (high half)
   u32x4 keys[MAXV];
@@ -326,7 +333,10 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   }
   const int n_gt = T >= 0x8000u ? 0 : (T == 0 ? npos : count_ge(T + 1));
   const int need_ties = k - n_gt;                  // elements equal to T to take (for T == 0: candidate zeros)
-  // ---- ties in (thread, register) order
+  // ---- ties at T in INCREASING COLUMN order (the rule of all three select kernels: what a stable descending sort
+  // takes).  Column = 8 (256 v + t) + e, i.e. vector-row v first, then thread, then element.  Most rows take every
+  // element equal to T (no boundary tie): only a row with more ties than it needs ranks them, one block scan per
+  // vector-row (block-uniform branch).
   int tie_l = 0;
 #pragma unroll
   for (int v = 0; v < MAXV; ++v)
@@ -336,27 +346,37 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       tie_l += (key == T && ((cand[v] >> e) & 1u)) ? 1 : 0;
     }
   int tie_tot;
-  const int tie_before = block_excl_scan_256(tie_l, sc, &tie_tot);
-  int tie_budget = need_ties - tie_before;         // how many of this thread's ties are taken
+  (void)block_excl_scan_256(tie_l, sc, &tie_tot);
+  const bool rank_ties = tie_tot > need_ties;
   // ---- emit
-  int sel_l = 0;
+  int sel_l = 0, tie_base = 0;
   unsigned selmask[MAXV];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
-    unsigned sm = 0;
+    unsigned gm = 0, tm = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const unsigned key = (keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
       const bool c = (cand[v] >> e) & 1u;
-      bool take = c && key > T;
-      if (c && key == T) {
-        take = tie_budget > 0;
-        tie_budget -= 1;
-      }
-      sm |= take ? (1u << e) : 0u;
+      gm |= (c && key > T) ? (1u << e) : 0u;
+      tm |= (c && key == T) ? (1u << e) : 0u;
     }
-    selmask[v] = sm;
-    sel_l += __popc(sm);
+    if (rank_ties) {
+      int row_tot;
+      const int before = block_excl_scan_256(__popc(tm), sc, &row_tot);
+      int budget = need_ties - tie_base - before;      // ties of this vector this thread may still take
+      tie_base += row_tot;
+      unsigned keep = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((tm >> e) & 1u) {
+          keep |= budget > 0 ? (1u << e) : 0u;
+          budget -= 1;
+        }
+      tm = keep;
+    }
+    selmask[v] = gm | tm;
+    sel_l += __popc(selmask[v]);
   }
   int sel_tot;
   int pos = block_excl_scan_256(sel_l, sc, &sel_tot);

@@ -36,6 +36,34 @@ def _r(t: torch.Tensor) -> torch.Tensor:
     return t.to(BF16).to(torch.float32)
 
 
+# How a bf16 x bf16 matmul is evaluated.  "native": torch's own CPU bf16 kernel (oneDNN) -- what the reference runs, and
+# what the golden fixtures pin bit for bit IN THE BUILD CONTAINER.  Its result is host dependent: on the GPU box's host
+# (other ISA extensions, other oneDNN kernels) the same call on a [512 x 40960] operand moved a gradient norm by 0.6 %.
+# "fp32": the definition both follow -- products of the bf16 operands accumulated in fp32, ONE rounding of the result to
+# bf16 -- evaluated with an fp32 matmul: host independent up to fp32 summation order.  Parity tests at sizes beyond the
+# fixtures use "fp32" (tests/conftest.py sets it for the GPU suite); tests/test_oracle.py checks the two agree to bf16
+# round-off on the fixtures.
+MATMUL_MODE = "native"
+# The same for the gradient norm of clip_grad_norm_: "native" = torch's fp32 vector_norm (bit-exact against the fixtures
+# here; on the GPU box's host the fp32 reduction over a 52 M element gradient read 0.6 % low), "float64" = the norm taken
+# in double and rounded to fp32 once.
+NORM_MODE = "native"
+
+
+def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16 [.., k] @ bf16 [k, n] -> bf16."""
+    if MATMUL_MODE == "native":
+        return a @ b
+    return (a.to(torch.float32) @ b.to(torch.float32)).to(BF16)
+
+
+def _linear(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """bf16 addmm of nn.Linear under autocast: bf16(a @ w^T + bias), one rounding."""
+    if MATMUL_MODE == "native":
+        return torch.nn.functional.linear(a, w, bias)
+    return (a.to(torch.float32) @ w.to(torch.float32).t() + bias.to(torch.float32)).to(BF16)
+
+
 def get_n_dict_components(activation_size: int, expansion_factor: int, n_dict_components: int) -> int:
     """src/utils/models.py:1-6."""
     if n_dict_components == 0:
@@ -52,8 +80,36 @@ def normalize_columns(W: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.normalize(W, dim=0)
 
 
+E4M3_MAX = 448.0
+FP8_W_SCALE = 256.0
+
+
+def _q8(t: torch.Tensor) -> torch.Tensor:
+    """Round to OCP e4m3fn (round to nearest even, subnormals kept) and back to fp32."""
+    return t.to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _pow2_scale(v: float) -> float:
+    """Largest power of two p with p * v <= 448, i.e. 2^floor(log2(448 / v)) (1 for v <= 0)."""
+    if not v > 0.0:
+        return 1.0
+    q = torch.tensor(E4M3_MAX, dtype=torch.float32) / torch.tensor(v, dtype=torch.float32)
+    _, e = math.frexp(float(q))
+    return math.ldexp(1.0, max(-100, min(100, e - 1)))
+
+
+def fp8_scales(x: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
+    """Per-tensor power-of-two scales of the fp8 forward (BASELINE configs[4]; freud_amd/csrc/l1_fp8.h): s_x from max |x|
+    of the bf16 activations; s_c from the bound (max_row ||x_row||_2 + max(0, max b)) * 1.15 >= every latent."""
+    xb = x.to(BF16).to(torch.float32)
+    amax = float(xb.abs().max())
+    rmax = float((xb * xb).sum(dim=1).max())
+    bound = (torch.sqrt(torch.tensor(rmax, dtype=torch.float32)) + max(float(b.max()), 0.0)) * torch.tensor(1.15, dtype=torch.float32)
+    return _pow2_scale(amax), _pow2_scale(float(bound))
+
+
 def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: float,
-               autocast: bool = True) -> Dict[str, torch.Tensor]:
+               autocast: bool = True, precision: str = "bf16") -> Dict[str, torch.Tensor]:
     """Forward of L1AutoEncoder on flat rows.  ``W`` must already be column-normalised.
 
     src/models/l1autoencoder.py:69-95 (+ mse_loss :29-36).  With ``autocast`` the dtype flow
@@ -63,15 +119,28 @@ def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: f
       x_hat = bf16( bf16(c) @ bf16(W)^T )          GEMM 2        (:84)
       l1    = mean_rows( sum_j |c| )               fp32          (:85)
       recon = alpha * mean_{x != -1}( (fp32(x_hat) - x)^2 )      (:86, :29-36)
+
+    precision="fp8" (BASELINE configs[4], not a reference mode): the two GEMMs take OCP e4m3 operands
+      x8 = e4m3(bf16(x) s_x), W8 = e4m3(W 2^8), c8 = e4m3(c s_c)   (power-of-two per-tensor scales, fp8_scales()),
+      pre = bf16((x8 @ W8) / (s_x 2^8)),  x_hat = bf16((c8 @ W8^T) / (s_c 2^8)),  fp32 accumulation,
+    everything else (bias add, ReLU, losses, and the backward on the bf16 latent) as in the bf16 path.
     """
     x = x.to(torch.float32)
     M = x.shape[0]
-    if autocast:
+    if precision == "fp8":
+        sx, sc = fp8_scales(x, b)
+        x8 = _q8(x.to(BF16).to(torch.float32) * sx)
+        W8 = _q8(W * FP8_W_SCALE)
+        pre = _r((x8 @ W8) / (sx * FP8_W_SCALE))
+        c = torch.relu(pre + b)
+        c8 = _q8(c * sc)
+        x_hat = _r((c8 @ W8.t()) / (sc * FP8_W_SCALE))
+    elif autocast:
         xb, Wb = x.to(BF16), W.to(BF16)
-        pre = (xb @ Wb).to(torch.float32)
+        pre = _mm(xb, Wb).to(torch.float32)
         c = torch.relu(pre + b)
         cb = c.to(BF16)
-        x_hat = (cb @ Wb.t()).to(torch.float32)
+        x_hat = _mm(cb, Wb.t()).to(torch.float32)
     else:
         c = torch.relu(x @ W + b)
         x_hat = c @ W.t()
@@ -83,8 +152,11 @@ def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: f
     l1 = c.abs().sum(dim=1).mean()
     recon = recon_alpha * mse_masked
     mse_plain = ((x_hat - x) ** 2).mean()                # return_mse path (:93-94), unmasked
-    return {"c": c, "x_hat": x_hat, "l1_loss": l1, "reconstruction_loss": recon,
-            "mse": mse_plain, "keep": keep, "count": count, "diff": diff, "sq_sum": sq_sum}
+    out = {"c": c, "x_hat": x_hat, "l1_loss": l1, "reconstruction_loss": recon,
+           "mse": mse_plain, "keep": keep, "count": count, "diff": diff, "sq_sum": sq_sum}
+    if precision == "fp8":
+        out.update({"x8": x8, "c8": c8, "W8": W8, "s_x": sx, "s_c": sc})
+    return out
 
 
 def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str, torch.Tensor],
@@ -108,10 +180,10 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
     if autocast:
         xb, Wb, cb = x.to(BF16), W.to(BF16), c.to(BF16)
         dxb = dx_hat.to(BF16)
-        dc = (dxb @ Wb).to(torch.float32) + torch.sign(c) / M
+        dc = _mm(dxb, Wb).to(torch.float32) + torch.sign(c) / M
         dpre = dc * gate
-        dW_dec = dxb.t() @ cb                            # bf16 [d, n]
-        dW_enc = xb.t() @ dpre.to(BF16)                  # bf16 [d, n]
+        dW_dec = _mm(dxb.t(), cb)                        # bf16 [d, n]
+        dW_enc = _mm(xb.t(), dpre.to(BF16))              # bf16 [d, n]
         dW = (dW_dec + dW_enc).to(torch.float32)         # summed in bf16 at the shared cast
     else:
         dc = dx_hat @ W + torch.sign(c) / M
@@ -126,7 +198,8 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
 # --------------------------------------------------------------------------------------
 def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_dec: torch.Tensor,
                  b_dec: torch.Tensor, k: int, dead_mask: Optional[torch.Tensor] = None,
-                 auxk_alpha: float = 0.0, autocast: bool = True, multi_topk: bool = False) -> Dict[str, torch.Tensor]:
+                 auxk_alpha: float = 0.0, autocast: bool = True, multi_topk: bool = False,
+                 stable_ties: bool = False) -> Dict[str, torch.Tensor]:
     """src/models/topkautoencoder.py:72-151 on x3 = [B, T, d] (B matters for x.mean(0), :104).
 
       pre   = relu( (x - b_dec) @ W_enc^T + b_enc )                   (:72-77)
@@ -138,22 +211,33 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
               are then the 4k ones (the names are re-bound at :135-136), which is what did_fire sees (train_sae.py:442)
     autocast: ``encoder`` is a Linear -> bf16 addmm (bias included, output bf16); relu keeps bf16;
     top_acts bf16; scatter buffer bf16; decode matmul bf16 -> + b_dec (fp32) -> fp32.
+
+    stable_ties: ``torch.topk`` has no rule for equal values at the k-th place (bf16 pre-activations tie there in
+    4-50 % of rows) and the reference takes whatever its partial sort leaves.  With stable_ties=True equal values are
+    taken lowest column first (a stable descending sort) -- the HIP engine's rule -- so that a batch WITH boundary
+    ties can be compared at the arithmetic tolerance; on rows without a boundary tie both selections are the same set.
     """
     B, T, d = x3.shape
     x = x3.reshape(B * T, d).to(torch.float32)
     sae_in = x - b_dec
     if autocast:
-        pre = torch.nn.functional.linear(sae_in.to(BF16), W_enc.to(BF16), b_enc.to(BF16))
+        pre = _linear(sae_in.to(BF16), W_enc.to(BF16), b_enc.to(BF16))
         pre = torch.relu(pre)                                            # bf16
     else:
         pre = torch.relu(sae_in @ W_enc.t() + b_enc)
-    top_acts, top_idx = pre.topk(k, dim=-1, sorted=False)
+    def select(lat, kk):
+        if not stable_ties:
+            return lat.topk(kk, dim=-1, sorted=False)
+        idx = torch.sort(lat.to(torch.float32), dim=-1, descending=True, stable=True).indices[..., :kk]
+        return torch.gather(lat, -1, idx), idx
+
+    top_acts, top_idx = select(pre, k)
 
     def decode(acts, idx):
         buf = acts.new_zeros(acts.shape[:-1] + (W_dec.shape[0],))
         dense = buf.scatter_(dim=-1, index=idx, src=acts)
         if autocast:
-            y = (dense @ W_dec.to(BF16)).to(torch.float32)
+            y = _mm(dense, W_dec.to(BF16)).to(torch.float32)
         else:
             y = dense @ W_dec
         return y + b_dec, dense
@@ -173,7 +257,7 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
         k_aux = min(k_aux, num_dead)
         neg_inf = torch.tensor(-float("inf"), dtype=pre.dtype)
         aux_lat = torch.where(dead_mask[None], pre, neg_inf)
-        aux_acts, aux_idx = aux_lat.topk(k_aux, dim=-1, sorted=False)
+        aux_acts, aux_idx = select(aux_lat, k_aux)
         e_hat, aux_dense = decode(aux_acts, aux_idx)
         auxk = scale * ((e_hat - e) ** 2).sum() / total_variance
         out.update({"aux_acts": aux_acts, "aux_indices": aux_idx, "e_hat": e_hat,
@@ -183,7 +267,7 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
     out["fvu"] = (e ** 2).sum() / total_variance
     out["auxk_loss"] = auxk * auxk_alpha
     if multi_topk:
-        m_acts, m_idx = pre.topk(4 * k, dim=-1, sorted=False)
+        m_acts, m_idx = select(pre, 4 * k)
         x_hat_m, m_dense = decode(m_acts, m_idx)
         e_m = x_hat_m - x
         out["multi_topk_fvu"] = (e_m ** 2).sum() / total_variance
@@ -220,8 +304,8 @@ def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_
     def dec_bwd(dy, dense):
         if autocast:
             dyb = dy.to(BF16)
-            dW = (dense.to(BF16).t() @ dyb).to(torch.float32)            # [n, d]
-            ddense = (dyb @ W_dec.to(BF16).t()).to(torch.float32)        # [M, n]
+            dW = _mm(dense.to(BF16).t(), dyb).to(torch.float32)          # [n, d]
+            ddense = _mm(dyb, W_dec.to(BF16).t()).to(torch.float32)      # [M, n]
         else:
             dW = dense.t() @ dy
             ddense = dy @ W_dec.t()
@@ -250,8 +334,8 @@ def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_
     sae_in = x - b_dec
     if autocast:
         dpb = dpre.to(BF16)
-        dW_enc = (dpb.t() @ sae_in.to(BF16)).to(torch.float32)           # [n, d]
-        dsae_in = (dpb @ W_enc.to(BF16)).to(torch.float32)               # [M, d]
+        dW_enc = _mm(dpb.t(), sae_in.to(BF16)).to(torch.float32)         # [n, d]
+        dsae_in = _mm(dpb, W_enc.to(BF16)).to(torch.float32)             # [M, d]
         db_enc = _r(dpb.to(torch.float32).sum(0))                        # Linear's bias is a bf16 cast: bf16 gradient
     else:
         dW_enc = dpre.t() @ sae_in
@@ -267,7 +351,10 @@ def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_
 def clip_grad_norm(grads, max_norm: float) -> Tuple[torch.Tensor, list]:
     """torch.nn.utils.clip_grad_norm_ (train_sae.py:449): total 2-norm over all grads;
     coef = clamp(max_norm / (norm + 1e-6), max=1); every grad multiplied by coef."""
-    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in grads]), 2.0)
+    if NORM_MODE == "native":
+        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in grads]), 2.0)
+    else:
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).to(torch.float32)
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     return total, [g * coef for g in grads]
 
@@ -347,11 +434,11 @@ def lr_at(step_index: int, base_lr: float, scheduler: str, steps: int, num_warmu
 # --------------------------------------------------------------------------------------
 def l1_train_step(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, st: OptState, *, recon_alpha: float,
                   lr: float, clip_thresh: float, optimizer: str = "radam", weight_decay: float = 0.0,
-                  autocast: bool = True) -> Dict[str, torch.Tensor]:
+                  autocast: bool = True, precision: str = "bf16") -> Dict[str, torch.Tensor]:
     """One iteration of train_sae.py:429-451 for the L1 variant.  W, b updated in place
     (W is first column-normalised in place, as encode() does)."""
     W.copy_(normalize_columns(W))
-    fwd = l1_forward(x, W, b, recon_alpha, autocast)
+    fwd = l1_forward(x, W, b, recon_alpha, autocast, precision)
     dW, db = l1_backward(x, W, b, fwd, recon_alpha, autocast)
     gnorm, (db_c, dW_c) = clip_grad_norm([db, dW], clip_thresh)
     params = {"encoder_bias": b, "decoder.weight": W}
@@ -369,11 +456,11 @@ def l1_train_step(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, st: OptStat
 def topk_train_step(x3: torch.Tensor, P: Dict[str, torch.Tensor], st: OptState, *, k: int, lr: float,
                     clip_thresh: float, dead_mask: Optional[torch.Tensor] = None, auxk_alpha: float = 0.0,
                     optimizer: str = "adam", weight_decay: float = 0.0,
-                    autocast: bool = True, multi_topk: bool = False) -> Dict[str, torch.Tensor]:
+                    autocast: bool = True, multi_topk: bool = False, stable_ties: bool = False) -> Dict[str, torch.Tensor]:
     """One iteration of train_sae.py:429-451 for the TopK variant.  P holds the reference's
     state_dict keys W_dec, b_dec, encoder.weight, encoder.bias (updated in place)."""
     fwd = topk_forward(x3, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k,
-                       dead_mask, auxk_alpha, autocast, multi_topk)
+                       dead_mask, auxk_alpha, autocast, multi_topk, stable_ties)
     g = topk_backward(x3, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], fwd,
                       auxk_alpha, autocast)
     # nn.Module.parameters() order: the module's own parameters (W_dec, b_dec) come before its children's (encoder.*)

@@ -125,3 +125,54 @@ def test_lr_schedules_match_trainloop_fixture(golden_dir):
         for s, v in lrs:
             want = O.lr_at(s, cfg["lr"], cfg["scheduler"], cfg["steps"], cfg["scheduler_params"].get("num_warmup_steps", 0))
             assert v == pytest.approx(want, rel=1e-9, abs=1e-15)
+
+
+@pytest.mark.parametrize("name", TOPK_CASES)
+def test_stable_tie_rule_equals_reference_on_tie_free_rows(golden_dir, name):
+    """stable_ties (lowest column first among equal values, the HIP engine's rule) selects the same SET as the
+    reference's torch.topk on every row without a boundary tie, and the same multiset of values on every row."""
+    z, meta = _load(golden_dir, name)
+    keys = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+    P = {k: torch.tensor(z["init__" + k]) for k in keys}
+    x, k, n = torch.tensor(z["x"])[0], meta["k"], meta["n"]
+    multi = bool(meta.get("multi_topk", False))
+    a = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k, multi_topk=multi)
+    b = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k, multi_topk=multi, stable_ties=True)
+    pre = a["pre"].reshape(-1, n).float()
+    srt = pre.sort(1, descending=True).values
+    for kk, key_i, key_a in ((k, "top_indices", "top_acts"),) + (((4 * k, "multi_indices", "multi_acts"),) if multi else ()):
+        ties = srt[:, kk - 1] == srt[:, kk]
+        ia, ib = a[key_i].reshape(-1, kk).sort(1).values, b[key_i].reshape(-1, kk).sort(1).values
+        assert torch.equal(ia[~ties], ib[~ties])
+        assert torch.equal(a[key_a].reshape(-1, kk).float().sort(1).values, b[key_a].reshape(-1, kk).float().sort(1).values)
+        assert ties.any() or torch.equal(ia, ib)
+
+
+@pytest.mark.parametrize("name", L1_CASES + TOPK_CASES)
+def test_fp32_matmul_mode_agrees_with_native(golden_dir, name, monkeypatch):
+    """MATMUL_MODE = "fp32" (bf16 operands, fp32 accumulation, one rounding: host independent) against torch's native CPU
+    bf16 matmul that the fixtures pin: same numbers up to the rare bf16 flip of a result that sits on a rounding
+    boundary -- losses to 1e-4, gradients to rel-Frobenius 2e-3."""
+    z, meta = _load(golden_dir, name)
+    outs = []
+    for mode in ("native", "fp32"):
+        monkeypatch.setattr(O, "MATMUL_MODE", mode)
+        if meta["variant"] == "l1":
+            W = O.normalize_columns(torch.tensor(z["W0"]))
+            x = torch.tensor(z["x"])[0].reshape(-1, meta["d"])
+            f = O.l1_forward(x, W, torch.tensor(z["b0"]), meta["recon_alpha"])
+            dW, db = O.l1_backward(x, W, torch.tensor(z["b0"]), f, meta["recon_alpha"])
+            outs.append(([f["l1_loss"].item(), f["reconstruction_loss"].item()], [dW, db]))
+        else:
+            keys = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
+            P = {k: torch.tensor(z["init__" + k]) for k in keys}
+            x = torch.tensor(z["x"])[0]
+            f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], meta["k"], stable_ties=True)
+            g = O.topk_backward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], f)
+            outs.append(([f["fvu"].item(), f["mse"].item()], [g["W_enc"], g["W_dec"]]))
+    (la, ga), (lb, gb) = outs
+    for u, v in zip(la, lb):
+        assert u == pytest.approx(v, rel=1e-4)
+    for u, v in zip(ga, gb):
+        assert float((u - v).norm() / v.norm()) < 2e-3
+

@@ -2,12 +2,15 @@
 backward GEMMs -> Adam) against the CPU oracle and the reference-generated golden vectors.
 
 Top-k ties: `pre` is bf16 under autocast, so the k-th and (k+1)-th largest latents of a row are EQUAL in
-4-16 % of rows of the golden batches; the reference takes whichever torch.topk's partial sort leaves
-(no rule: sometimes the lower, sometimes the higher column), the engine takes the lower column.  Parity is
-therefore stated as: (i) the multiset of selected VALUES is identical on every row; (ii) the index sets
-are identical on every row without a boundary tie; (iii) on a batch without boundary ties gradients agree to
-rel-Frobenius 1e-2 and losses to rtol 2e-3; (iv) on the golden batches (with ties) losses agree to rtol 3e-3 at
-step 1 / 2e-2 along the trajectory and gradients to 0.15 (tie rows pick different decoder rows)."""
+4-50 % of rows; the reference takes whichever torch.topk's partial sort leaves (no rule: sometimes the lower,
+sometimes the higher column), the engine takes the lower column.  Parity is therefore stated in two layers:
+(a) against the reference's own outputs (golden fixtures): the multiset of selected VALUES is identical on every row,
+    the index sets are identical on every row without a boundary tie, and the numbers agree as far as the tie rows
+    allow (losses rtol 3e-2, gradients rel-Frobenius 0.25: a tie row decodes through a different W_dec row);
+(b) against the oracle evaluated with the engine's tie rule (oracle stable_ties=True: lowest column first, identical
+    to the reference on tie-free rows -- tests/test_oracle.py): index sets identical on EVERY row, losses rtol 3e-3
+    at step 1 / 2e-2 along a trajectory, gradients rel-Frobenius 1e-2, also on batches full of ties and at the real
+    dictionary sizes."""
 import json
 import os
 
@@ -37,14 +40,34 @@ def _boundary_ties(pre, k):
     return srt[:, k - 1] == srt[:, k]
 
 
-def _check_selection(eng, fwd, M, n, k):
+def _check_selection(eng, fwd, M, n, k, exact=False, approx=False):
+    """exact: fwd comes from the oracle with the engine's tie rule -> the index sets must agree on every row.
+    approx (large d: the MFMA and the host matmul sum the K = d products in different orders, so a few of the M x n
+    pre-activations differ by one bf16 ulp and exact set equality is not defined): the engine's set must be a valid top-k
+    of the oracle's pre-activations up to one ulp at the boundary, its values must agree to one ulp, and the sets must be
+    identical on all but a few rows."""
     pre = fwd["pre"].reshape(M, n)
     ties = _boundary_ties(pre, k).numpy()
     idx = eng.debug_read(3, M * k).reshape(M, k).astype(np.int64)
     ref = fwd["top_indices"].reshape(M, k).numpy()
     same = (np.sort(idx, 1) == np.sort(ref, 1)).all(1)
-    assert same[~ties].all(), "index sets differ on rows without a boundary tie"
     dense = eng.debug_read(0, M * n).reshape(M, n)
+    if approx:
+        pf = pre.float().numpy()
+        assert (np.sort(idx, 1)[:, 1:] != np.sort(idx, 1)[:, :-1]).all() and idx.min() >= 0 and idx.max() < n
+        sel = np.zeros((M, n), bool)
+        np.put_along_axis(sel, idx, True, 1)
+        lo = np.where(sel, pf, np.inf).min(1)            # smallest selected / largest unselected oracle pre-activation
+        hi = np.where(sel, -np.inf, pf).max(1)
+        assert (lo >= hi * (1 - 2.0 ** -7) - 1e-30).all(), "a selected latent is more than one bf16 ulp below an unselected one"
+        got = np.take_along_axis(dense, idx, 1)
+        np.testing.assert_allclose(got, np.take_along_axis(pf, idx, 1), rtol=2.0 ** -7, atol=1e-30)
+        assert (dense != 0).sum() == (got != 0).sum()
+        assert same.mean() > 0.9, f"index sets identical on only {same.mean():.3f} of the rows"
+        return ties
+    assert same[~ties].all(), "index sets differ on rows without a boundary tie"
+    if exact:
+        assert same.all(), f"index sets differ on {int((~same).sum())} tie rows (tie rule: lowest column first)"
     got_vals = np.sort(np.take_along_axis(dense, idx, 1), 1)
     ref_vals = np.sort(fwd["top_acts"].float().reshape(M, k).numpy(), 1)
     assert np.array_equal(got_vals, ref_vals), "selected activation values differ"
@@ -64,33 +87,56 @@ def test_topk_steps_match_reference_golden(golden_dir, name):
     eng.set_topk_options(meta["dead_feature_threshold"], T)
     eng.set_params({kk: z["init__" + kk] for kk in KEYS})
     P0 = {kk: torch.tensor(z["init__" + kk]) for kk in KEYS}
+    Po = {kk: v.clone() for kk, v in P0.items()}          # oracle with the engine's tie rule, stepped alongside
+    st, nfsf = O.OptState(), torch.zeros(n, dtype=torch.long)
     xs = torch.tensor(z["x"])
     xd = xs.cuda()
+    kf = 4 * k if multi else k
     for i in range(meta["steps"]):
         lr = O.lr_at(i, meta["lr"], "linear", meta["steps"], meta["num_warmup_steps"])
         eng.forward_backward(xd[i])
         if i == 0:
             f = O.topk_forward(xs[0], P0["encoder.weight"], P0["encoder.bias"], P0["W_dec"], P0["b_dec"], k, multi_topk=multi)
-            kf = 4 * k if multi else k
             assert torch.equal(f["fire_indices"].reshape(M, kf).sort(1).values,
                                torch.tensor(z["first__top_indices"]).reshape(M, kf).sort(1).values)   # oracle == reference
             _check_selection(eng, f, M, n, k)
             g = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
             for kk in KEYS:
-                assert _rel(g[kk], z["first__" + kk]) < 0.15, kk
+                assert _rel(g[kk], z["first__" + kk]) < 0.25, kk
+        dead = nfsf > meta["dead_feature_threshold"]
+        out = O.topk_train_step(xs[i], Po, st, k=k, lr=lr, clip_thresh=1.0, dead_mask=dead, auxk_alpha=meta["auxk_alpha"],
+                                optimizer="adam", multi_topk=multi, stable_ties=True)
+        did = torch.zeros(n, dtype=torch.bool)
+        did[out["fire_indices"].flatten()] = True
+        nfsf += M
+        nfsf[did] = 0
+        if i == 0:
+            g = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+            for kk in KEYS:
+                assert _rel(g[kk], out["grads"][kk].numpy()) < 1e-2, kk
         eng.optimizer_step(lr)
         m = eng.metrics()
+        # (b) the oracle under the engine's tie rule: arithmetic tolerance
         tol = 3e-3 if i == 0 else 2e-2
-        assert m[0] == pytest.approx(float(z["fvu"][i]), rel=tol)
+        assert m[0] == pytest.approx(out["fvu"].item(), rel=tol)
+        # (the AuxK term rests on a handful of dead latents here and drifts with the trajectory: fp32 vs bf16-rounded
+        # weight gradients under Adam)
+        assert m[1] == pytest.approx(out["auxk_loss"].item(), rel=0.1, abs=1e-7)
+        assert m[3] == pytest.approx(out["grad_norm"].item(), rel=2e-2)
+        assert m[5] == pytest.approx(float(dead.float().mean()), abs=1e-7)
+        assert m[6] == (pytest.approx(out["multi_topk_fvu"].item(), rel=tol) if multi else 0.0)
+        # (a) the reference's own numbers: as far as its arbitrary choice among tied latents allows
+        assert m[0] == pytest.approx(float(z["fvu"][i]), rel=3e-2)
         assert m[1] == pytest.approx(float(z["auxk"][i]), rel=0.1, abs=1e-6)
         assert m[5] == pytest.approx(float(z["num_dead"][i]) / n, abs=2.0 / n)
         if multi:
-            assert m[6] == pytest.approx(float(z["multi"][i]), rel=tol)
-        else:
-            assert m[6] == 0.0
+            assert m[6] == pytest.approx(float(z["multi"][i]), rel=3e-2)
     p = eng.get_params()
-    for kk in KEYS:   # Adam turns a tie row's different gradient into a full-size step on the few elements it touches
+    for kk in KEYS:
+        assert _rel(p[kk], Po[kk].numpy()) < (2e-3 if kk in ("encoder.weight", "W_dec") else 5e-2), kk
+        # Adam turns a tie row's different gradient into a full-size step on the few elements it touches
         assert _rel(p[kk], z["final__" + kk]) < (5e-3 if kk in ("encoder.weight", "W_dec") else 0.15), kk
+    assert np.array_equal(eng.get_topk_state(), nfsf.numpy())
     eng.close()
 
 
@@ -155,14 +201,15 @@ def test_topk_auxk_and_dead_bookkeeping():
         dead = nfsf > thr
         eng.step(xd, 1e-4)
         m = eng.metrics()
-        out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=dead, auxk_alpha=aux, optimizer="adam")
+        out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=dead, auxk_alpha=aux, optimizer="adam",
+                                stable_ties=True)
         did = torch.zeros(n, dtype=torch.bool)
         did[out["top_indices"].flatten()] = True
         nfsf += B * T
         nfsf[did] = 0
-        assert m[5] == pytest.approx(float(dead.float().mean()), abs=3.0 / n)      # dead_pct (ties move a few latents)
+        assert m[5] == pytest.approx(float(dead.float().mean()), abs=3.0 / n)      # dead_pct
         assert m[0] == pytest.approx(out["fvu"].item(), rel=2e-2)
-        assert m[1] == pytest.approx(out["auxk_loss"].item(), rel=0.1, abs=1e-7)
+        assert m[1] == pytest.approx(out["auxk_loss"].item(), rel=5e-2, abs=1e-7)
         if i >= 1:
             assert m[1] > 0
     # sae_get_topk_state / sae_set_topk_state (resume fidelity): the device counters follow the
@@ -299,29 +346,29 @@ def test_topk_multi_topk_sparse_path_matches_oracle():
 ])
 def test_topk_real_dictionary_sizes_match_oracle(d, n, k, B, T, kernel):
     """The configs[2] shape at full n / k against the oracle (M = 512 rows), and the two select kernels that only large
-    dictionaries reach.  Ties at the k-th value are common with bf16 pre-activations: the selected VALUES must be
-    identical on every row and the index sets on every row without a boundary tie; losses to rtol 5e-3, gradients to
-    rel-Frobenius 0.15 when tie rows exist (they pick different decoder rows) and 1e-2 when none do."""
+    dictionaries reach.  Ties at the k-th value are common with bf16 pre-activations (half of the rows here): against the
+    oracle under the engine's tie rule the index sets are identical on every row, losses agree to rtol 5e-3 and gradients
+    to rel-Frobenius 1e-2."""
     from freud_amd.engine import SaeEngine
     P, x = _make_case(d, n, k, B, T, 3)
     M = B * T
-    f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k)
+    f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k, stable_ties=True)
     eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.0)
     eng.set_topk_options(1e12, T)
     eng.set_params({kk: v.numpy() for kk, v in P.items()})
     eng.forward_backward(x.cuda())
-    ties = _check_selection(eng, f, M, n, k)
+    _check_selection(eng, f, M, n, k, exact=d <= 384, approx=d > 384)
     graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
     eng.optimizer_step(1e-4)
     m = eng.metrics()
     st = O.OptState()
-    out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=None, auxk_alpha=0.0, optimizer="adam")
+    out = O.topk_train_step(x, P, st, k=k, lr=1e-4, clip_thresh=1.0, dead_mask=None, auxk_alpha=0.0, optimizer="adam",
+                            stable_ties=True)
     assert m[0] == pytest.approx(out["fvu"].item(), rel=5e-3)
     assert m[2] == pytest.approx(out["mse"].item(), rel=5e-3)
-    gtol = 0.15 if ties.any() else 1e-2
-    assert m[3] == pytest.approx(out["grad_norm"].item(), rel=0.05 if ties.any() else 1e-2)
+    assert m[3] == pytest.approx(out["grad_norm"].item(), rel=1e-2)
     for kk in KEYS:
-        assert _rel(graw[kk], out["grads"][kk].numpy()) < gtol, (kk, int(ties.sum()))
+        assert _rel(graw[kk], out["grads"][kk].numpy()) < 1e-2, kk
     eng.close()
 
 
