@@ -92,6 +92,9 @@ def main():
                     help="TopK dead_feature_threshold in frames (configs use 1e6: AuxK switches on after ~16 steps of 65536 "
                          "rows once latents stay silent; 1e15 keeps AuxK off)")
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
+    ap.add_argument("--dp-host", action="store_true",
+                    help="data parallel through torch.distributed from Python (statistics + gradient-range all-reduces) instead "
+                         "of the engine's own RCCL communicator")
     ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
@@ -144,20 +147,30 @@ def main():
                         clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128,
                         precision=args.precision)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
-    grads = eng.grad_tensor() if use_dist else None
-    works = []
-    if use_dist:    # ranges of the gradient buffer are all-reduced as soon as the engine reports them final
+    # Data parallel: the engine's own RCCL communicator (sae_dist_init) runs the whole protocol -- batch statistics and
+    # gradient ranges all-reduced on a communication stream under the forward / backward kernels -- inside step(); --dp-host
+    # drives the same protocol from Python through torch.distributed (the host-side variant train() keeps for CPU tests).
+    grads, works = None, []
+    if use_dist and not args.dp_host:
+        ids = [SaeEngine.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.dist_init(ids[0], rank, world)
+    elif use_dist:
+        eng.set_dp_world(world)
+        grads = eng.grad_tensor()
         eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     total_steps, base_lr = 100000, 4e-4
     lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
     def one_step(i):
-        if use_dist:
+        if use_dist and args.dp_host:
+            eng.batch_stats(x)
+            dist.all_reduce(eng.stats_tensor())
             eng.forward_backward(x)
             for w in works:
                 w.wait()
             works.clear()
-            eng.optimizer_step(lr_of(i), 1.0 / world)
+            eng.optimizer_step(lr_of(i), 1.0)
         else:
             eng.step(x, lr_of(i))
 
@@ -245,7 +258,8 @@ def main():
         "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
         "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
-                   "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}"},
+                   "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}",
+                   "dp": (("host-driven (torch.distributed)" if args.dp_host else "in-engine RCCL") if use_dist else "none")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,

@@ -15,6 +15,8 @@
 #include "gemm256.h"
 #include "gemm256_fp8.h"
 #include "l1_fp8.h"
+#include "dp_kernels.h"
+#include <rccl/rccl.h>
 
 static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
@@ -33,6 +35,12 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+#define NCCL_TRY(expr)                                                                                      \
+  do {                                                                                                      \
+    ncclResult_t r_ = (expr);                                                                               \
+    if (r_ != ncclSuccess) return fail(SAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), \
+                                       __FILE__, __LINE__);                                                 \
+  } while (0)
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \
@@ -144,6 +152,19 @@ struct sae_ctx {
   int* multi_idx = nullptr;
   float *em = nullptr, *m2_part = nullptr;
   unsigned char* dead = nullptr;
+  // ---- data parallel (dp_kernels.h): batch statistics the losses normalise by, summed over the ranks
+  double* stats = nullptr;      // [stats_cap] doubles
+  int64_t stats_cap = 0, stats_n = 0;   // capacity / doubles the last sae_batch_stats wrote
+  unsigned int* stats_part = nullptr;
+  int dp_world = 0;             // > 0: forward_backward normalises by `stats` (which the host, or the engine's own RCCL
+                                // communicator, has summed over dp_world ranks) instead of this rank's own batch
+  // in-engine RCCL (sae_dist_init): statistics and gradient ranges are all-reduced on a communication stream
+  bool dist = false;
+  ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_x = nullptr, ev_stats = nullptr, ev_done = nullptr;
+  hipEvent_t ev_range[16] = {};
+  int ev_range_i = 0;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
@@ -260,6 +281,8 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->tv_part, ((Mp * c->d + 255) / 256 + 1) * 8);
   TALLOC(c->nfsf, (size_t)c->n_p * 8);
   TALLOC(c->dbe_fx, (size_t)c->n_p * 8);
+  c->stats_cap = DP_STATS_HEAD + 2 * (int64_t)c->cfg.max_rows * c->d;     // column sums / sums of squares: at most one file
+  TALLOC(c->stats, c->stats_cap * 8);
   // topk_dense_backward keeps the dense ddense GEMM (tests cover both)
   c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.topk_dense_backward != 1;
   TALLOC(c->dead, c->n_p);
@@ -294,9 +317,16 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
-                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part};
+                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
+                  c->stats, c->stats_part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_range)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_init)
     for (auto& r : c->ev)
       for (int i = 0; i < EV_RING; ++i) {
@@ -411,6 +441,9 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
+  c->stats_cap = DP_STATS_HEAD;
+  ALLOC(c->stats, c->stats_cap * 8);
+  ALLOC(c->stats_part, 1024 * 4);
   if (c->fp8) {
     ALLOC(c->x8, Mp * c->d_p);
     ALLOC(c->c8, Mp * c->n_p);
@@ -565,8 +598,19 @@ extern "C" int sae_set_grad_ready_callback(sae_ctx* c, sae_grad_ready_fn fn, voi
   return SAE_OK;
 }
 
+// A contiguous range of the gradient buffer is final in stream order: tell the host (its own all-reduce), or -- with the
+// engine's own communicator -- all-reduce it now on the communication stream, under the backward kernels still to come.
+static int dist_error = 0;
 static inline void notify_grads(sae_ctx* c, int64_t offset, int64_t count, hipStream_t s) {
-  if (c->grad_ready && count > 0) c->grad_ready(c->grad_ready_user, offset, count, (void*)s);
+  if (count <= 0) return;
+  if (c->dist && c->dp_world > 0) {
+    hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess ||
+        ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess)
+      dist_error = 1;
+    return;
+  }
+  if (c->grad_ready) c->grad_ready(c->grad_ready_user, offset, count, (void*)s);
 }
 
 extern "C" int sae_get_topk_state(sae_ctx* c, int64_t* out, int64_t n) {
@@ -595,6 +639,90 @@ extern "C" int sae_grad_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_floats) {
   *n_floats = c->nparams + SAE_NUM_METRICS + (c->topk ? c->n_p : 0);   // TopK: + did_fire flags (OR == sum > 0)
   return SAE_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// data parallel: batch statistics (dp_kernels.h) and the engine's own RCCL communicator
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int batch_stats_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s) {
+  if (c->topk) {
+    const int64_t T_rows = (c->rows_per_file > 0 && M % c->rows_per_file == 0) ? c->rows_per_file : M;
+    const int B = (int)(M / T_rows);
+    const int64_t TD = T_rows * c->d, need = DP_STATS_HEAD + 2 * TD;
+    if (need > c->stats_cap) return fail(SAE_ERR_INVALID, "batch statistics need %lld doubles, capacity %lld", (long long)need, (long long)c->stats_cap);
+    hipLaunchKernelGGL(dp_topk_stats_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, M, c->stats);
+    c->stats_n = need;
+  } else {
+    const int64_t total = M * c->d;
+    int grid = (int)((total + 256 * 16 - 1) / (256 * 16));
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(dp_count_masked_kernel<T>, dim3(grid), dim3(256), 0, s, x, total, c->stats_part);
+    hipLaunchKernelGGL(dp_l1_stats_kernel, dim3(1), dim3(256), 0, s, c->stats_part, grid, M, c->d, c->stats);
+    c->stats_n = DP_STATS_HEAD;
+  }
+  HIP_TRY(hipGetLastError());
+  return SAE_OK;
+}
+
+static int batch_stats_dispatch(sae_ctx* c, const void* x, int64_t M, int x_dtype, hipStream_t s) {
+  switch (x_dtype) {
+    case SAE_DTYPE_F32: return batch_stats_impl<float>(c, (const float*)x, M, s);
+    case SAE_DTYPE_F16: return batch_stats_impl<_Float16>(c, (const _Float16*)x, M, s);
+    case SAE_DTYPE_BF16: return batch_stats_impl<bf16_t>(c, (const bf16_t*)x, M, s);
+    default: return fail(SAE_ERR_INVALID, "unknown x_dtype %d", x_dtype);
+  }
+}
+
+extern "C" int sae_batch_stats(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
+  if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
+  if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
+  USE_DEVICE(c);
+  return batch_stats_dispatch(c, x, M, x_dtype, (hipStream_t)stream);
+}
+
+extern "C" int sae_stats_buffer(sae_ctx* c, void** dev_ptr, int64_t* n_doubles) {
+  if (!c || !dev_ptr || !n_doubles) return fail(SAE_ERR_INVALID, "null argument");
+  *dev_ptr = c->stats;
+  *n_doubles = c->stats_n;
+  return SAE_OK;
+}
+
+extern "C" int sae_set_dp_world(sae_ctx* c, int world) {
+  if (!c || world < 0) return fail(SAE_ERR_INVALID, "bad argument");
+  if (c->dist && world != c->dp_world) return fail(SAE_ERR_STATE, "the context owns a communicator of %d ranks", c->dp_world);
+  c->dp_world = world;
+  return SAE_OK;
+}
+
+extern "C" int sae_dist_unique_id(void* out, int64_t capacity) {
+  if (!out || capacity < (int64_t)sizeof(ncclUniqueId)) return fail(SAE_ERR_INVALID, "need %d bytes", (int)sizeof(ncclUniqueId));
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memcpy(out, &id, sizeof(id));
+  return SAE_OK;
+}
+
+extern "C" int sae_dist_init(sae_ctx* c, const void* unique_id, int64_t id_bytes, int rank, int world) {
+  if (!c || !unique_id) return fail(SAE_ERR_INVALID, "null argument");
+  if (id_bytes != (int64_t)sizeof(ncclUniqueId)) return fail(SAE_ERR_INVALID, "unique id must be %d bytes", (int)sizeof(ncclUniqueId));
+  if (world < 1 || rank < 0 || rank >= world) return fail(SAE_ERR_INVALID, "rank %d / world %d", rank, world);
+  if (c->dist) return fail(SAE_ERR_STATE, "communicator already initialised");
+  USE_DEVICE(c);
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
+  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  for (auto& e : c->ev_range) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  c->dist = true;
+  c->dp_world = world;
+  return SAE_OK;
+}
+
+extern "C" int sae_dist_world(sae_ctx* c) { return (c && c->dist) ? c->dp_world : 0; }
 
 // ------------------------------------------------------------------------------------------
 // launches
@@ -659,8 +787,11 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       hipLaunchKernelGGL((prep_x_kernel<T, true>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
     else
       hipLaunchKernelGGL((prep_x_kernel<T, false>), dim3(grid), dim3(256), 0, s, x, c->xb, c->masked, M, d, Mp, d_p);
-    if (!c->use_fused_fwd)
-      hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha);
+    if (!c->use_fused_fwd) {
+      const double* gs = (need_backward && c->dp_world > 0) ? c->stats : nullptr;
+      if (gs && c->dist) HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));     // the summed statistics have arrived
+      hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(256), 0, s, c->masked, grid, c->scal, M, d, alpha, gs);
+    }
   }
   if (c->fp8) {   // per-tensor power-of-two scales from the batch (max |x|, max row norm) and the bias, then x8 = e4m3(xb s_x)
     const int sgrid = (int)((Mp / 4) < 1024 ? (Mp / 4) : 1024);
@@ -759,12 +890,15 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   const int d = c->d, d_p = c->d_p, n_p = c->n_p;
   const int64_t Mp = round_up(M, c->row_pad);
   const float alpha = (float)c->cfg.recon_alpha;
+  const double* gs = (backward && c->dp_world > 0) ? c->stats : nullptr;    // data parallel: global normalisers
   ev_begin(c, KID_STEP_TOTAL, s);
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
   if (rc) return rc;
-  if (c->use_fused_fwd)   // the fused forward counted the masked entries itself: scal[] and the losses are due now
+  if (c->use_fused_fwd) {  // the fused forward counted the masked entries itself: scal[] and the losses are due now
+    if (gs && c->dist) HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));      // the summed statistics have arrived
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)(Mp / 128), c->sq_part,
-                       (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128));
+                       (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128), gs);
+  }
   bool dw_chunked_any = false;
   if (backward) {
     int splits = c->dw_splits;
@@ -848,7 +982,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   if (!c->use_fused_fwd)
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
                        c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, gs);
   if (backward) {   // everything that was not announced chunk by chunk: [dW] | db | loss scalars
     const int64_t total = c->nparams + SAE_NUM_METRICS;
     if (dw_chunked_any) notify_grads(c, c->nW, total - c->nW, s);
@@ -882,6 +1016,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   float* gbd = c->G + 2 * c->nW + n_p;
   float* metrics = c->G + c->nparams;
   float* did_fire = metrics + SAE_NUM_METRICS;
+  const double* gs = (backward && c->dp_world > 0) ? c->stats : nullptr;    // data parallel: global normalisers
   int rc;
   ev_begin(c, KID_STEP_TOTAL, s);
 
@@ -904,7 +1039,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     if (g2 > 4096) g2 = 4096;
     hipLaunchKernelGGL(topk_prep_x_kernel<T>, dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
     const int64_t TD = T_rows * d;
-    hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
+    if (!gs)   // (data parallel: the variance comes from the column statistics summed over the ranks, below)
+      hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
   }
   {  // pre = relu(sae_in We^T + be)
     GemmArgs g{};
@@ -957,9 +1093,13 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     else launch_decode(std::integral_constant<int, 0>{});
   }
   const int64_t TD = T_rows * d;
+  if (gs) {
+    if (c->dist) HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));     // the summed statistics have arrived
+    hipLaunchKernelGGL(dp_topk_tv_kernel, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, gs, TD, c->tv_part);
+  }
   hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
                      aux ? c->a2_part : (const float*)nullptr, c->multi ? c->m2_part : (const float*)nullptr, Mp, M, d, alpha,
-                     c->tk, c->tkf, metrics, (float)n);
+                     c->tk, c->tkf, metrics, (float)n, gs, c->dp_world);
   ev_end(c, KID_TK_DECODE, s);
   if (backward) {
     const int rpb = 256;
@@ -1080,11 +1220,38 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   return SAE_OK;
 }
 
+static int dispatch_fwd_bwd_inner(sae_ctx* c, const void* x, int64_t M, int x_dtype, hipStream_t s, bool backward);
+
+// With the engine's own communicator (sae_dist_init) a training step is bracketed by: (1) the batch statistics and their
+// all-reduce on the communication stream, concurrent with the weight preparation and the forward kernels (they depend on
+// x only); (2) [the step's kernels; every gradient range is all-reduced on the communication stream as soon as it is
+// final, notify_grads]; (3) the compute stream waits for the last of those all-reduces.
 static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream, bool backward) {
   if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
   if (M <= 0 || M > c->cfg.max_rows) return fail(SAE_ERR_INVALID, "M=%lld outside (0, max_rows=%lld]", (long long)M, (long long)c->cfg.max_rows);
   USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
+  const bool dp = c->dist && backward;
+  if (dp) {
+    dist_error = 0;
+    HIP_TRY(hipEventRecord(c->ev_x, s));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
+    int rc = batch_stats_dispatch(c, x, M, x_dtype, c->comm_stream);
+    if (rc) return rc;
+    NCCL_TRY(ncclAllReduce(c->stats, c->stats, (size_t)c->stats_n, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    HIP_TRY(hipEventRecord(c->ev_stats, c->comm_stream));
+  }
+  int rc = dispatch_fwd_bwd_inner(c, x, M, x_dtype, s, backward);
+  if (rc) return rc;
+  if (dp) {
+    if (dist_error) return fail(SAE_ERR_HIP, "RCCL all-reduce of a gradient range failed");
+    HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+  }
+  return SAE_OK;
+}
+
+static int dispatch_fwd_bwd_inner(sae_ctx* c, const void* x, int64_t M, int x_dtype, hipStream_t s, bool backward) {
   c->last_dtype = x_dtype;
   if (c->topk) {
     switch (x_dtype) {
@@ -1156,7 +1323,8 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
                      a, c->G + c->nparams);
   if (c->topk)   // train_sae.py:443-446 with the (possibly data-parallel summed) did_fire flags
     hipLaunchKernelGGL(nfsf_update_kernel, dim3((c->n + 255) / 256), dim3(256), 0, s, c->nfsf, c->G + c->nparams + SAE_NUM_METRICS,
-                       c->n, (long long)(c->last_M * (grad_scale > 0 ? (long long)llround(1.0 / grad_scale) : 1)));
+                       c->n, (long long)(c->last_M * (grad_scale > 0 ? (long long)llround(1.0 / grad_scale) : 1)),
+                       c->dp_world > 0 ? c->stats : (const double*)nullptr);
   ev_end(c, KID_OPT, s);
   HIP_TRY(hipGetLastError());
   return SAE_OK;
@@ -1173,7 +1341,8 @@ extern "C" int sae_set_topk_options(sae_ctx* c, double dead_feature_threshold, i
 extern "C" int sae_step(sae_ctx* c, const void* x, int64_t M, int x_dtype, double lr, void* stream) {
   int rc = sae_forward_backward(c, x, M, x_dtype, stream);
   if (rc) return rc;
-  c->step_fused_call = true;
+  // (data parallel with global statistics: the all-reduced gradient already is the whole batch's -- grad_scale stays 1)
+  c->step_fused_call = c->dp_world == 0;     // the local sum of squares is only the clip norm without an all-reduce
   rc = sae_optimizer_step(c, lr, 1.0, stream);
   c->step_fused_call = false;
   return rc;

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const T* __restrict__ x, bf
 }
 
 // scal[0] = count of unmasked entries, scal[1] = alpha/count (d loss / d squared-error term), scal[2] = 1/M
+// gstats != null (data parallel, dp_kernels.h): the count and the row number are the GLOBAL ones, summed over the ranks.
 __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int* masked_part, int nparts, float* scal,
-                                                              int64_t M, int d, float alpha) {
+                                                              int64_t M, int d, float alpha, const double* gstats) {
   __shared__ unsigned int red[4];
   unsigned int m = 0;
   for (int i = threadIdx.x; i < nparts; i += 256) m += masked_part[i];
@@ -126,10 +127,11 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double count = (double)M * d - (double)(red[0] + red[1] + red[2] + red[3]);
+    const double count = gstats ? gstats[0] : (double)M * d - (double)(red[0] + red[1] + red[2] + red[3]);
     scal[0] = (float)count;
     scal[1] = alpha / (float)count;
-    scal[2] = 1.0f / (float)M;
+    scal[2] = 1.0f / (float)(gstats ? gstats[1] : (double)M);
+    scal[3] = (float)((double)M * d - (double)(red[0] + red[1] + red[2] + red[3]));     // this rank's own count
   }
 }
 
@@ -360,9 +362,12 @@ __global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict_
 // metrics: [0]=alpha*sq/count  [1]=l1_sum/M  [2]=plain_sq/(M*d)  [4]=count
 // With cnt_part != null (fused forward) the masked-entry count comes from the forward's own partials and the
 // scalars scal[0..2] = {count, alpha/count, 1/M} are produced here instead of by finalize_count_kernel.
+// gstats != null (data parallel): every scalar is normalised by the GLOBAL count / rows so that the SUM over the ranks of
+// metrics[0..2] is the loss of the whole batch; metrics[4] stays this rank's own count (it sums to the global one).
 __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
                                                                 int n_sq, float* scal, float* metrics, int64_t M,
-                                                                int d, float alpha, const float* cnt_part, int n_cnt) {
+                                                                int d, float alpha, const float* cnt_part, int n_cnt,
+                                                                const double* gstats) {
   __shared__ double red[3][16];
   __shared__ double redc[16];
   double a = 0, b = 0, c = 0;
@@ -375,10 +380,12 @@ __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_p
     if (threadIdx.x == 0) {
       double tot = 0;
       for (int k = 0; k < 16; ++k) tot += redc[k];
-      const double count = (double)M * d - tot;
+      const double local = (double)M * d - tot;
+      const double count = gstats ? gstats[0] : local;
       scal[0] = (float)count;
       scal[1] = alpha / (float)count;
-      scal[2] = 1.0f / (float)M;
+      scal[2] = 1.0f / (float)(gstats ? gstats[1] : (double)M);
+      scal[3] = (float)local;
     }
     __syncthreads();
   }
@@ -403,12 +410,12 @@ __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_p
       sq += red[1][k];
       pl += red[2][k];
     }
-    const double count = (double)scal[0];
+    const double count = (double)scal[0], rows = gstats ? gstats[1] : (double)M;
     metrics[0] = (float)((double)alpha * (sq / count));
-    metrics[1] = (float)(l1 / (double)M);
-    metrics[2] = (float)(pl / ((double)M * d));
+    metrics[1] = (float)(l1 / rows);
+    metrics[2] = (float)(pl / (rows * d));
     metrics[3] = 0.f;
-    metrics[4] = scal[0];
+    metrics[4] = gstats ? scal[3] : scal[0];
     metrics[5] = metrics[6] = metrics[7] = 0.f;
   }
 }

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __rest
                                                              const float* __restrict__ m2_part,
                                                              int64_t Mp, int64_t M, int d, float auxk_alpha, const int* tk,
                                                              float* __restrict__ tkf, float* __restrict__ metrics,
-                                                             float dead_frac_n) {
+                                                             float dead_frac_n, const double* __restrict__ gstats, int world) {
   __shared__ double red[4][4];
   double a = 0, b = 0, c = 0, m = 0;
   const bool have_aux = a2_part != nullptr && tk[0] > 0;     // with no dead latent the AuxK kernels did not run
@@ -538,10 +538,13 @@ __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __rest
     tkf[5] = (tk[0] > 0 && a2_part) ? auxk_alpha * scale * 2.0f / tvf : 0.f;
     metrics[0] = fvu;
     metrics[1] = auxk;
-    metrics[2] = (float)(e2 / ((double)M * d));
+    // data parallel (gstats != null): tv above is the GLOBAL total variance, so fvu / auxk / multi are this rank's share
+    // of the global losses (they SUM over the ranks); mse likewise over the global rows; dead_pct is the same on every
+    // rank, so each contributes 1 / world of it
+    metrics[2] = (float)(e2 / ((gstats ? gstats[0] : (double)M) * d));
     metrics[3] = 0.f;
     metrics[4] = 0.f;
-    metrics[5] = (float)tk[0] / dead_frac_n;   // dead_pct (train/dead_pct, train_sae.py:481-485)
+    metrics[5] = (float)tk[0] / dead_frac_n / (float)(gstats ? world : 1);   // dead_pct (train/dead_pct, train_sae.py:481-485)
     metrics[6] = m2_part ? (float)m2 / tvf : 0.f;   // multi_topk_fvu (topkautoencoder.py:134-140)
     metrics[7] = 0.f;
   }
@@ -790,7 +793,8 @@ __global__ __launch_bounds__(256) void topk_dbd_kernel(const float* __restrict__
 
 // num_frames_since_fired += rows; [did_fire] = 0 (train_sae.py:443-446).  did_fire may be a data-parallel SUM.
 __global__ __launch_bounds__(256) void nfsf_update_kernel(long long* __restrict__ nfsf, const float* __restrict__ did_fire, int n,
-                                                           long long rows) {
+                                                           long long rows, const double* __restrict__ gstats) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (gstats) rows = (long long)gstats[0];            // data parallel: the rows of ALL ranks (activations.shape[0] * shape[1])
   if (i < n) nfsf[i] = did_fire[i] > 0.f ? 0 : nfsf[i] + rows;
 }

@@ -84,6 +84,12 @@ def load() -> C.CDLL:
         "sae_forward_backward": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_grad_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_optimizer_step": (C.c_int, [vp, dbl, dbl, vp]),
+        "sae_batch_stats": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+        "sae_stats_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
+        "sae_set_dp_world": (C.c_int, [vp, C.c_int]),
+        "sae_dist_unique_id": (C.c_int, [vp, i64]),
+        "sae_dist_init": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
+        "sae_dist_world": (C.c_int, [vp]),
         "sae_set_grad_ready_callback": (C.c_int, [vp, GRAD_READY_FN, vp]),
         "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
@@ -113,7 +119,8 @@ def load() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
-    "sae_set_grad_ready_callback", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_set_grad_ready_callback", "sae_batch_stats", "sae_stats_buffer", "sae_set_dp_world", "sae_dist_unique_id",
+    "sae_dist_init", "sae_dist_world", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
@@ -271,6 +278,43 @@ class SaeEngine:
         err, self._cb_error = getattr(self, "_cb_error", None), None
         if err is not None:
             raise err
+
+    # -- data parallel (include/freud_sae.h, "data-parallel exactness") ------------------------------------
+    def batch_stats(self, x, stream=None) -> None:
+        """This rank's statistics of batch x (what the losses normalise by) into the statistics buffer."""
+        self._note_shape(x)
+        x, ptr, rows, dt = self._x_args(x)
+        _check(self._lib.sae_batch_stats(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    def stats_tensor(self):
+        """The statistics of the last batch_stats() as a float64 torch CUDA tensor aliasing the engine's buffer:
+        all-reduce (sum) it over the ranks before forward_backward()."""
+        import torch
+        p, n = C.c_void_p(), C.c_int64()
+        _check(self._lib.sae_stats_buffer(self._ctx, C.byref(p), C.byref(n)))
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f8", "data": (int(p.value), False), "version": 2}
+
+        return torch.as_tensor(_Alias(), device=f"cuda:{self.device_id}")
+
+    def set_dp_world(self, world: int) -> None:
+        _check(self._lib.sae_set_dp_world(self._ctx, int(world)))
+
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load().sae_dist_unique_id(buf, 128))
+        return buf.raw
+
+    def dist_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        """Give the context its own RCCL communicator: forward_backward() / step() then run the data-parallel protocol
+        (statistics and gradient all-reduces on a communication stream) inside the engine."""
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        _check(self._lib.sae_dist_init(self._ctx, buf, len(unique_id), int(rank), int(world)))
+
+    def dist_world(self) -> int:
+        return int(self._lib.sae_dist_world(self._ctx))
 
     def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))

@@ -6,8 +6,13 @@ this file is orchestration only: seeds, loader, LR schedule, logging, checkpoint
 all-reduce.  There is no CPU implementation of the step here: without the engine it fails loudly.
 
 Data parallel: launch one process per GPU with torch.distributed.run; rank r trains on
-perm[r::R] of every epoch permutation with the per-GPU batch_size of the config; gradients are
-summed over ranks with RCCL (backend "nccl") and scaled by 1/R before clip + optimizer.
+perm[r::R] of every epoch permutation with the per-GPU batch_size of the config.  The step is exact:
+the batch statistics the losses normalise by (unmasked-entry count and rows; for TopK the column sums
+behind total_variance) are summed over the ranks first, every rank's backward normalises by the
+global values, and the summed gradients are the whole batch's (include/freud_sae.h).  On GPUs the
+engine does all of it itself on its own RCCL communicator (sae_dist_init: no Python in the step); a
+host-driven variant of the same protocol over torch.distributed serves CPU tests (gloo) and
+FREUD_DP_HOST=1.
 """
 from __future__ import annotations
 
@@ -365,13 +370,25 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             print(f"Checkpoint: {start_checkpoint}")
         load_checkpoint(state, start_checkpoint, device=device)
 
-    grads = eng.grad_tensor() if use_dist else None
-    works = []
-    overlap = use_dist and hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
-    if overlap:
-        # every range of the gradient buffer is all-reduced (RCCL, communication stream) as soon as the engine reports
-        # it final, i.e. under the backward kernels that are still to run (sae_set_grad_ready_callback)
-        eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
+    # Data parallel: (a) in-engine -- the context gets its own RCCL communicator and step() runs statistics, gradient
+    # all-reduces (overlapped with the backward) and the optimizer without returning to Python; (b) host-driven -- the
+    # same protocol through torch.distributed: statistics all-reduce, forward_backward, gradient all-reduce (ranges as
+    # the engine announces them when it can), optimizer.
+    grads, works, overlap, in_engine = None, [], False, False
+    if use_dist:
+        in_engine = (hasattr(eng, "dist_init") and dist.get_backend() == "nccl" and os.environ.get("FREUD_DP_HOST") != "1")
+        if in_engine:
+            ids = [eng.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            eng.dist_init(ids[0], rank, world)
+        else:
+            eng.set_dp_world(world)
+            grads = eng.grad_tensor()
+            overlap = hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
+            if overlap:
+                # every range of the gradient buffer is all-reduced (communication stream) as soon as the engine
+                # reports it final, i.e. under the backward kernels that are still to run
+                eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     t_start, rows_done = time.time(), 0
     while state["step"] < steps:
         n_batches = 0
@@ -384,15 +401,17 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             n_batches += 1
             state["epoch_batches_done"] = n_batches
             step_lr = lr_at(state["step"], lr, scheduler, steps, scheduler_params)
-            if use_dist:
+            if use_dist and not in_engine:
+                eng.batch_stats(activations)
+                dist.all_reduce(eng.stats_tensor())         # what the losses normalise by, over the whole batch
                 eng.forward_backward(activations)
                 if overlap:
                     for w in works:                         # the compute stream waits for the communication stream
                         w.wait()
                     works.clear()
                 else:
-                    dist.all_reduce(grads)                  # sum of [grads | loss scalars] over ranks
-                eng.optimizer_step(step_lr, 1.0 / world)
+                    dist.all_reduce(grads)                  # sum of [grads | loss shares (| did_fire)] over ranks
+                eng.optimizer_step(step_lr, 1.0)            # the summed gradient IS the whole batch's: no 1/R
             else:
                 eng.step(activations, step_lr)
             state["step"] += 1

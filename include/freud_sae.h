@@ -135,6 +135,36 @@ int sae_grad_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* n_floats);
 typedef void (*sae_grad_ready_fn)(void* user, int64_t offset, int64_t count, void* stream);
 int sae_set_grad_ready_callback(sae_ctx* ctx, sae_grad_ready_fn fn, void* user);
 
+/* ---- data-parallel exactness and the engine's own communicator (the reference is single-process: train_sae.py never
+ * leaves one device; this is the partitioning BASELINE.json's north_star asks for).
+ *
+ * R ranks x batch B must train like one rank x batch R B.  The gradients are linear in the per-row contributions but the
+ * losses NORMALISE by whole-batch quantities -- the number of unmasked entries of the masked MSE and the row count of the
+ * L1 mean (l1autoencoder.py:29-36,85); for TopK the total variance around x.mean(0) over ALL files (topkautoencoder.py:
+ * 104-106) and the rows of mse -- so those statistics are summed over the ranks FIRST (they depend on the batch only, not
+ * on the model) and every rank's backward normalises by the global values; the summed gradients then ARE the whole
+ * batch's and no 1/R rescaling follows (grad_scale = 1).
+ *
+ *   sae_batch_stats   writes this rank's statistics of batch x into the context's statistics buffer (float64, device;
+ *                     L1: [unmasked entries, rows]; TopK: [rows, files, sum_b x, sum_b x^2 per (t, feature)]); asynchronous.
+ *   sae_stats_buffer  the buffer and the number of doubles the last sae_batch_stats wrote: a host-driven data-parallel
+ *                     loop all-reduces (sum) exactly that range before sae_forward_backward.
+ *   sae_set_dp_world  world > 0: sae_forward_backward normalises by the statistics buffer (and loss scalars become this
+ *                     rank's SHARE of the global losses: they sum over the ranks; dead_pct is pre-divided by world);
+ *                     0 (default): by the rank's own batch.
+ *
+ * sae_dist_unique_id / sae_dist_init give the context its own RCCL communicator (one process per GPU; the unique id made on
+ * rank 0 travels to the others by any host channel).  Afterwards sae_forward_backward / sae_step do the whole protocol
+ * inside the engine, with no host code in the step: statistics + their all-reduce on a communication stream while the
+ * forward runs, every gradient range all-reduced on that stream as soon as its backward kernels are enqueued (i.e. under
+ * the remaining backward GEMMs), the compute stream joining before the optimizer.  sae_optimizer_step takes grad_scale 1. */
+int sae_batch_stats(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, void* stream);
+int sae_stats_buffer(sae_ctx* ctx, void** dev_ptr, int64_t* n_doubles);
+int sae_set_dp_world(sae_ctx* ctx, int world);
+int sae_dist_unique_id(void* out_host, int64_t capacity_bytes);       /* 128 bytes (ncclUniqueId) */
+int sae_dist_init(sae_ctx* ctx, const void* unique_id_host, int64_t id_bytes, int rank, int world);
+int sae_dist_world(sae_ctx* ctx);                                      /* 0 without a communicator */
+
 /* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
 int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream);

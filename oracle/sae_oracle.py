@@ -109,7 +109,8 @@ def fp8_scales(x: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
 
 
 def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: float,
-               autocast: bool = True, precision: str = "bf16") -> Dict[str, torch.Tensor]:
+               autocast: bool = True, precision: str = "bf16", dp_count: Optional[float] = None,
+               dp_rows: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """Forward of L1AutoEncoder on flat rows.  ``W`` must already be column-normalised.
 
     src/models/l1autoencoder.py:69-95 (+ mse_loss :29-36).  With ``autocast`` the dtype flow
@@ -124,6 +125,11 @@ def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: f
       x8 = e4m3(bf16(x) s_x), W8 = e4m3(W 2^8), c8 = e4m3(c s_c)   (power-of-two per-tensor scales, fp8_scales()),
       pre = bf16((x8 @ W8) / (s_x 2^8)),  x_hat = bf16((c8 @ W8^T) / (s_c 2^8)),  fp32 accumulation,
     everything else (bias add, ReLU, losses, and the backward on the bf16 latent) as in the bf16 path.
+
+    dp_count / dp_rows (data parallel, not in the reference): this call sees one rank's rows of a larger batch whose
+    unmasked-entry count and row number are given; losses are then this rank's SHARE of the whole batch's losses
+    (they sum over the ranks) and the backward normalises by the global numbers, so that the ranks' gradients sum to
+    the gradient of the whole batch (freud_amd/csrc/dp_kernels.h).
     """
     x = x.to(torch.float32)
     M = x.shape[0]
@@ -148,12 +154,19 @@ def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: f
     count = keep.sum()
     diff = torch.where(keep, x_hat - x, torch.zeros_like(x))
     sq_sum = (diff.double() ** 2).sum()
-    mse_masked = (diff[keep] ** 2).mean() if int(count) > 0 else torch.tensor(float("nan"))
-    l1 = c.abs().sum(dim=1).mean()
+    rows = M
+    if dp_count is None:
+        mse_masked = (diff[keep] ** 2).mean() if int(count) > 0 else torch.tensor(float("nan"))
+        l1 = c.abs().sum(dim=1).mean()
+        mse_plain = ((x_hat - x) ** 2).mean()            # return_mse path (:93-94), unmasked
+    else:
+        count, rows = torch.tensor(float(dp_count), dtype=torch.float64), float(dp_rows)
+        mse_masked = (sq_sum / count).to(torch.float32)
+        l1 = (c.abs().sum().double() / rows).to(torch.float32)
+        mse_plain = (((x_hat - x).double() ** 2).sum() / (rows * x.shape[1])).to(torch.float32)
     recon = recon_alpha * mse_masked
-    mse_plain = ((x_hat - x) ** 2).mean()                # return_mse path (:93-94), unmasked
-    out = {"c": c, "x_hat": x_hat, "l1_loss": l1, "reconstruction_loss": recon,
-           "mse": mse_plain, "keep": keep, "count": count, "diff": diff, "sq_sum": sq_sum}
+    out = {"c": c, "x_hat": x_hat, "l1_loss": l1, "reconstruction_loss": recon, "rows": rows,
+           "mse": mse_plain, "keep": keep, "count": count, "local_count": keep.sum(), "diff": diff, "sq_sum": sq_sum}
     if precision == "fp8":
         out.update({"x8": x8, "c8": c8, "W8": W8, "s_x": sx, "s_c": sc})
     return out
@@ -172,7 +185,7 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
     them *in bf16* before the cast back to fp32 (observed bit-exact against the reference).
     """
     x = x.to(torch.float32)
-    M = x.shape[0]
+    M = fwd.get("rows", x.shape[0])                      # (data parallel: the rows of the whole batch)
     c, diff, count = fwd["c"], fwd["diff"], fwd["count"]
     g = (recon_alpha / count.to(torch.float32))          # d loss / d each squared term
     dx_hat = (diff * 2.0) * g                            # zero where masked
@@ -199,7 +212,7 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
 def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_dec: torch.Tensor,
                  b_dec: torch.Tensor, k: int, dead_mask: Optional[torch.Tensor] = None,
                  auxk_alpha: float = 0.0, autocast: bool = True, multi_topk: bool = False,
-                 stable_ties: bool = False) -> Dict[str, torch.Tensor]:
+                 stable_ties: bool = False, dp_stats: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """src/models/topkautoencoder.py:72-151 on x3 = [B, T, d] (B matters for x.mean(0), :104).
 
       pre   = relu( (x - b_dec) @ W_enc^T + b_enc )                   (:72-77)
@@ -216,6 +229,10 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
     4-50 % of rows) and the reference takes whatever its partial sort leaves.  With stable_ties=True equal values are
     taken lowest column first (a stable descending sort) -- the HIP engine's rule -- so that a batch WITH boundary
     ties can be compared at the arithmetic tolerance; on rows without a boundary tie both selections are the same set.
+
+    dp_stats (data parallel, not in the reference): float64 [2 + 2 T d] = (rows, files, column sums, column sums of squares)
+    of the WHOLE batch (topk_batch_stats summed over the ranks): total_variance and the mse denominator become the global
+    ones, so fvu / auxk / multi / mse are this rank's share of the whole batch's values and the gradients sum exactly.
     """
     B, T, d = x3.shape
     x = x3.reshape(B * T, d).to(torch.float32)
@@ -244,8 +261,15 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
 
     x_hat, dense = decode(top_acts, top_idx)
     e = x_hat - x
-    xm = x3.to(torch.float32).mean(0)                                    # [T, d]
-    total_variance = ((x3.to(torch.float32) - xm) ** 2).sum()
+    if dp_stats is None:
+        xm = x3.to(torch.float32).mean(0)                                # [T, d]
+        total_variance = ((x3.to(torch.float32) - xm) ** 2).sum()
+        mse_den = float(x.numel())
+    else:
+        TD = T * d
+        s1, s2 = dp_stats[2:2 + TD], dp_stats[2 + TD:2 + 2 * TD]
+        total_variance = (s2 - s1 * s1 / dp_stats[1]).sum().to(torch.float32)
+        mse_den = float(dp_stats[0]) * d
     if float(total_variance) == 0.0:
         total_variance = torch.tensor(1.0)
     out = {"pre": pre, "top_acts": top_acts, "top_indices": top_idx, "x_hat": x_hat, "e": e,
@@ -276,8 +300,21 @@ def topk_forward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_d
     else:
         out["multi_topk_fvu"] = torch.tensor(0.0)
         out.update({"fire_indices": top_idx, "sae_out": x_hat})
-    out["mse"] = (e ** 2).mean()
+    out["mse"] = (e ** 2).sum() / mse_den
     return out
+
+
+def topk_batch_stats(x3: torch.Tensor) -> torch.Tensor:
+    """(rows, files, per-(t, feature) sums of x and of x^2 over the files) in float64: dp_kernels.h."""
+    B, T, d = x3.shape
+    xd = x3.to(torch.float32).to(torch.float64).reshape(B, T * d)
+    return torch.cat([torch.tensor([float(B * T), float(B)], dtype=torch.float64), xd.sum(0), (xd * xd).sum(0)])
+
+
+def l1_batch_stats(x: torch.Tensor) -> torch.Tensor:
+    """(unmasked entries, rows) in float64: dp_kernels.h."""
+    x = x.reshape(-1, x.shape[-1]).to(torch.float32)
+    return torch.tensor([float((x != -1.0).sum()), float(x.shape[0])], dtype=torch.float64)
 
 
 def topk_backward(x3: torch.Tensor, W_enc: torch.Tensor, b_enc: torch.Tensor, W_dec: torch.Tensor,

@@ -9,8 +9,10 @@ from oracle import sae_oracle as O
 
 class OracleEngine:
     def __init__(self, variant, d_model, n_dict, max_rows, *, optimizer="radam", recon_alpha=1.0, k=0, auxk_alpha=0.0,
-                 clip_thresh=1.0, weight_decay=0.0, device_id=0, multi_topk=False, **_):
+                 clip_thresh=1.0, weight_decay=0.0, device_id=0, multi_topk=False, autocast=True, **_):
         self.multi_topk = bool(multi_topk)
+        self.autocast = bool(autocast)          # False: fp32 math (data-parallel exactness tests)
+        self.dp_world, self.stats = 0, None
         self.variant, self.d, self.n, self.max_rows = variant, d_model, n_dict, max_rows
         self.optimizer, self.recon_alpha, self.k, self.auxk_alpha = optimizer, recon_alpha, k, auxk_alpha
         self.clip_thresh, self.weight_decay = clip_thresh, weight_decay
@@ -19,7 +21,8 @@ class OracleEngine:
         self.dead_threshold = None
         self.nfsf = torch.zeros(n_dict, dtype=torch.long)
         nflat = sum(int(np.prod(s)) for s in self.param_shapes().values())
-        self.flat = torch.zeros(nflat + 8)
+        self.flat = torch.zeros(nflat + 8 + (n_dict if variant == "topk" else 0))
+        self._nflat = nflat
         self._latent = None
 
     def param_shapes(self):
@@ -60,6 +63,17 @@ class OracleEngine:
     def grad_tensor(self):
         return self.flat
 
+    # data parallel: freud_amd.engine.SaeEngine.batch_stats / stats_tensor / set_dp_world
+    def batch_stats(self, x, stream=None):
+        x = x.detach().cpu()
+        self.stats = O.l1_batch_stats(x) if self.variant == "l1" else O.topk_batch_stats(x.float())
+
+    def stats_tensor(self):
+        return self.stats
+
+    def set_dp_world(self, world):
+        self.dp_world = int(world)
+
     def _pack(self, grads, metrics):
         off = 0
         for k in self.param_shapes():
@@ -74,26 +88,28 @@ class OracleEngine:
             W, b = self.P["decoder.weight"], self.P["encoder_bias"]
             W.copy_(O.normalize_columns(W))
             xf = x.reshape(-1, self.d).float()
-            f = O.l1_forward(xf, W, b, self.recon_alpha, True)
-            dW, db = O.l1_backward(xf, W, b, f, self.recon_alpha, True)
+            dp = {"dp_count": float(self.stats[0]), "dp_rows": float(self.stats[1])} if self.dp_world > 0 else {}
+            f = O.l1_forward(xf, W, b, self.recon_alpha, self.autocast, **dp)
+            dW, db = O.l1_backward(xf, W, b, f, self.recon_alpha, self.autocast)
             self._latent = f["c"]
             self._pack({"decoder.weight": dW, "encoder_bias": db},
-                       [f["reconstruction_loss"].item(), f["l1_loss"].item(), f["mse"].item(), 0.0, float(f["count"])])
+                       [f["reconstruction_loss"].item(), f["l1_loss"].item(), f["mse"].item(), 0.0, float(f["local_count"])])
         else:
             P = self.P
             dead = self.nfsf > self.dead_threshold
             f = O.topk_forward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], self.k, dead,
-                               self.auxk_alpha, True, self.multi_topk)
+                               self.auxk_alpha, self.autocast, self.multi_topk,
+                               dp_stats=self.stats if self.dp_world > 0 else None)
             g = O.topk_backward(x.float(), P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], f,
-                                self.auxk_alpha, True)
+                                self.auxk_alpha, self.autocast)
             did = torch.zeros(self.n, dtype=torch.bool)
             did[f["fire_indices"].flatten()] = True
-            self.nfsf += x.shape[0] * x.shape[1]
-            self.nfsf[did] = 0
+            self._did, self._rows = did, x.shape[0] * x.shape[1]
             self._latent = f["dense"].float()
             self._pack({"encoder.weight": g["W_enc"], "encoder.bias": g["b_enc"], "W_dec": g["W_dec"], "b_dec": g["b_dec"]},
-                       [f["fvu"].item(), f["auxk_loss"].item(), f["mse"].item(), 0.0, 0.0, float(dead.float().mean()),
-                        f["multi_topk_fvu"].item()])
+                       [f["fvu"].item(), f["auxk_loss"].item(), f["mse"].item(), 0.0, 0.0,
+                        float(dead.float().mean()) / max(self.dp_world, 1), f["multi_topk_fvu"].item()])
+            self.flat[-self.n:] = did.float()        # did_fire flags ride in the all-reduced buffer (OR == sum > 0)
 
     def optimizer_step(self, lr, grad_scale=1.0, stream=None):
         off, grads = 0, {}
@@ -112,6 +128,11 @@ class OracleEngine:
         self.flat[off + 3] = gn
         if grad_scale != 1.0:
             self.flat[off:off + 3] *= grad_scale
+            self.flat[off + 5] *= grad_scale
+        if self.variant == "topk":               # train_sae.py:443-446 with the (possibly summed) did_fire flags
+            rows = int(self.stats[0]) if self.dp_world > 0 else self._rows * (round(1.0 / grad_scale) if grad_scale > 0 else 1)
+            self.nfsf += rows
+            self.nfsf[self.flat[-self.n:] > 0] = 0
 
     def step(self, x, lr, stream=None):
         self.forward_backward(x)
@@ -123,12 +144,12 @@ class OracleEngine:
         W.copy_(O.normalize_columns(W))
         f = O.l1_forward(x.reshape(-1, self.d).float(), W, b, self.recon_alpha, True)
         self._latent = f["c"]
-        off = self.flat.numel() - 8
+        off = self._nflat
         self.flat[off:off + 5] = torch.tensor([f["reconstruction_loss"].item(), f["l1_loss"].item(), f["mse"].item(), 0.0,
                                                float(f["count"])])
 
     def metrics(self, stream=None):
-        return self.flat[-8:].numpy().copy()
+        return self.flat[self._nflat:self._nflat + 8].numpy().copy()
 
     def latent_colmax(self, stream=None):
         return self._latent.abs().reshape(-1, self.n).max(0).values.numpy()

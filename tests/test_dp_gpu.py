@@ -1,0 +1,183 @@
+"""GPU: data-parallel exactness of the HIP path on ONE GPU.  Two engine contexts play two ranks: each gets half of the
+rows, the batch statistics (sae_batch_stats) are summed by the test as an all-reduce would, each context's backward
+normalises by the global values (sae_set_dp_world), and the SUM of the two gradient buffers must equal the gradient of
+one context that sees the whole batch -- with masked entries spread unevenly over the halves (different unmasked counts)
+and, for TopK, total_variance around the mean over ALL files.  Also: the statistics kernels against the oracle's, and the
+engine's own RCCL communicator (sae_dist_init) with one rank against the plain single-GPU step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("d,n,M,generic", [(384, 1024, 2048, False), (384, 1024, 2048, True), (768, 1024, 1024, False)])
+def test_l1_two_halves_sum_to_whole_batch(d, n, M, generic):
+    from freud_amd.engine import SaeEngine
+    g = torch.Generator().manual_seed(d + M)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    b = 0.01 * torch.randn(n, generator=g)
+    x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16)
+    x[: M // 8] = torch.where(torch.rand(M // 8, d, generator=g) < 0.5, torch.tensor(-1.0, dtype=torch.bfloat16), x[: M // 8])
+    xd = x.cuda()
+    halves = [xd[: M // 2].contiguous(), xd[M // 2:].contiguous()]
+
+    def make(rows):
+        e = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=rows, optimizer="adam", recon_alpha=1e4, force_generic=generic)
+        e.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        return e
+
+    whole = make(M)
+    whole.batch_stats(xd)
+    st = whole.stats_tensor().cpu()
+    assert torch.equal(st, O.l1_batch_stats(x))                 # (unmasked entries, rows): exact integers
+    whole.forward_backward(xd)
+    torch.cuda.synchronize()
+    ref = whole.grad_tensor().cpu().numpy().copy()
+    ranks = [make(M // 2) for _ in halves]
+    for e, h in zip(ranks, halves):
+        e.batch_stats(h)
+    total = ranks[0].stats_tensor().clone() + ranks[1].stats_tensor()
+    assert total[0].item() != 2 * ranks[0].stats_tensor()[0].item()     # the halves really have different counts
+    acc = None
+    for e, h in zip(ranks, halves):
+        e.stats_tensor().copy_(total)                            # "all-reduce"
+        e.set_dp_world(2)
+        e.forward_backward(h)
+        torch.cuda.synchronize()
+        gbuf = e.grad_tensor().cpu().numpy().copy()
+        acc = gbuf if acc is None else acc + gbuf
+    nW = acc.size - 8
+    assert _rel(acc[:nW], ref[:nW]) < 2e-5                       # gradients: fp32 summation order only
+    np.testing.assert_allclose(acc[nW:nW + 3], ref[nW:nW + 3], rtol=2e-5)       # loss shares sum to the whole batch's losses
+    assert acc[nW + 4] == ref[nW + 4]                            # unmasked count
+    # optimizer on the summed gradient == optimizer of the whole batch
+    for e in ranks:
+        e.grad_tensor().copy_(torch.from_numpy(acc).cuda())
+        e.optimizer_step(1e-3, 1.0)
+    whole.optimizer_step(1e-3, 1.0)
+    assert _rel(ranks[0].get_params()["decoder.weight"], whole.get_params()["decoder.weight"]) < 1e-6
+    assert np.array_equal(ranks[0].get_params()["decoder.weight"], ranks[1].get_params()["decoder.weight"])
+    for e in ranks + [whole]:
+        e.close()
+
+
+def test_topk_two_halves_sum_to_whole_batch():
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T = 384, 1024, 8, 4, 64
+    g = torch.Generator().manual_seed(5)
+    We = torch.randn(n, d, generator=g) / d ** 0.5
+    Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
+    P = {"encoder.weight": We, "encoder.bias": torch.zeros(n), "W_dec": Wd, "b_dec": 0.01 * torch.randn(d, generator=g)}
+    x = (torch.relu(torch.randn(B * T, 48, generator=g)) @ torch.randn(48, d, generator=g) * 0.2).reshape(B, T, d)
+    x[2:] += 0.3                                               # the halves have different means: a local x.mean(0) would differ
+    xd = x.cuda()
+    halves = [xd[:2].contiguous(), xd[2:].contiguous()]
+    nfsf = np.zeros(n, np.int64)
+    nfsf[::7] = 10 ** 6                                        # some dead latents: the AuxK branch runs
+
+    def make(rows):
+        e = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=rows, optimizer="adam", k=k, auxk_alpha=0.03125)
+        e.set_topk_options(1000.0, T)
+        e.set_params({kk: v.numpy() for kk, v in P.items()})
+        e.set_topk_state(nfsf)
+        return e
+
+    whole = make(B * T)
+    whole.batch_stats(xd)
+    np.testing.assert_allclose(whole.stats_tensor().cpu().numpy(), O.topk_batch_stats(x).numpy(), rtol=1e-12, atol=1e-12)
+    whole.forward_backward(xd)
+    torch.cuda.synchronize()
+    ref = whole.grad_tensor().cpu().numpy().copy()
+    ranks = [make(2 * T) for _ in halves]
+    for e, h in zip(ranks, halves):
+        e.batch_stats(h)
+    total = ranks[0].stats_tensor().clone() + ranks[1].stats_tensor()
+    acc = None
+    for e, h in zip(ranks, halves):
+        e.stats_tensor().copy_(total)
+        e.set_dp_world(2)
+        e.forward_backward(h)
+        torch.cuda.synchronize()
+        gbuf = e.grad_tensor().cpu().numpy().copy()
+        acc = gbuf if acc is None else acc + gbuf
+    np_ = 2 * n * d + n + d
+    assert ref[np_ + 1] > 0                                       # AuxK active
+    # (per-rank bf16 roundings of de = 2 e / tv and of the decoder-gradient operands differ from the whole batch's only
+    # through the fp32 value of tv: identical here, so the gradients agree to summation order)
+    assert _rel(acc[:np_], ref[:np_]) < 5e-4
+    np.testing.assert_allclose(acc[np_:np_ + 3], ref[np_:np_ + 3], rtol=1e-4)      # fvu, auxk, mse shares sum up
+    assert acc[np_ + 5] == pytest.approx(ref[np_ + 5], rel=1e-6)                   # dead_pct: 1/world from each rank
+    assert np.array_equal(acc[np_ + 8:] > 0, ref[np_ + 8:] > 0)                    # did_fire: OR == sum > 0
+    for e in ranks:
+        e.grad_tensor().copy_(torch.from_numpy(acc).cuda())
+        e.optimizer_step(1e-4, 1.0)
+    whole.optimizer_step(1e-4, 1.0)
+    assert np.array_equal(ranks[0].get_topk_state(), whole.get_topk_state())       # frames of ALL ranks are counted
+    for e in ranks + [whole]:
+        e.close()
+
+
+_DIST_CHILD = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.environ["FREUD_ROOT"])
+from freud_amd.engine import SaeEngine
+variant = sys.argv[1]
+torch.cuda.set_device(0)
+g = torch.Generator().manual_seed(1)
+d, n, M = (384, 1024, 2048) if variant == "l1" else (768, 2048, 1024)
+x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
+outs = []
+for dist_mode in (False, True):
+    if variant == "l1":
+        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4)
+        W = torch.empty(d, n); torch.nn.init.orthogonal_(W, generator=torch.Generator().manual_seed(2))
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)})
+        key = "decoder.weight"
+    else:
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=16, auxk_alpha=0.03125)
+        eng.set_topk_options(1e9, M)
+        We = (torch.rand(n, d, generator=torch.Generator().manual_seed(2)) * 2 - 1) / d ** 0.5
+        eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32),
+                        "W_dec": (We / We.norm(dim=1, keepdim=True)).numpy(), "b_dec": np.zeros(d, np.float32)})
+        key = "W_dec"
+    if dist_mode:
+        eng.dist_init(SaeEngine.dist_unique_id(), 0, 1)
+        assert eng.dist_world() == 1
+    for i in range(4):
+        eng.step(x, 1e-3)
+    torch.cuda.synchronize()
+    outs.append((eng.get_params()[key].copy(), eng.metrics().copy()))
+    eng.close()
+rel = float(np.linalg.norm(outs[0][0] - outs[1][0]) / np.linalg.norm(outs[0][0]))
+print(json.dumps({"rel": rel, "m0": outs[0][1].tolist(), "m1": outs[1][1].tolist()}))
+"""
+
+
+@pytest.mark.parametrize("variant", ["l1", "topk"])
+def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant):
+    """sae_dist_init with a communicator of ONE rank: statistics all-reduce on the communication stream, gradient ranges
+    all-reduced as they become final, stream joins -- the whole in-engine protocol -- must reproduce the plain step
+    (global statistics == local ones).  Child process: the communicator must not leak into the other tests."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "child.py")
+    open(script, "w").write(_DIST_CHILD)
+    env = dict(os.environ, FREUD_ROOT=root, NCCL_DEBUG_FILE="/tmp/rccl_debug_%h_%p.log")
+    out = subprocess.run([sys.executable, script, variant], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["rel"] < 1e-6, res
+    np.testing.assert_allclose(res["m1"][:4], res["m0"][:4], rtol=1e-5)

@@ -119,11 +119,14 @@ def test_bench_data_parallel_path_single_rank():
     assert res["loss"]["grad_norm"] == pytest.approx(ref["loss"]["grad_norm"], rel=1e-4)
 
 
+@pytest.mark.parametrize("host_driven", ["0", "1"])
 @pytest.mark.parametrize("fixture", ["trainloop_l1", "trainloop_topk"])
-def test_train_data_parallel_path_single_rank(tmp_path, golden_dir, fixture):
-    """train() through its data-parallel code path (RCCL process group of one rank, gradient-ready callback, asynchronous
-    all-reduce of every announced range, separate optimizer call; FREUD_FORCE_DIST=1) ends with the same weights as the
-    single-process path.  Run in a child process: the process group must not leak into the other tests."""
+def test_train_data_parallel_path_single_rank(tmp_path, golden_dir, fixture, host_driven):
+    """train() through its data-parallel code paths with one rank (FREUD_FORCE_DIST=1) ends with the same weights as the
+    single-process path: host_driven 0 = the engine's own RCCL communicator (sae_dist_init; statistics and gradient
+    ranges all-reduced on its communication stream, no Python in the step), 1 = the same protocol from Python through
+    torch.distributed (FREUD_DP_HOST=1: statistics all-reduce, gradient-ready callback, asynchronous all-reduce of every
+    announced range, separate optimizer call).  Run in a child process: the process group must not leak into other tests."""
     import subprocess
     import sys
     z = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
@@ -138,7 +141,7 @@ def test_train_data_parallel_path_single_rank(tmp_path, golden_dir, fixture):
         cfg.update(train_folder=folder, val_folder=folder, run_dir=os.path.join(str(tmp_path), "run" + force), device="cuda")
         cfg_path = os.path.join(str(tmp_path), f"cfg{force}.json")
         json.dump(cfg, open(cfg_path, "w"))
-        env = dict(os.environ, FREUD_FORCE_DIST=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env = dict(os.environ, FREUD_FORCE_DIST=force, FREUD_DP_HOST=host_driven, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
         out = subprocess.run([sys.executable, "-m", "src.scripts.train_sae", "--config", cfg_path], cwd=root, env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
