@@ -92,6 +92,8 @@ def main():
                     help="TopK dead_feature_threshold in frames (configs use 1e6: AuxK switches on after ~16 steps of 65536 "
                          "rows once latents stay silent; 1e15 keeps AuxK off)")
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
+    ap.add_argument("--dp-payload", default="float32", choices=["float32", "bfloat16"],
+                    help="gradient payload of the in-engine all-reduce (bfloat16: fused d=384 path only, half the bytes)")
     ap.add_argument("--dp-host", action="store_true",
                     help="data parallel through torch.distributed from Python (statistics + gradient-range all-reduces) instead "
                          "of the engine's own RCCL communicator")
@@ -155,6 +157,8 @@ def main():
         ids = [SaeEngine.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.dist_init(ids[0], rank, world)
+        if args.dp_payload == "bfloat16":
+            eng.dist_set_payload("bfloat16")
     elif use_dist:
         eng.set_dp_world(world)
         grads = eng.grad_tensor()
@@ -259,7 +263,7 @@ def main():
         "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}",
-                   "dp": (("host-driven (torch.distributed)" if args.dp_host else "in-engine RCCL") if use_dist else "none")},
+                   "dp": (("host-driven (torch.distributed)" if args.dp_host else f"in-engine RCCL, {args.dp_payload} gradients") if use_dist else "none")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,

@@ -12,12 +12,20 @@
 
 constexpr int DP_STATS_HEAD = 2;
 
-// per-block partial counts of x == -1 over M*d elements (fixed order, no atomics)
+// per-block partial counts of x == -1 over M*d elements (fixed order, no atomics); 16-byte loads when x is aligned
 template <typename T>
 __global__ __launch_bounds__(256) void dp_count_masked_kernel(const T* __restrict__ x, int64_t total, unsigned int* __restrict__ part) {
   __shared__ unsigned int red[4];
   unsigned int m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) m += ((float)x[i] == -1.0f);
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef __attribute__((ext_vector_type(V))) T TV;
+  const int64_t nvec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? total / V : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const TV v = reinterpret_cast<const TV*>(x)[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) m += ((float)v[j] == -1.0f);
+  }
+  for (int64_t i = nvec * V + (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) m += ((float)x[i] == -1.0f);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m += (unsigned int)__shfl_xor((int)m, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

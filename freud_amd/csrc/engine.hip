@@ -165,10 +165,14 @@ struct sae_ctx {
   hipEvent_t ev_x = nullptr, ev_stats = nullptr, ev_done = nullptr;
   hipEvent_t ev_range[16] = {};
   int ev_range_i = 0;
+  int payload = SAE_DTYPE_F32;  // SAE_DTYPE_BF16: the fused d = 384 path all-reduces a bf16 copy of the gradient (sae_dist_set_payload)
+  bf16_t* Gb = nullptr;         // that copy
+  bool grads_in_bf16 = false;   // the current step's summed gradient lives in Gb (the optimizer step converts it back)
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
   int profile = 0;
+  int64_t prof_tick = 0;        // forward/backward calls since sae_profile (level 1 samples every PROF_PERIOD-th)
   EvRing ev[KID_COUNT];
   bool ev_init = false;
 };
@@ -185,14 +189,22 @@ static int use_device(const sae_ctx* c) {
   } while (0)
 
 static int dominant_kid(const sae_ctx* c) { return c->topk ? KID_TK_ENC : (c->use_fused_bwd ? KID_BWD_FUSED : KID_DW); }
+// Level 1 brackets the dominant kernel and the whole step on every PROF_PERIOD-th step only: an event record is a packet of
+// its own in the queue and costs ~6 us of idle GPU between two dependent kernels (kernel trace of the C2 step: 3 records
+// per step were 3 % of it), so the timed region of bench.py samples instead of instrumenting every step.
+constexpr int PROF_PERIOD = 8;
+static bool ev_on(const sae_ctx* c, int kid) {
+  if (c->profile >= 2) return true;
+  return c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL) && (c->prof_tick % PROF_PERIOD) == 0;
+}
 static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
-  if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
+  if (ev_on(c, kid)) {
     EvRing& r = c->ev[kid];
     (void)hipEventRecord(r.beg[r.n % EV_RING], s);   // a failure stays sticky and is reported by the hipGetLastError that ends the call
   }
 }
 static void ev_end(sae_ctx* c, int kid, hipStream_t s) {
-  if (c->profile >= 2 || (c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL))) {
+  if (ev_on(c, kid)) {
     EvRing& r = c->ev[kid];
     (void)hipEventRecord(r.end[r.n % EV_RING], s);
     r.n++;
@@ -318,7 +330,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
-                  c->stats, c->stats_part};
+                  c->stats, c->stats_part, c->Gb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->comm) (void)ncclCommDestroy(c->comm);
@@ -604,6 +616,22 @@ static int dist_error = 0;
 static inline void notify_grads(sae_ctx* c, int64_t offset, int64_t count, hipStream_t s) {
   if (count <= 0) return;
   if (c->dist && c->dp_world > 0) {
+    if (c->use_fused_bwd && !c->topk) {
+      // fused d = 384 backward: the whole gradient becomes final at once, nothing is left to overlap with -- the
+      // all-reduce goes on the COMPUTE stream (no cross-stream hand-over: two event hops cost ~20 us of a 600 us step)
+      if (c->payload == SAE_DTYPE_BF16) {     // bf16 copy of the parameters' gradient + the fp32 scalars, one RCCL group
+        const bool ok = ncclGroupStart() == ncclSuccess &&
+                        ncclAllReduce(c->Gb, c->Gb, (size_t)c->nparams, ncclBfloat16, ncclSum, c->comm, s) == ncclSuccess &&
+                        ncclAllReduce(c->G + c->nparams, c->G + c->nparams, (size_t)(count - c->nparams), ncclFloat, ncclSum,
+                                      c->comm, s) == ncclSuccess &&
+                        ncclGroupEnd() == ncclSuccess;
+        if (!ok) dist_error = 1;
+        c->grads_in_bf16 = true;
+      } else if (ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) {
+        dist_error = 1;
+      }
+      return;
+    }
     hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
     if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess ||
         ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess)
@@ -723,6 +751,15 @@ extern "C" int sae_dist_init(sae_ctx* c, const void* unique_id, int64_t id_bytes
 }
 
 extern "C" int sae_dist_world(sae_ctx* c) { return (c && c->dist) ? c->dp_world : 0; }
+
+extern "C" int sae_dist_set_payload(sae_ctx* c, int dtype) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (dtype != SAE_DTYPE_F32 && dtype != SAE_DTYPE_BF16) return fail(SAE_ERR_INVALID, "payload must be SAE_DTYPE_F32 or SAE_DTYPE_BF16");
+  USE_DEVICE(c);
+  if (dtype == SAE_DTYPE_BF16 && !c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
+  c->payload = dtype;
+  return SAE_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // launches
@@ -966,7 +1003,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       int blocks = (int)((n4 + 255) / 256);
       if (blocks > 1024) blocks = 1024;
       hipLaunchKernelGGL(reduce_grads_kernel, dim3(blocks), dim3(256), 0, s, c->slab, nW4, splits, c->db_part, db_rows, n_p,
-                         c->G, nW4, n4, c->gn_part);
+                         c->G, nW4, n4, c->gn_part,
+                         (c->dist && c->dp_world > 0 && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr);
       c->gn_blocks = blocks;
       c->gn_valid = true;
     } else {
@@ -993,6 +1031,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   c->last_M = M;
   c->last_M_p = Mp;
   c->metrics_fresh = true;
+  c->prof_tick++;
   return SAE_OK;
 }
 
@@ -1217,6 +1256,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   c->last_M = M;
   c->last_M_p = Mp;
   c->metrics_fresh = true;
+  c->prof_tick++;
   return SAE_OK;
 }
 
@@ -1245,8 +1285,10 @@ static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, v
   if (rc) return rc;
   if (dp) {
     if (dist_error) return fail(SAE_ERR_HIP, "RCCL all-reduce of a gradient range failed");
-    HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
-    HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    if (!(c->use_fused_bwd && !c->topk)) {      // (the fused path all-reduced on the compute stream itself)
+      HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
+      HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    }
   }
   return SAE_OK;
 }
@@ -1311,7 +1353,10 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   if (gblocks > 1024) gblocks = 1024;
   // the reduction kernel already left the local sum of squares; it is only valid when nothing (no all-reduce, no
   // rescaling) touched the gradient buffer in between, i.e. for the single-GPU sae_step path
-  if (c->gn_valid && grad_scale == 1.0 && c->step_fused_call) {
+  if (c->grads_in_bf16) {     // data parallel, bf16 payload: the summed gradient comes back to fp32 in the same pass
+    hipLaunchKernelGGL(gnorm_from_bf16_kernel, dim3(gblocks), dim3(256), 0, s, c->Gb, c->G, n4, a.grad_scale, c->gn_part);
+    c->grads_in_bf16 = false;
+  } else if (c->gn_valid && grad_scale == 1.0 && c->step_fused_call) {
     gblocks = c->gn_blocks;
   } else {
     hipLaunchKernelGGL(gnorm_partial_kernel, dim3(gblocks), dim3(256), 0, s, c->G, n4, a.grad_scale, c->gn_part);
@@ -1535,6 +1580,7 @@ extern "C" int sae_profile(sae_ctx* c, int level) {
   USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   c->profile = level;
+  c->prof_tick = 0;
   for (auto& r : c->ev) r.n = 0;
   return SAE_OK;
 }

@@ -308,10 +308,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 // Fused gradient reduction: grad[i] = sum_s slab[s][i] over the flat [dW | db] range (db partials live at
 // part_db[s][j]) AND the per-block sum of squares of the result (for clip_grad_norm_ when no data-parallel
 // all-reduce follows).  Fixed order everywhere -> deterministic.
+// grad_bf16 != null (data parallel with a bf16 payload): the same values are also written rounded to bf16, the copy the
+// all-reduce then sums (gnorm_from_bf16_kernel brings the sum back to fp32).
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restrict__ slab, int64_t stride4, int splits,
                                                             const float* __restrict__ db_part, int db_rows, int n_p,
                                                             float* __restrict__ grad, int64_t nW4, int64_t n4,
-                                                            double* __restrict__ gn_part) {
+                                                            double* __restrict__ gn_part, bf16_t* __restrict__ grad_bf16) {
   __shared__ double red[4];
   double ss = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -327,12 +329,31 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restri
       for (int k = 1; k < db_rows; ++k) a += s[j4 + (int64_t)k * (n_p / 4)];
     }
     reinterpret_cast<f32x4*>(grad)[i] = a;
+    if (grad_bf16) reinterpret_cast<bf16x4*>(grad_bf16)[i] = bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
     ss += (double)(a[0] * a[0]) + (double)(a[1] * a[1]) + (double)(a[2] * a[2]) + (double)(a[3] * a[3]);
   }
   ss = wave_sum_d(ss);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
   if (threadIdx.x == 0) gn_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// data parallel, bf16 payload: the all-reduced bf16 gradient back to the fp32 buffer + per-block sum of (scale g)^2
+__global__ __launch_bounds__(256) void gnorm_from_bf16_kernel(const bf16_t* __restrict__ gb, float* __restrict__ grad, int64_t n4,
+                                                               float scale, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const bf16x4 v = reinterpret_cast<const bf16x4*>(gb)[i];
+    const f32x4 g = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    reinterpret_cast<f32x4*>(grad)[i] = g;
+    const f32x4 q = g * scale;
+    s += (double)(q[0] * q[0]) + (double)(q[1] * q[1]) + (double)(q[2] * q[2]) + (double)(q[3] * q[3]);
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // db[j] = sum over row tiles of db_part[tile][j]; block = 32 columns x 8 row lanes (fixed order)

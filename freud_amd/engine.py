@@ -90,6 +90,7 @@ def load() -> C.CDLL:
         "sae_dist_unique_id": (C.c_int, [vp, i64]),
         "sae_dist_init": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
         "sae_dist_world": (C.c_int, [vp]),
+        "sae_dist_set_payload": (C.c_int, [vp, C.c_int]),
         "sae_set_grad_ready_callback": (C.c_int, [vp, GRAD_READY_FN, vp]),
         "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
@@ -120,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
     "sae_set_grad_ready_callback", "sae_batch_stats", "sae_stats_buffer", "sae_set_dp_world", "sae_dist_unique_id",
-    "sae_dist_init", "sae_dist_world", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
     "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
@@ -315,6 +316,10 @@ class SaeEngine:
 
     def dist_world(self) -> int:
         return int(self._lib.sae_dist_world(self._ctx))
+
+    def dist_set_payload(self, dtype: str) -> None:
+        """"float32" (default, exact) or "bfloat16" (fused d=384 path: half the all-reduce bytes)."""
+        _check(self._lib.sae_dist_set_payload(self._ctx, DTYPE[dtype]))
 
     def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))

@@ -164,6 +164,12 @@ int sae_set_dp_world(sae_ctx* ctx, int world);
 int sae_dist_unique_id(void* out_host, int64_t capacity_bytes);       /* 128 bytes (ncclUniqueId) */
 int sae_dist_init(sae_ctx* ctx, const void* unique_id_host, int64_t id_bytes, int rank, int world);
 int sae_dist_world(sae_ctx* ctx);                                      /* 0 without a communicator */
+/* Gradient payload of the in-engine all-reduce: SAE_DTYPE_F32 (default: R ranks == one rank exactly, up to summation
+ * order) or SAE_DTYPE_BF16 -- the fused d = 384 path then sums a bf16 copy of the parameter gradients (half the bytes of
+ * a latency- and link-bound 4.7 MB exchange; the loss scalars stay fp32).  The reference's own CPU autocast rounds these
+ * gradients to bf16 as well (the weight-gradient GEMMs' outputs), so this stays inside the parity tolerance; paths
+ * other than the fused one keep fp32. */
+int sae_dist_set_payload(sae_ctx* ctx, int dtype);
 
 /* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
