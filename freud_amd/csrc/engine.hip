@@ -23,6 +23,7 @@ static thread_local int g_device = 0;  // device of the context the current call
 #include "bwd_fused.h"
 #include "fwd_fused.h"
 #include "topk_kernels.h"
+#include "topk_sparse.h"
 
 // ------------------------------------------------------------------------------------------
 // error handling
@@ -141,10 +142,20 @@ struct sae_ctx {
   bf16_t *de_b = nullptr, *dh_b = nullptr;
   float *e = nullptr, *dh = nullptr, *e2_part = nullptr, *a2_part = nullptr, *dbd_part = nullptr, *ds_part = nullptr, *tkf = nullptr;
   int *top_idx = nullptr, *aux_idx = nullptr, *tk = nullptr;
+  bf16_t *top_vals = nullptr, *aux_vals = nullptr, *multi_vals = nullptr;   // selected activations, compact [M_p][kcap]
+  bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
+  int* dead_hint = nullptr;     // pinned host copy of tk[0] (number of dead latents), refreshed asynchronously every step
   double* tv_part = nullptr;
   long long* nfsf = nullptr;
   long long* dbe_fx = nullptr;  // [n_p] fixed-point d b_enc accumulator of the sparse d-activation kernel
   bool topk_sparse_da = false;  // sparse d pre-activations (topk_dacts_kernel) instead of the dense ddense GEMM + mask
+  // CSC backward (topk_sparse.h): the selection sorted by latent, all three gradients as gathered weighted row sums
+  bool topk_csc = false;
+  unsigned short* csc_counts = nullptr;
+  unsigned int *csc_block_off = nullptr, *csc_total = nullptr, *csc_start = nullptr, *csc_item_start = nullptr, *csc_item_latent = nullptr;
+  CscEntry* csc_entries = nullptr;
+  float *csc_part = nullptr, *csc_pbe = nullptr;
+  int64_t csc_max_items = 0;
   // cfg.multi_topk (topkautoencoder.py:134-140): a second selection of 4k latents, its decode and its FVU / 8 in the loss
   bool multi = false;
   int k4 = 0;
@@ -290,6 +301,10 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->tk, 64);
   TALLOC(c->top_idx, Mp * c->k * 4);
   TALLOC(c->aux_idx, Mp * c->k_aux_cap * 4);
+  TALLOC(c->top_vals, Mp * c->k * 2);
+  TALLOC(c->aux_vals, Mp * c->k_aux_cap * 2);
+  HIP_TRY(hipHostMalloc((void**)&c->dead_hint, 64, hipHostMallocDefault));
+  c->dead_hint[0] = 0;
   TALLOC(c->tv_part, ((Mp * c->d + 255) / 256 + 1) * 8);
   TALLOC(c->nfsf, (size_t)c->n_p * 8);
   TALLOC(c->dbe_fx, (size_t)c->n_p * 8);
@@ -303,9 +318,26 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   if (c->multi) {
     TALLOC(c->multi_dense, Mp * c->n_p * 2);
     TALLOC(c->multi_idx, Mp * c->k4 * 4);
+    TALLOC(c->multi_vals, Mp * c->k4 * 2);
     TALLOC(c->em, Mp * c->d_p * 4);
     TALLOC(c->dm_b, Mp * c->d_p * 2);
     TALLOC(c->m2_part, Mp * 4);
+  }
+  // reserved switches: topk_dense_backward = 1 dense ddense GEMM, 2 = sparse d pre-activations + dense weight-gradient GEMMs
+  c->topk_csc = c->topk_sparse_da && c->n_p <= CSC_MAX_NP && c->cfg.topk_dense_backward == 0;
+  if (c->topk_csc) {
+    const int64_t nb = (Mp + CSC_ROWS - 1) / CSC_ROWS;
+    const int64_t emax = Mp * (int64_t)(c->k + c->k_aux_cap + (c->multi ? c->k4 : 0));
+    c->csc_max_items = c->n_p + emax / CSC_CHUNK + 1;
+    TALLOC(c->csc_counts, nb * c->n_p * 2);
+    TALLOC(c->csc_block_off, nb * c->n_p * 4);
+    TALLOC(c->csc_total, (size_t)c->n_p * 4);
+    TALLOC(c->csc_start, (size_t)(c->n_p + 1) * 4);
+    TALLOC(c->csc_item_start, (size_t)(c->n_p + 1) * 4);
+    TALLOC(c->csc_item_latent, (size_t)c->csc_max_items * 4);
+    TALLOC(c->csc_entries, (size_t)emax * sizeof(CscEntry));
+    TALLOC(c->csc_part, (size_t)c->csc_max_items * 2 * c->d_p * 4);
+    TALLOC(c->csc_pbe, (size_t)c->csc_max_items * 4);
   }
   // the multi-TopK weight gradient is a second GEMM launch into its own split-K slabs
   TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * (c->multi ? 2 : 1) * c->nW * 4);
@@ -330,9 +362,11 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
-                  c->stats, c->stats_part, c->Gb};
+                  c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
+                  c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->dead_hint) (void)hipHostFree(c->dead_hint);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
@@ -1066,6 +1100,15 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   hipLaunchKernelGGL(dead_mask_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
                      c->tkf);
   const bool aux = alpha != 0.f && backward;      // "possible": the device gates it on tk[0] > 0
+  // Which backward: the CSC one (topk_sparse.h) wins by a wide margin while no latent is dead, the dense-GEMM one once the
+  // AuxK pass brings d/2 more entries per row.  Both are correct for any number of dead latents (each gates its AuxK part
+  // on the device), so the choice may rest on a STALE count: the last value of tk[0] that an asynchronous copy happened to
+  // land in pinned host memory (this step's copy is enqueued now and read by some later step; never waited for).
+  const bool use_csc = c->topk_csc && backward && !(aux && c->dead_hint[0] > 0);
+  HIP_TRY(hipMemcpyAsync(c->dead_hint, c->tk, 4, hipMemcpyDeviceToHost, s));
+  // the masked DENSE rows [M x n] are only written for those who read them: the dense fallbacks and validation / inference
+  const bool write_dense = !use_csc;
+  c->dense_valid = write_dense;
 
   {
     const int64_t n8 = c->nW / 8;
@@ -1094,36 +1137,38 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   }
   ev_begin(c, KID_TK_SELECT, s);
   {
-    auto launch_select = [&](bf16_t* dense_out, int* idx_out, float* fire, const unsigned char* dead_mask, const int* k_ptr,
-                             int k_fixed, int kcap) {
+    auto launch_select = [&](bf16_t* dense_out, int* idx_out, bf16_t* vals_out, float* fire, const unsigned char* dead_mask,
+                             const int* k_ptr, int k_fixed, int kcap) {
+      unsigned short* vo = reinterpret_cast<unsigned short*>(vals_out);
+      const int wd = write_dense ? 1 : 0;
       if (n_p <= 2048 * 12)
         hipLaunchKernelGGL(topk_select_reg_kernel<12>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
       else if (n_p <= 2048 * 44)
         hipLaunchKernelGGL(topk_select_reg_kernel<44>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
       else
         hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire, dead_mask,
-                           k_ptr, k_fixed, kcap, n, n_p, M);
+                           k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
     };
     // did_fire follows out.encoded.top_indices (train_sae.py:442), which forward() re-binds to the 4k selection when
     // cfg.multi_topk is set (topkautoencoder.py:135)
-    launch_select(c->dense, c->top_idx, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
-    if (c->multi) launch_select(c->multi_dense, c->multi_idx, did_fire, nullptr, nullptr, c->k4, c->k4);
-    if (aux) launch_select(c->aux_dense, c->aux_idx, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
+    launch_select(c->dense, c->top_idx, c->top_vals, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
+    if (c->multi) launch_select(c->multi_dense, c->multi_idx, c->multi_vals, did_fire, nullptr, nullptr, c->k4, c->k4);
+    if (aux) launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
   }
   ev_end(c, KID_TK_SELECT, s);
   ev_begin(c, KID_TK_DECODE, s);
   {
     auto launch_decode = [&](auto np_tag) {
       constexpr int NP = decltype(np_tag)::value;
-      hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->dense, c->top_idx, k, c->Wd_b,
+      hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->top_vals, c->top_idx, k, c->Wd_b,
                          bd, c->e, c->dh, c->e2_part, M, d, d_p, n_p, 0, (const int*)nullptr);
       if (aux)
-        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_dense, c->aux_idx,
+        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_vals, c->aux_idx,
                            c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1, (const int*)c->tk);
       if (c->multi)     // e_multi = decode(top-4k) - x into its own residual buffer
-        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->multi_dense, c->multi_idx,
+        hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->multi_vals, c->multi_idx,
                            c->k4, c->Wd_b, bd, c->em, c->dh, c->m2_part, M, d, d_p, n_p, 0, (const int*)nullptr);
     };
     if (d_p == 384) launch_decode(std::integral_constant<int, 3>{});
@@ -1145,98 +1190,137 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     const int nrb = (int)((Mp + rpb - 1) / rpb);
     hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
                        c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0, c->tk, c->multi ? c->em : (const float*)nullptr, c->dm_b);
-    if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row
+    if (use_csc) {
+      // ---- CSC backward: selection sorted by latent, then d W_dec, d W_enc and d b_enc as gathered row sums (topk_sparse.h)
+      SparsePasses ps{};
+      if (c->multi) { ps.idx[0] = c->multi_idx; ps.vals[0] = c->multi_vals; ps.g[0] = c->dm_b; ps.kcap[0] = c->k4; }
+      if (aux) { ps.idx[1] = c->aux_idx; ps.vals[1] = c->aux_vals; ps.g[1] = c->dh_b; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
+      ps.idx[2] = c->top_idx; ps.vals[2] = c->top_vals; ps.g[2] = c->de_b; ps.kcap[2] = k;
+      const int nb = (int)((M + CSC_ROWS - 1) / CSC_ROWS);
+      const int lds = n_p * 2;
       ev_begin(c, KID_TK_DDENSE, s);
-      HIP_TRY(hipMemsetAsync(c->dpre, 0, (size_t)Mp * n_p * 2, s));
-      HIP_TRY(hipMemsetAsync(c->dbe_fx, 0, (size_t)n_p * 8, s));
-      DactsPasses ps{};
-      if (c->multi) { ps.g[0] = c->dm_b; ps.dense[0] = c->multi_dense; ps.idx[0] = c->multi_idx; ps.kcap[0] = c->k4; }
-      if (aux) { ps.g[1] = c->dh_b; ps.dense[1] = c->aux_dense; ps.idx[1] = c->aux_idx; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
-      ps.g[2] = c->de_b; ps.dense[2] = c->dense; ps.idx[2] = c->top_idx; ps.kcap[2] = k;
-      auto launch_dacts = [&](auto np_tag) {
-        constexpr int NP = decltype(np_tag)::value;
-        hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, ps, c->Wd_b, c->dpre, c->dbe_fx, M,
-                           n_p, c->tk);
-      };
-      if (d_p == 384) launch_dacts(std::integral_constant<int, 3>{});
-      else if (d_p == 768) launch_dacts(std::integral_constant<int, 6>{});
-      else launch_dacts(std::integral_constant<int, 10>{});
+      hipLaunchKernelGGL(csc_count_kernel, dim3(nb), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_counts);
+      hipLaunchKernelGGL(csc_scan_blocks_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_counts, nb, n_p, c->csc_block_off,
+                         c->csc_total);
+      hipLaunchKernelGGL(csc_scan_latents_kernel, dim3(1), dim3(1024), 0, s, c->csc_total, n_p, c->csc_start, c->csc_item_start);
+      hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent);
+      hipLaunchKernelGGL(csc_fill_kernel, dim3(nb), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_block_off, c->csc_start, c->csc_entries);
       ev_end(c, KID_TK_DDENSE, s);
-    } else {  // dpre = [selected] (de W_dec^T)  (+ aux part) as a dense GEMM with a masking epilogue
-      // (A/B and test path only, topk_dense_backward: its second launch is a host decision, so this path reads num_dead back)
-      int num_dead = 0;
-      if (aux) {
-        HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-      }
-      const bool aux_now = aux && num_dead > 0;
-      GemmArgs g{};
-      g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
-      g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
-      // passes in autograd's execution order (multi-TopK, AuxK, main); each adds into dpre with one bf16 rounding
-      const bf16_t* gsrc[3] = {c->multi ? c->dm_b : nullptr, aux_now ? c->dh_b : nullptr, c->de_b};
-      const bf16_t* sel[3] = {c->multi_dense, c->aux_dense, c->dense};
-      ev_begin(c, KID_TK_DDENSE, s);
-      bool first = true;
-      rc = SAE_OK;
-      for (int pass = 0; pass < 3 && !rc; ++pass) {
-        if (!gsrc[pass]) continue;
-        g.A0 = gsrc[pass];
-        EpiTopkDpre e{};
-        e.sel = sel[pass]; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = first ? 0 : 1; e.last = pass == 2;
-        rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
-        first = false;
-      }
-      ev_end(c, KID_TK_DDENSE, s);
-      if (rc) return rc;
-    }
-    const int splits = c->dw_splits;
-    {  // dW_dec[n][d] = dense^T de (+ aux_dense^T de_hat) (+ multi_dense^T dm as a second launch into its own slabs)
-      GemmArgs g{};
-      g.A0 = c->dense; g.B0 = c->de_b; g.A1 = c->aux_dense; g.B1 = c->dh_b; g.lda = n_p; g.ldb = d_p;
-      g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = aux ? 2 * g.ktiles0 : g.ktiles0;
-      g.seg1_gate = aux ? c->tk : nullptr;          // the AuxK pair joins only while latents are dead
-      g.splits = splits > g.ktiles0 ? g.ktiles0 : splits;
-      const bool slabs = g.splits > 1 || c->multi;
-      EpiSlab e{};
-      e.slab = slabs ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
       ev_begin(c, KID_TK_DWD, s);
-      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
-      int nslabs = g.splits;
-      if (!rc && c->multi) {
-        GemmArgs g2 = g;
-        g2.A0 = c->multi_dense; g2.B0 = c->dm_b; g2.A1 = nullptr; g2.B1 = nullptr; g2.ktiles = g2.ktiles0; g2.seg1_gate = nullptr;
-        EpiSlab e2 = e;
-        e2.slab = c->slab + (int64_t)g.splits * c->nW;
-        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g2, e2, s);
-        nslabs = 2 * g.splits;
-      }
-      if (!rc && slabs) {
-        const int64_t n4 = c->nW / 4;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWd, n4, n4, nslabs);
+      {
+        const unsigned blocks = (unsigned)((c->csc_max_items + 3) / 4);
+        auto launch_sb = [&](auto np_tag) {
+          constexpr int NP = decltype(np_tag)::value;
+          hipLaunchKernelGGL(sparse_bwd_kernel<NP>, dim3(blocks), dim3(256), 0, s, ps, c->xs, c->Wd_b, c->csc_entries, c->csc_start,
+                             c->csc_item_start, c->csc_item_latent, n_p, c->csc_part, c->csc_pbe);
+        };
+        if (d_p == 384) launch_sb(std::integral_constant<int, 3>{});
+        else if (d_p == 768) launch_sb(std::integral_constant<int, 6>{});
+        else launch_sb(std::integral_constant<int, 10>{});
       }
       ev_end(c, KID_TK_DWD, s);
-      if (rc) return rc;
-      notify_grads(c, c->nW + c->n_p, c->nW, s);     // d W_dec is final: its all-reduce runs under the d W_enc GEMM
-    }
-    {  // dW_enc[n][d] = dpre^T sae_in
-      GemmArgs g{};
-      g.A0 = c->dpre; g.B0 = c->xs; g.lda = n_p; g.ldb = d_p;
-      g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
-      g.splits = splits > g.ktiles ? g.ktiles : splits;
-      EpiSlab e{};
-      e.slab = g.splits > 1 ? c->slab : gWe; e.slab_stride = c->nW; e.ld = d_p;
       ev_begin(c, KID_TK_DWE, s);
-      rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
-      if (!rc && g.splits > 1) {
-        const int64_t n4 = c->nW / 4;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWe, n4, n4, g.splits);
-      }
+      hipLaunchKernelGGL(sparse_combine_kernel, dim3(n_p), dim3(256), 0, s, c->csc_part, c->csc_pbe, c->csc_item_start, n_p, d_p, gWd,
+                         gWe, gbe, c->db_part);
       ev_end(c, KID_TK_DWE, s);
-      if (rc) return rc;
+      HIP_TRY(hipGetLastError());
+      notify_grads(c, c->nW + c->n_p, c->nW, s);                 // d W_dec
+    } else {
+    if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row
+        ev_begin(c, KID_TK_DDENSE, s);
+        HIP_TRY(hipMemsetAsync(c->dpre, 0, (size_t)Mp * n_p * 2, s));
+        HIP_TRY(hipMemsetAsync(c->dbe_fx, 0, (size_t)n_p * 8, s));
+        DactsPasses ps{};
+        if (c->multi) { ps.g[0] = c->dm_b; ps.vals[0] = c->multi_vals; ps.idx[0] = c->multi_idx; ps.kcap[0] = c->k4; }
+        if (aux) { ps.g[1] = c->dh_b; ps.vals[1] = c->aux_vals; ps.idx[1] = c->aux_idx; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
+        ps.g[2] = c->de_b; ps.vals[2] = c->top_vals; ps.idx[2] = c->top_idx; ps.kcap[2] = k;
+        auto launch_dacts = [&](auto np_tag) {
+          constexpr int NP = decltype(np_tag)::value;
+          hipLaunchKernelGGL(topk_dacts_kernel<NP>, dim3((unsigned)(Mp / 4)), dim3(256), 0, s, ps, c->Wd_b, c->dpre, c->dbe_fx, M,
+                             n_p, c->tk);
+        };
+        if (d_p == 384) launch_dacts(std::integral_constant<int, 3>{});
+        else if (d_p == 768) launch_dacts(std::integral_constant<int, 6>{});
+        else launch_dacts(std::integral_constant<int, 10>{});
+        ev_end(c, KID_TK_DDENSE, s);
+      } else {  // dpre = [selected] (de W_dec^T)  (+ aux part) as a dense GEMM with a masking epilogue
+        // (A/B and test path only, topk_dense_backward: its second launch is a host decision, so this path reads num_dead back)
+        int num_dead = 0;
+        if (aux) {
+          HIP_TRY(hipMemcpyAsync(&num_dead, c->tk, 4, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        }
+        const bool aux_now = aux && num_dead > 0;
+        GemmArgs g{};
+        g.B0 = c->Wd_b; g.lda = d_p; g.ldb = d_p;
+        g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+        // passes in autograd's execution order (multi-TopK, AuxK, main); each adds into dpre with one bf16 rounding
+        const bf16_t* gsrc[3] = {c->multi ? c->dm_b : nullptr, aux_now ? c->dh_b : nullptr, c->de_b};
+        const bf16_t* sel[3] = {c->multi_dense, c->aux_dense, c->dense};
+        ev_begin(c, KID_TK_DDENSE, s);
+        bool first = true;
+        rc = SAE_OK;
+        for (int pass = 0; pass < 3 && !rc; ++pass) {
+          if (!gsrc[pass]) continue;
+          g.A0 = gsrc[pass];
+          EpiTopkDpre e{};
+          e.sel = sel[pass]; e.dpre = c->dpre; e.dbe_part = c->db_part; e.n_p = n_p; e.accumulate = first ? 0 : 1; e.last = pass == 2;
+          rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+          first = false;
+        }
+        ev_end(c, KID_TK_DDENSE, s);
+        if (rc) return rc;
+      }
+      const int splits = c->dw_splits;
+      {  // dW_dec[n][d] = dense^T de (+ aux_dense^T de_hat) (+ multi_dense^T dm as a second launch into its own slabs)
+        GemmArgs g{};
+        g.A0 = c->dense; g.B0 = c->de_b; g.A1 = c->aux_dense; g.B1 = c->dh_b; g.lda = n_p; g.ldb = d_p;
+        g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = aux ? 2 * g.ktiles0 : g.ktiles0;
+        g.seg1_gate = aux ? c->tk : nullptr;          // the AuxK pair joins only while latents are dead
+        g.splits = splits > g.ktiles0 ? g.ktiles0 : splits;
+        const bool slabs = g.splits > 1 || c->multi;
+        EpiSlab e{};
+        e.slab = slabs ? c->slab : gWd; e.slab_stride = c->nW; e.ld = d_p;
+        ev_begin(c, KID_TK_DWD, s);
+        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+        int nslabs = g.splits;
+        if (!rc && c->multi) {
+          GemmArgs g2 = g;
+          g2.A0 = c->multi_dense; g2.B0 = c->dm_b; g2.A1 = nullptr; g2.B1 = nullptr; g2.ktiles = g2.ktiles0; g2.seg1_gate = nullptr;
+          EpiSlab e2 = e;
+          e2.slab = c->slab + (int64_t)g.splits * c->nW;
+          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g2, e2, s);
+          nslabs = 2 * g.splits;
+        }
+        if (!rc && slabs) {
+          const int64_t n4 = c->nW / 4;
+          hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWd, n4, n4, nslabs);
+        }
+        ev_end(c, KID_TK_DWD, s);
+        if (rc) return rc;
+        notify_grads(c, c->nW + c->n_p, c->nW, s);     // d W_dec is final: its all-reduce runs under the d W_enc GEMM
+      }
+      {  // dW_enc[n][d] = dpre^T sae_in
+        GemmArgs g{};
+        g.A0 = c->dpre; g.B0 = c->xs; g.lda = n_p; g.ldb = d_p;
+        g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
+        g.splits = splits > g.ktiles ? g.ktiles : splits;
+        EpiSlab e{};
+        e.slab = g.splits > 1 ? c->slab : gWe; e.slab_stride = c->nW; e.ld = d_p;
+        ev_begin(c, KID_TK_DWE, s);
+        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+        if (!rc && g.splits > 1) {
+          const int64_t n4 = c->nW / 4;
+          hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab, gWe, n4, n4, g.splits);
+        }
+        ev_end(c, KID_TK_DWE, s);
+        if (rc) return rc;
+      }
     }
     ev_begin(c, KID_REDUCE, s);
-    if (c->topk_sparse_da)
+    if (use_csc) {
+      // (d b_enc and its exact copy came out of sparse_combine_kernel)
+    } else if (c->topk_sparse_da)
       hipLaunchKernelGGL(topk_dbe_from_fx_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->dbe_fx, gbe, c->db_part, n_p);
     else
       hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
@@ -1244,7 +1328,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     ev_begin(c, KID_TK_DSAE, s);
     const int nchunks = (n_p + 255) / 256;
     hipLaunchKernelGGL(topk_dsae_colsum_kernel, dim3((d_p + 255) / 256, nchunks), dim3(256), 0, s,
-                       c->topk_sparse_da ? c->db_part : gbe, c->We_b, c->ds_part, n_p, d_p);
+                       (use_csc || c->topk_sparse_da) ? c->db_part : gbe, c->We_b, c->ds_part, n_p, d_p);
     ev_end(c, KID_TK_DSAE, s);
     hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
     ev_end(c, KID_REDUCE, s);
@@ -1401,10 +1485,26 @@ extern "C" int sae_read_metrics(sae_ctx* c, float out[SAE_NUM_METRICS], void* st
   return SAE_OK;
 }
 
+// TopK: the masked dense rows of the last forward, written on demand when the step itself did not need them
+static int ensure_dense(sae_ctx* c) {
+  if (!c->topk || c->dense_valid || c->last_M <= 0) return SAE_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  hipLaunchKernelGGL(topk_densify_kernel, dim3((unsigned)c->last_M_p), dim3(256), 0, (hipStream_t)0, c->top_vals, c->top_idx, c->k,
+                     c->dense, c->n_p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  c->dense_valid = true;
+  return SAE_OK;
+}
+
 extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
   if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
   USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
+  if (which == 0) {
+    int rc_d = ensure_dense(c);
+    if (rc_d) return rc_d;
+  }
   const int64_t M = c->last_M;
   if (which == 0 || which == 1) {
     const int cols = which == 0 ? c->n : c->d, ld = which == 0 ? c->n_p : c->d_p;
@@ -1481,6 +1581,11 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
 extern "C" int sae_latent_buffer(sae_ctx* c, void** dev_ptr, int64_t* row_stride) {
   if (!c || !dev_ptr || !row_stride) return fail(SAE_ERR_INVALID, "null argument");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  USE_DEVICE(c);
+  {
+    int rc_d = ensure_dense(c);
+    if (rc_d) return rc_d;
+  }
   *dev_ptr = c->topk ? (void*)c->dense : (void*)c->c;
   *row_stride = c->n_p;
   return SAE_OK;
@@ -1559,6 +1664,10 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   if (capacity < c->n) return fail(SAE_ERR_INVALID, "capacity too small");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
   USE_DEVICE(c);
+  {
+    int rc_d = ensure_dense(c);
+    if (rc_d) return rc_d;
+  }
   hipStream_t s = (hipStream_t)stream;
   int* bits = reinterpret_cast<int*>(c->db_part);   // scratch, free outside of a backward pass
   HIP_TRY(hipMemsetAsync(bits, 0, (size_t)c->n_p * 4, s));

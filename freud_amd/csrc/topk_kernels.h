@@ -115,7 +115,8 @@ struct EpiTopkEnc {
 __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
                                                            int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                            const unsigned char* __restrict__ dead, const int* __restrict__ k_ptr,
-                                                           int k_fixed, int kcap, int n, int n_p, int64_t M) {
+                                                           int k_fixed, int kcap, int n, int n_p, int64_t M,
+                                                           unsigned short* __restrict__ vals, int write_dense) {
   if (k_ptr && *k_ptr <= 0) return;     // AuxK pass without dead latents: nothing downstream reads its outputs
   __shared__ int hist[256];
   __shared__ int sel_hi, need, sel_lo, ntie;
@@ -125,8 +126,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
   const unsigned short* p = reinterpret_cast<const unsigned short*>(pre + row * n_p);
   unsigned short* o = reinterpret_cast<unsigned short*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
+  unsigned short* tv = vals + row * kcap;     // the selected activations, compact: tv[p] belongs to ti[p]
   if (k <= 0 || row >= M) {             // padding rows select nothing (and must not mark any latent as fired)
-    for (int i = t; i < n_p; i += 256) o[i] = 0;
+    if (write_dense)
+      for (int i = t; i < n_p; i += 256) o[i] = 0;
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
@@ -202,10 +205,13 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
     if (take) {
       val = (unsigned short)kk;
       const int pos = atomicAdd(&out_pos, 1);
-      if (pos < kcap) ti[pos] = i;
+      if (pos < kcap) {
+        ti[pos] = i;
+        tv[pos] = val;
+      }
       if (did_fire) did_fire[i] = 1.0f;
     }
-    if (i < n_p) o[i] = val;
+    if (write_dense && i < n_p) o[i] = val;
     __syncthreads();
     if (t == 0) tie_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const bf16_t* __restri
 // value; non-candidates -- padding columns, or living latents in the AuxK pass -- become key 0).  The k-th largest
 // key is found by a binary search on the key value; each probe counts "key >= T" on two packed keys per
 // instruction: ((w | 0x80008000) - T*0x00010001) has bit 15 / 31 set exactly where the half is >= T.
+// (That is the general path; nearly every row takes the fast path in front of it -- see there.)
 // Elements > T are selected; ties at T are taken in increasing column order up to k (like the radix kernel above: the
 // engine's tie rule is "lowest column first", what a stable descending sort takes); exact zeros only enter the selection
 // when fewer than k positive candidates exist (then in the same order).  Writes the masked dense row, the index list
@@ -248,7 +255,8 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
-                                                               int n_p, int64_t M) {
+                                                               int n_p, int64_t M, unsigned short* __restrict__ vals,
+                                                               int write_dense) {
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
@@ -259,8 +267,10 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   const u32x4* src = reinterpret_cast<const u32x4*>(pre + row * n_p);
   u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
+  unsigned short* tv = vals + row * kcap;     // the selected activations, compact: tv[p] belongs to ti[p]
   if (row >= M) {                       // padding rows (all-zero pre) select nothing and must not mark any latent as fired
-    for (int g = t; g < nvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
+    if (write_dense)
+      for (int g = t; g < nvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
@@ -313,12 +323,117 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   (void)block_excl_scan_256(ncand_l, sc, &ncand);
   const int k = k_req < ncand ? k_req : ncand;     // where(dead, pre, -inf).topk(k_aux): k_aux <= num_dead by construction
   if (k <= 0) {
+    if (write_dense) {
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v)
-      if (v * 256 + t < nvec) dst[v * 256 + t] = u32x4{0u, 0u, 0u, 0u};
+      for (int v = 0; v < MAXV; ++v)
+        if (v * 256 + t < nvec) dst[v * 256 + t] = u32x4{0u, 0u, 0u, 0u};
+    }
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
+  // ---- fast path (rows with plenty of positive candidates, i.e. nearly all): a PROVABLE lower bound L of the k-th
+  // largest value from the threads' own maxima, then an exact ranking of the few keys >= L.
+  //   Each wave takes the kw-th largest of its 64 lane maxima, kw = ceil(k / 4) (binary search on the value with ballots,
+  //   no barrier): at least kw of its keys are >= that value, so at least 4 kw >= k keys of the row are >= the smallest
+  //   of the four -- L <= k-th largest.  The keys >= L (typically 1-3 k of them) go to LDS as ONE sortable word
+  //   (key << 17 | (0x1FFFF - column): larger = larger value, then lower column, the tie rule), every candidate counts
+  //   the candidates above it -- its rank IS its output slot (sorted by value), ranks below k are the selection.
+  //   This replaces ~18 block-wide counting probes over all n keys (the old path below, kept for rows it cannot take:
+  //   L == 0, k > 256, or more than TOPK_CAND_CAP candidates).
+  constexpr int TOPK_CAND_CAP = 1024;
+  __shared__ unsigned int cand_pk[TOPK_CAND_CAP];
+  __shared__ unsigned int wave_lb[4];
+  __shared__ int cand_cnt;
+  __shared__ unsigned int thr_pk;
+  bool done = false;
+  if (k <= 256) {
+    unsigned int m2 = 0;                               // packed max of the thread's keys (two 16-bit lanes)
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+        const us2 a = __builtin_bit_cast(us2, m2), b = __builtin_bit_cast(us2, keys[v][q]);
+        m2 = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
+      }
+    const unsigned int tmax = max(m2 & 0xFFFFu, m2 >> 16);
+    const int kw = (k + 3) >> 2;
+    unsigned int lo = 0, hi = 0x8000u;                 // largest lw with #(lane maxima >= lw) >= kw (lw = 0 always qualifies)
+    while (lo < hi) {
+      const unsigned int mid = (lo + hi + 1) >> 1;
+      if (__popcll(__ballot(tmax >= mid)) >= kw) lo = mid; else hi = mid - 1;
+    }
+    if ((t & 63) == 0) wave_lb[t >> 6] = lo;
+    if (t == 0) cand_cnt = 0;
+    __syncthreads();
+    const unsigned int L = min(min(wave_lb[0], wave_lb[1]), min(wave_lb[2], wave_lb[3]));
+    if (L > 0) {                                       // block-uniform
+      const unsigned int lp = L * 0x00010001u;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned int w = keys[v][q];
+          if ((((w | 0x80008000u) - lp) & 0x80008000u) != 0u) {        // at least one of the pair is >= L (rare)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const unsigned int key = (w >> (16 * h)) & 0xFFFFu;
+              if (key >= L) {                          // (non-candidates carry key 0 < L)
+                const int col = 8 * (v * 256 + t) + 2 * q + h;
+                const int pos = atomicAdd(&cand_cnt, 1);
+                if (pos < TOPK_CAND_CAP) cand_pk[pos] = (key << 17) | (0x1FFFFu - (unsigned int)col);
+              }
+            }
+          }
+        }
+      __syncthreads();
+      const int C = cand_cnt;
+      if (C <= TOPK_CAND_CAP) {                        // block-uniform; C >= k by construction
+        for (int i = t; i < C; i += 256) {
+          const unsigned int my = cand_pk[i];
+          int rank = 0;
+          for (int j = 0; j < C; ++j) rank += cand_pk[j] > my ? 1 : 0;
+          if (rank < k) {
+            const int col = (int)(0x1FFFFu - (my & 0x1FFFFu));
+            if (rank < kcap) {
+              ti[rank] = col;
+              tv[rank] = (unsigned short)(my >> 17);
+            }
+            if (did_fire) did_fire[col] = 1.0f;
+            if (rank == k - 1) thr_pk = my;
+          }
+        }
+        for (int j = k + t; j < kcap; j += 256) ti[j] = -1;
+        if (write_dense) {                             // the masked dense row for those who read it (validation, fallbacks)
+          __syncthreads();
+          const unsigned int thr = thr_pk;
+#pragma unroll
+          for (int v = 0; v < MAXV; ++v) {
+            const int g = v * 256 + t;
+            if (g < nvec) {
+              u32x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                unsigned int w = keys[v][q], keep = 0u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const unsigned int key = (w >> (16 * h)) & 0xFFFFu;
+                  const unsigned int pk = (key << 17) | (0x1FFFFu - (unsigned int)(8 * g + 2 * q + h));
+                  keep |= (key >= L && pk >= thr) ? (0xFFFFu << (16 * h)) : 0u;
+                }
+                o[q] = w & keep;
+              }
+              dst[g] = o;
+            }
+          }
+        }
+        done = true;
+      }
+    }
+  }
+  if (done) return;
+  __syncthreads();
+
   // ---- largest T in [1, 0x8000] with count(key >= T) >= k; T = 0 if fewer than k positive keys
   const int npos = count_ge(1u);
   unsigned T = 0;
@@ -384,24 +499,43 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   for (int v = 0; v < MAXV; ++v) {
     const int g = v * 256 + t;
     if (g < nvec) {
-      u32x4 o;
+      if (write_dense) {          // the masked dense row: only the inference / validation calls and the dense fallbacks read it
+        u32x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned m = ((selmask[v] >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((selmask[v] >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
-        o[q] = keys[v][q] & m;
+        for (int q = 0; q < 4; ++q) {
+          const unsigned m = ((selmask[v] >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((selmask[v] >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
+          o[q] = keys[v][q] & m;
+        }
+        dst[g] = o;
       }
-      dst[g] = o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if ((selmask[v] >> e) & 1u) {
           const int col = 8 * g + e;
-          if (pos < kcap) ti[pos] = col;
+          if (pos < kcap) {
+            ti[pos] = col;
+            tv[pos] = (unsigned short)((keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+          }
           ++pos;
           if (did_fire) did_fire[col] = 1.0f;
         }
     }
   }
   for (int j = sel_tot + t; j < kcap; j += 256) ti[j] = -1;
+}
+
+// masked dense row from the compact selection (only when somebody asks for it: sae_latent_buffer, sae_latent_colmax,
+// sae_debug_read after a training forward, which does not write the dense rows): one block per row
+__global__ __launch_bounds__(256) void topk_densify_kernel(const bf16_t* __restrict__ vals, const int* __restrict__ idx, int kcap,
+                                                            bf16_t* __restrict__ dense, int n_p) {
+  const int64_t row = blockIdx.x;
+  u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
+  for (int g = threadIdx.x; g < n_p / 8; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  for (int p = threadIdx.x; p < kcap; p += 256) {
+    const int j = idx[row * kcap + p];
+    if (j >= 0) dense[row * n_p + j] = vals[row * kcap + p];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,7 +549,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
 // NPAIR > 0: d_p == 128 * NPAIR is a compile-time constant, so a lane's 4 * NPAIR bytes of a W_dec row are fetched with
 // unconditional (mergeable into dwordx2/x4) loads and two gathered rows are kept in flight; NPAIR == 0: any d_p <= 1536.
 template <typename T, int NPAIR = 0>
-__global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ dense,
+__global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ vals,
                                                            const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
                                                            const float* __restrict__ b_dec, float* __restrict__ e,
                                                            float* __restrict__ dh, float* __restrict__ part, int64_t M, int d,
@@ -430,12 +564,12 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 2 * MAXP; ++i) acc[i] = 0.f;
   const int* ri = idx + row * kcap;
-  const bf16_t* rd = dense + row * n_p;
+  const bf16_t* rv = vals + row * kcap;      // compact selected activations, rv[p] <-> ri[p]
   for (int j0 = 0; j0 < kcap; j0 += 64) {
     // 64 (index, activation) pairs at a time, one per lane, broadcast with readlane-style shuffles
     const int jj = j0 + lane;
     const int my_i = jj < kcap ? ri[jj] : -1;
-    const float my_a = my_i >= 0 ? (float)rd[my_i] : 0.f;
+    const float my_a = my_i >= 0 ? (float)rv[jj] : 0.f;
     const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
     if constexpr (NPAIR > 0) {
       // two gathered rows per trip (negative = padding index: row 0 is read and weighted by 0)
@@ -602,7 +736,7 @@ constexpr double TOPK_FX_SCALE = 1099511627776.0;   // 2^40
 // of `pre` with one rounding, which the read-add-write below reproduces)
 struct DactsPasses {
   const bf16_t* g[3];       // d output of the decode [M_p][d_p] (null = pass absent)
-  const bf16_t* dense[3];   // its masked dense activations [M_p][n_p]
+  const bf16_t* vals[3];    // its selected activations, compact [M_p][kcap]
   const int* idx[3];        // its index list [M_p][kcap]
   int kcap[3];
   int gated[3];             // 1: runs only while tk[0] > 0 (AuxK)
@@ -620,8 +754,8 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(DactsPasses ps, const b
   for (int pass = 0; pass < 3; ++pass) {
     const bf16_t* gsrc = ps.g[pass];
     if (!gsrc || (ps.gated[pass] && tk[0] <= 0)) continue;      // the AuxK pass needs dead latents (device-side decision)
-    const bf16_t* rd = ps.dense[pass] + row * n_p;
     const int kcap = ps.kcap[pass];
+    const bf16_t* rv = ps.vals[pass] + row * kcap;
     const int* ri = ps.idx[pass] + row * kcap;
     float g[2 * NPAIR];
     {
@@ -637,7 +771,7 @@ __global__ __launch_bounds__(256) void topk_dacts_kernel(DactsPasses ps, const b
     for (int j0 = 0; j0 < kcap; j0 += 64) {
       const int jj = j0 + lane;
       const int my_i = jj < kcap ? ri[jj] : -1;
-      const float my_a = my_i >= 0 ? (float)rd[my_i] : 0.f;
+      const float my_a = my_i >= 0 ? (float)rv[jj] : 0.f;
       const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
       for (int j = 0; j < cnt; j += 2) {
         const int j1 = j + 1 < cnt ? j + 1 : j;

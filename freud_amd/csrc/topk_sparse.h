@@ -1,0 +1,246 @@
+// Sparse backward of the TopK SAE (reference: autograd of src/models/topkautoencoder.py:72-91, where the decoder input is
+// the top-k activations SCATTERED into a dense [M x n] row and every gradient GEMM runs densely on 99.7 % zeros).
+//
+// Only the selected (row m, latent j) pairs carry gradient.  With g = d loss / d (decoder output) of a decode pass
+// (main: de, AuxK: de_hat, multi-TopK: dm) and a = its selected activation:
+//     da        = bf16( g[m] . W_dec[j] )                (one rounding, like the dense GEMM output it replaces)
+//     dW_dec[j] += a  * g[m]           dW_enc[j] += da * sae_in[m]          d b_enc[j] += da        (ReLU gate: a > 0)
+// i.e. per LATENT a weighted sum of gathered rows.  The pairs are first sorted by latent (a CSC view of the selection)
+// and one wave then owns a latent (or a chunk of a long list): W_dec[j] and both accumulator rows stay in registers,
+// each entry costs two gathered rows (g[m], sae_in[m]; 3 KB at d = 768, served by L2 / Infinity Cache: both arrays
+// are 100 MB) instead of three dense [M x n] GEMM passes + a dense [M x n] dpre.
+//
+// Determinism: the CSC order inside a latent's list is fixed by construction (row block, then row, then pass -- never by
+// which thread got there first), every work item writes its partial sums to its own slot, and a last kernel adds the
+// slots of a latent in order: run-to-run bitwise identical, no float atomics.
+//
+// CSC build (stable counting sort by latent):
+//   1. csc_count:  one WAVE per block of CSC_ROWS rows counts its entries per latent in LDS (u16 counters, n_p <= 32768);
+//   2. csc_scan_blocks: per latent, exclusive prefix over the row blocks (+ the latent's total);
+//   3. csc_scan_latents: exclusive prefix over the latents (list starts) and over the work-item counts;
+//   4. csc_fill:   the same wave walks its rows IN ORDER; an LDS add-with-return hands every entry its rank inside
+//                  (block, latent) -- LDS operations of one wave execute in program order, and the indices of one
+//                  (row, pass) are distinct, so the ranks do not depend on timing.
+#pragma once
+#include "topk_kernels.h"
+
+constexpr int CSC_ROWS = 64;          // rows per counting block (one wave)
+constexpr int CSC_MAX_NP = 32768;     // u16 LDS counters: 64 KiB per wave
+constexpr int CSC_CHUNK = 256;        // entries per work item of the gradient kernel
+
+struct SparsePasses {                 // autograd's execution order: multi-TopK, AuxK, main
+  const int* idx[3];                  // [M_p][kcap] (null = pass absent)
+  const bf16_t* vals[3];              // selected activations of the pass, compact [M_p][kcap]
+  const bf16_t* g[3];                 // d (decoder output) [M_p][d_p]
+  int kcap[3];
+  int gated[3];                       // 1: only while tk[0] > 0 (AuxK)
+};
+
+struct CscEntry {                     // 8 bytes
+  unsigned int row_pass;              // row | pass << 30
+  float act;
+};
+
+// ---- 1. counts[b][j] (u16) --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const int* __restrict__ tk, int64_t M, int n_p,
+                                                       unsigned short* __restrict__ counts) {
+  extern __shared__ unsigned int ctr32[];                     // n_p / 2 words = n_p u16 counters
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
+  for (int i = lane; i < n_p / 2; i += 64) ctr32[i] = 0u;
+  __syncthreads();
+  for (int pass = 0; pass < 3; ++pass) {
+    if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
+    const int kcap = ps.kcap[pass];
+    for (int r = 0; r < CSC_ROWS && r0 + r < M; ++r) {
+      const int* ri = ps.idx[pass] + (r0 + r) * kcap;
+      for (int q = lane; q < kcap; q += 64) {
+        const int j = ri[q];
+        if (j >= 0) atomicAdd(&ctr32[j >> 1], (j & 1) ? 0x10000u : 1u);      // (a block holds < 65536 entries of a latent)
+      }
+    }
+  }
+  __syncthreads();
+  unsigned int* out = reinterpret_cast<unsigned int*>(counts + (int64_t)blockIdx.x * n_p);
+  for (int i = lane; i < n_p / 2; i += 64) out[i] = ctr32[i];
+}
+
+// ---- 2. per latent: exclusive prefix over the row blocks, total -----------------------------------------------------------
+__global__ __launch_bounds__(256) void csc_scan_blocks_kernel(const unsigned short* __restrict__ counts, int nblocks, int n_p,
+                                                              unsigned int* __restrict__ block_off, unsigned int* __restrict__ total) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_p) return;
+  unsigned int run = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    block_off[(int64_t)b * n_p + j] = run;
+    run += counts[(int64_t)b * n_p + j];
+  }
+  total[j] = run;
+}
+
+// ---- 3. one block: list starts and work-item starts (exclusive prefixes over the latents) ---------------------------------
+//   start[j] (j <= n_p), item_start[j] (j <= n_p) with ceil(total / CSC_CHUNK) items per latent (none for an empty list)
+__global__ __launch_bounds__(1024) void csc_scan_latents_kernel(const unsigned int* __restrict__ total, int n_p,
+                                                                unsigned int* __restrict__ start, unsigned int* __restrict__ item_start) {
+  __shared__ unsigned int wsum[2][16];
+  __shared__ unsigned int carry[2];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  for (int base = 0; base < n_p; base += 1024) {
+    const int j = base + t;
+    const unsigned int c = j < n_p ? total[j] : 0u;
+    unsigned int v0 = c, v1 = (c + CSC_CHUNK - 1) / CSC_CHUNK;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int a = __shfl_up(v0, o, 64), b = __shfl_up(v1, o, 64);
+      if (lane >= o) { v0 += a; v1 += b; }
+    }
+    if (lane == 63) { wsum[0][w] = v0; wsum[1][w] = v1; }
+    __syncthreads();
+    unsigned int p0 = carry[0], p1 = carry[1];
+    for (int ww = 0; ww < w; ++ww) { p0 += wsum[0][ww]; p1 += wsum[1][ww]; }
+    if (j < n_p) {
+      start[j] = p0 + v0 - c;
+      item_start[j] = p1 + v1 - (c + CSC_CHUNK - 1) / CSC_CHUNK;
+    }
+    __syncthreads();
+    if (t == 1023) { carry[0] = p0 + v0; carry[1] = p1 + v1; }
+    __syncthreads();
+  }
+  if (t == 0) { start[n_p] = carry[0]; item_start[n_p] = carry[1]; }
+}
+
+// ---- 3b. item -> latent table (one thread per latent writes its chunks' slots) --------------------------------------------------
+__global__ __launch_bounds__(256) void csc_items_kernel(const unsigned int* __restrict__ item_start, int n_p,
+                                                        unsigned int* __restrict__ item_latent) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_p) return;
+  for (unsigned int i = item_start[j]; i < item_start[j + 1]; ++i) item_latent[i] = (unsigned int)j;
+}
+
+// ---- 4. fill: entries[start[j] + block_off[b][j] + rank] ----------------------------------------------------------------------
+__global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int* __restrict__ tk, int64_t M, int n_p,
+                                                      const unsigned int* __restrict__ block_off, const unsigned int* __restrict__ start,
+                                                      CscEntry* __restrict__ entries) {
+  extern __shared__ unsigned int ctr32[];
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
+  for (int i = lane; i < n_p / 2; i += 64) ctr32[i] = 0u;
+  __syncthreads();
+  const unsigned int* boff = block_off + (int64_t)blockIdx.x * n_p;
+  for (int pass = 0; pass < 3; ++pass) {
+    if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
+    const int kcap = ps.kcap[pass];
+    for (int r = 0; r < CSC_ROWS && r0 + r < M; ++r) {
+      const int64_t row = r0 + r;
+      const int* ri = ps.idx[pass] + row * kcap;
+      const bf16_t* rv = ps.vals[pass] + row * kcap;
+      for (int q = lane; q < kcap; q += 64) {
+        const int j = ri[q];
+        if (j < 0) continue;
+        // rank inside (block, latent): LDS add with return; one wave, program order, distinct j within a (row, pass)
+        const unsigned int old = atomicAdd(&ctr32[j >> 1], (j & 1) ? 0x10000u : 1u);
+        const unsigned int rank = (j & 1) ? (old >> 16) : (old & 0xFFFFu);
+        CscEntry e;
+        e.row_pass = (unsigned int)row | ((unsigned int)pass << 30);
+        e.act = (float)rv[q];
+        entries[start[j] + boff[j] + rank] = e;
+      }
+    }
+  }
+}
+
+// ---- 5. gradient work items -----------------------------------------------------------------------------------------------
+// item -> (latent j = item_latent[item], chunk item - item_start[j]); partial sums to part[item][2][d_p] and pbe[item].
+template <int NPAIR>
+__global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const bf16_t* __restrict__ xs, const bf16_t* __restrict__ Wd,
+                                                         const CscEntry* __restrict__ entries, const unsigned int* __restrict__ start,
+                                                         const unsigned int* __restrict__ item_start,
+                                                         const unsigned int* __restrict__ item_latent, int n_p,
+                                                         float* __restrict__ part, float* __restrict__ pbe) {
+  constexpr int d_p = 128 * NPAIR, CPL = 2 * NPAIR;           // columns per lane
+  const int lane = threadIdx.x & 63;
+  const unsigned int nitems = item_start[n_p];
+  const unsigned int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nitems) return;                                 // wave-uniform
+  const int j = (int)item_latent[item];
+  const unsigned int e0 = start[j] + (item - item_start[j]) * CSC_CHUNK;
+  const unsigned int e1 = min(e0 + CSC_CHUNK, start[j + 1]);
+  const int c0 = lane * CPL;
+  float wd[CPL], accd[CPL], acce[CPL];
+  {
+    const unsigned* wp = reinterpret_cast<const unsigned*>(Wd + (int64_t)j * d_p + c0);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      const unsigned u = wp[p];
+      wd[2 * p] = __uint_as_float(u << 16);
+      wd[2 * p + 1] = __uint_as_float(u & 0xFFFF0000u);
+      accd[2 * p] = accd[2 * p + 1] = acce[2 * p] = acce[2 * p + 1] = 0.f;
+    }
+  }
+  float dbe = 0.f;
+  for (unsigned int e = e0; e < e1; e += 2) {                 // two entries in flight
+    const bool two = e + 1 < e1;
+    const CscEntry ea = entries[e], eb = entries[two ? e + 1 : e];
+    const int64_t ma = ea.row_pass & 0x3FFFFFFFu, mb = eb.row_pass & 0x3FFFFFFFu;
+    const unsigned* ga = reinterpret_cast<const unsigned*>(ps.g[ea.row_pass >> 30] + ma * d_p + c0);
+    const unsigned* gb = reinterpret_cast<const unsigned*>(ps.g[eb.row_pass >> 30] + mb * d_p + c0);
+    const unsigned* xa = reinterpret_cast<const unsigned*>(xs + ma * d_p + c0);
+    const unsigned* xb = reinterpret_cast<const unsigned*>(xs + mb * d_p + c0);
+    unsigned ua[NPAIR], ub[NPAIR], va[NPAIR], vb[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) { ua[p] = ga[p]; ub[p] = gb[p]; }
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) { va[p] = xa[p]; vb[p] = xb[p]; }
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      sa += __uint_as_float(ua[p] << 16) * wd[2 * p] + __uint_as_float(ua[p] & 0xFFFF0000u) * wd[2 * p + 1];
+      sb += __uint_as_float(ub[p] << 16) * wd[2 * p] + __uint_as_float(ub[p] & 0xFFFF0000u) * wd[2 * p + 1];
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    const float aa = ea.act, ab = two ? eb.act : 0.f;
+    const float da = aa > 0.f ? bf16_round(sa) : 0.f, db = ab > 0.f ? bf16_round(sb) : 0.f;    // ReLU gate
+    dbe += da + db;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      accd[2 * p] += aa * __uint_as_float(ua[p] << 16) + ab * __uint_as_float(ub[p] << 16);
+      accd[2 * p + 1] += aa * __uint_as_float(ua[p] & 0xFFFF0000u) + ab * __uint_as_float(ub[p] & 0xFFFF0000u);
+      acce[2 * p] += da * __uint_as_float(va[p] << 16) + db * __uint_as_float(vb[p] << 16);
+      acce[2 * p + 1] += da * __uint_as_float(va[p] & 0xFFFF0000u) + db * __uint_as_float(vb[p] & 0xFFFF0000u);
+    }
+  }
+  float* po = part + (int64_t)item * 2 * d_p + c0;
+#pragma unroll
+  for (int p = 0; p < CPL; ++p) {
+    po[p] = accd[p];
+    po[d_p + p] = acce[p];
+  }
+  if (lane == 0) pbe[item] = dbe;
+}
+
+// ---- 6. per latent: its items' partial sums in order -> dW_dec[j], dW_enc[j], d b_enc[j] (bf16-rounded) + exact copy ------------
+__global__ __launch_bounds__(256) void sparse_combine_kernel(const float* __restrict__ part, const float* __restrict__ pbe,
+                                                             const unsigned int* __restrict__ item_start, int n_p, int d_p,
+                                                             float* __restrict__ gWd, float* __restrict__ gWe, float* __restrict__ gbe,
+                                                             float* __restrict__ dbe_exact) {
+  const int j = blockIdx.x;
+  const unsigned int i0 = item_start[j], i1 = item_start[j + 1];
+  for (int c = threadIdx.x; c < d_p; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (unsigned int i = i0; i < i1; ++i) {
+      a += part[(int64_t)i * 2 * d_p + c];
+      b += part[(int64_t)i * 2 * d_p + d_p + c];
+    }
+    gWd[(int64_t)j * d_p + c] = a;
+    gWe[(int64_t)j * d_p + c] = b;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (unsigned int i = i0; i < i1; ++i) s += pbe[i];
+    dbe_exact[j] = s;
+    gbe[j] = bf16_round(s);
+  }
+}

@@ -169,7 +169,7 @@ class SaeEngine:
         cfg.debug_flags = debug_flags                 # timing experiments only (results become wrong)
         cfg.force_generic = 1 if force_generic else 0   # 1 = generic three-GEMM backward even where a fused kernel exists
         cfg.force_gemm128 = 1 if force_gemm128 else 0   # 1 = 128x128 GEMM tiles even where the 256x256 kernel applies
-        cfg.topk_dense_backward = 1 if topk_dense_backward else 0   # 1 = TopK d pre-activations by the dense GEMM + mask
+        cfg.topk_dense_backward = int(topk_dense_backward)   # 0 = CSC sparse backward; 1 = dense GEMM + mask; 2 = sparse dpre + dense dW GEMMs
         cfg.multi_topk = 1 if multi_topk else 0       # TopKAutoEncoderConfig.multi_topk
         if precision not in PRECISION:
             raise ValueError(f"Invalid precision: {precision}, must be one of {sorted(PRECISION)}")

@@ -231,14 +231,15 @@ def test_topk_auxk_and_dead_bookkeeping():
 
 
 def test_sparse_dacts_matches_dense_ddense():
-    """TopK backward: the sparse d pre-activation kernel (gathered dot products on the selected latents, exact fixed-point
-    d b_enc) and the dense GEMM + mask it replaces give the same gradients, with AuxK active (dead latents) as well."""
+    """TopK backward, three implementations of the same gradients, with AuxK active (dead latents) as well: 0 = the CSC
+    sparse backward (selection sorted by latent, gathered row sums: topk_sparse.h), 2 = sparse d pre-activations (gathered
+    dot products, exact fixed-point d b_enc) + dense weight-gradient GEMMs, 1 = everything as dense GEMMs + mask."""
     from freud_amd.engine import SaeEngine
     d, n, k, B, T, aux = 384, 1024, 16, 2, 64, 0.03125
     P, x = _make_case(d, n, k, B, T, 9)
     xd = x.cuda()
     res = []
-    for dense in (False, True):
+    for dense in (0, 1, 2):
         eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=B * T, optimizer="adam", k=k, auxk_alpha=aux,
                         topk_dense_backward=dense)
         eng.set_topk_options(0.5 * B * T, T)
@@ -252,10 +253,11 @@ def test_sparse_dacts_matches_dense_ddense():
         assert m[1] > 0                         # AuxK was active
         res.append(grads)
         eng.close()
-    for gs, gd in zip(*res):
-        s_, d_ = _split(gs, n, d), _split(gd, n, d)
-        for key in KEYS:
-            assert _rel(s_[key], d_[key]) < 2e-3, key
+    for other in (0, 2):
+        for gs, gd in zip(res[other], res[1]):
+            s_, d_ = _split(gs, n, d), _split(gd, n, d)
+            for key in KEYS:
+                assert _rel(s_[key], d_[key]) < 2e-3, (other, key)
     # determinism of the fixed-point bias-gradient accumulation: two sparse runs are bitwise equal
     eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=B * T, optimizer="adam", k=k, auxk_alpha=aux)
     eng.set_topk_options(0.5 * B * T, T)
