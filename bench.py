@@ -17,10 +17,10 @@ GEMM pair), timed with HIP events on the launch stream inside the timed region; 
 the CPU oracle (oracle/sae_oracle.py, a port of the reference's step) timed on this box's host
 cores on a bounded sample (rank 0, N=1 only).
 
-Before the W warm-up steps the same step is run untimed for --spinup seconds (default 1 s): an idle MI355X starts in a
-low power state and needs some tens of milliseconds of load to reach its sustained clocks; without it a 10 + 50 step
-run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second or more.  The timed region is still
-exactly K steps after W warm-up steps.
+Before the W warm-up steps the GPU is held at load for --spinup seconds (default 1 s) by a bare MFMA loop (sae_spinup):
+an idle MI355X starts in a low power state and needs some tens of milliseconds of load to reach its sustained clocks;
+without it a 10 + 50 step run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second or more.  The
+timed region is still exactly K steps after W warm-up steps.
 """
 import argparse
 import json
@@ -179,18 +179,11 @@ def main():
             eng.step(x, lr_of(i))
 
     if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
-        t_spin = time.perf_counter()
-        while True:
-            for _ in range(20):
-                one_step(0)
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t_spin
-            if use_dist:                     # every rank must leave after the same number of (collective) steps
-                te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-                dist.all_reduce(te, op=dist.ReduceOp.MAX)
-                elapsed = float(te.item())
-            if elapsed >= args.spinup:
-                break
+        # a bare MFMA loop of the engine's own (sae_spinup), NOT the step kernels: a profiler's per-kernel statistics of
+        # the step then cover only launches on sustained clocks (the first ~100 steps of a cold chip run 25 % slow)
+        eng.spinup(args.spinup)
+        if use_dist:
+            dist.barrier()
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -245,15 +238,17 @@ def main():
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the value
     # measured with rocprofv3 (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes for gfx950) is kept under profiles/ and quoted when the workload matches
-    traffic = None
+    traffic, traffic_source = None, None
     try:
-        if args.variant == "l1" and (M, d, n) == (65536, 384, 3072):
+        if args.variant == "l1" and args.precision == "bf16" and (M, d, n) == (65536, 384, 3072):
             import glob
             latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]   # newest round's pass
             with open(latest) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_source = (f"profiles/{os.path.basename(latest)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command (FETCH_SIZE doubled per the gfx950 correction), recorded earlier -- not measured in this run")
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
 
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
@@ -265,7 +260,7 @@ def main():
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}",
                    "dp": (("host-driven (torch.distributed)" if args.dp_host else f"in-engine RCCL, {args.dp_payload} gradients") if use_dist else "none")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "kernel": dom,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,
                      "flops_per_launch": dom_flops, "peak_measured_bare_mfma_loop": MEASURED_MFMA_LOOP_TFLOPS,
                      "frac_of_measured": achieved / MEASURED_MFMA_LOOP_TFLOPS},
