@@ -17,10 +17,12 @@ GEMM pair), timed with HIP events on the launch stream inside the timed region; 
 the CPU oracle (oracle/sae_oracle.py, a port of the reference's step) timed on this box's host
 cores on a bounded sample (rank 0, N=1 only).
 
-Before the W warm-up steps the GPU is held at load for --spinup seconds (default 1 s) by a bare MFMA loop (sae_spinup):
-an idle MI355X starts in a low power state and needs some tens of milliseconds of load to reach its sustained clocks;
-without it a 10 + 50 step run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second or more.  The
-timed region is still exactly K steps after W warm-up steps.
+Before the W warm-up steps the same step is run untimed for --spinup seconds (default 1 s): an idle MI355X starts in a
+low power state and needs some tens of milliseconds of load to reach its sustained clocks; without it a 10 + 50 step
+run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second or more.  The spin-up must be the
+workload itself: a second of a bare MFMA loop (tried: more power than the step draws) leaves the chip throttled and the
+following steps 10 % SLOWER (0.66 vs 0.60 ms) -- the steady state of a training run is the one its own steps settle into.
+The timed region is still exactly K steps after W warm-up steps.
 """
 import argparse
 import json
@@ -179,11 +181,18 @@ def main():
             eng.step(x, lr_of(i))
 
     if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
-        # a bare MFMA loop of the engine's own (sae_spinup), NOT the step kernels: a profiler's per-kernel statistics of
-        # the step then cover only launches on sustained clocks (the first ~100 steps of a cold chip run 25 % slow)
-        eng.spinup(args.spinup)
-        if use_dist:
-            dist.barrier()
+        t_spin = time.perf_counter()
+        while True:
+            for _ in range(20):
+                one_step(0)
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t_spin
+            if use_dist:                     # every rank must leave after the same number of (collective) steps
+                te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                elapsed = float(te.item())
+            if elapsed >= args.spinup:
+                break
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()

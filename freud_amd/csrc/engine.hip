@@ -1684,56 +1684,6 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   return SAE_OK;
 }
 
-// Clock spin-up for benchmarks: an idle MI355X sits in a low power state and needs some tens of milliseconds of load to
-// reach its sustained clocks.  A bare MFMA loop on every CU (not the step's own kernels, so that a profiler's per-kernel
-// statistics of the step contain only steps that ran on sustained clocks) held for `seconds` of wall time.
-__global__ __launch_bounds__(256) void spinup_mfma_kernel(int iters, float* __restrict__ sink) {
-  const int lane = threadIdx.x & 63;
-  bf16x8 a, b;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    a[i] = (bf16_t)(0.001f * (float)((lane * 7 + i * 3) % 97) - 0.04f);
-    b[i] = (bf16_t)(0.002f * (float)((lane * 5 + i * 11) % 89) - 0.08f);
-  }
-  f32x16 acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q], 0, 0, 0);
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += acc[q][r];
-  if (s == 123.456f) sink[0] = s;      // keeps the loop alive; never true in practice
-}
-
-extern "C" int sae_spinup(sae_ctx* c, double seconds, void* stream) {
-  if (!c) return fail(SAE_ERR_INVALID, "null argument");
-  USE_DEVICE(c);
-  hipStream_t s = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  double done = 0;
-  while (done < seconds) {             // ~4 ms per launch: 1024 workgroups x 4 waves x 2048 x 4 MFMAs
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(spinup_mfma_kernel, dim3(1024), dim3(256), 0, s, 2048, c->scal);
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    done += ms * 1e-3;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return SAE_OK;
-}
-
 extern "C" int sae_profile(sae_ctx* c, int level) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
   USE_DEVICE(c);

@@ -105,7 +105,6 @@ def load() -> C.CDLL:
         "sae_latent_colmax": (C.c_int, [vp, fptr, i64, vp]),
         "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
         "sae_profile": (C.c_int, [vp, C.c_int]),
-        "sae_spinup": (C.c_int, [vp, dbl, vp]),
         "sae_kernel_times": (C.c_int, [vp, fptr, C.POINTER(i32), C.c_int]),
         "sae_kernel_name": (C.c_char_p, [C.c_int]),
         "sae_dominant_kernel": (C.c_int, [vp]),
@@ -124,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "sae_set_grad_ready_callback", "sae_batch_stats", "sae_stats_buffer", "sae_set_dp_world", "sae_dist_unique_id",
     "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
-    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_spinup", "sae_kernel_times",
+    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
 
@@ -428,10 +427,6 @@ class SaeEngine:
         out = np.empty(count, dtype=np.float32)
         _check(self._lib.sae_debug_read(self._ctx, which, out.ctypes.data_as(C.POINTER(C.c_float)), count))
         return out
-
-    def spinup(self, seconds: float, stream=None) -> None:
-        """Hold the GPU at load with a bare MFMA loop (clock spin-up before a timed region)."""
-        _check(self._lib.sae_spinup(self._ctx, float(seconds), self._stream(stream)))
 
     def profile(self, level: int) -> None:
         _check(self._lib.sae_profile(self._ctx, level))

@@ -234,10 +234,6 @@ int sae_debug_read(sae_ctx* ctx, int which, float* out_host, int64_t capacity_fl
  * kernel ids 0..n-1 (ids: sae_kernel_name).  Level 1 samples every 8th step: an event record costs ~6 us of idle GPU
  * between two dependent kernels, which at three records per 0.6 ms step was 3 % of the thing being measured. */
 int sae_profile(sae_ctx* ctx, int level);
-/* Benchmark utility: keep every CU busy with a bare MFMA loop for `seconds` of wall time (synchronous), so that the chip
- * leaves its idle power state BEFORE the measured steps -- with a kernel of its own, so that a profiler's per-kernel
- * averages of the step kernels cover sustained-clock launches only. */
-int sae_spinup(sae_ctx* ctx, double seconds, void* stream);
 int sae_kernel_times(sae_ctx* ctx, float* ms_sum, int32_t* launches, int n);
 const char* sae_kernel_name(int id);        /* NULL past the last id */
 int sae_dominant_kernel(sae_ctx* ctx);      /* id bracketed at level 1 */
