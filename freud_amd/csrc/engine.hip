@@ -936,6 +936,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
     EpiEnc e{};
     e.c = c->c; e.bias = b; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = g.nbn;
+    e.skip_store = c->cfg.debug_flags == 70;
     ev_begin(c, KID_ENC_FWD, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
     ev_end(c, KID_ENC_FWD, s);

@@ -154,6 +154,7 @@ struct EpiEnc {
   float* l1_part;       // [tiles]
   int64_t M;
   int n_p, nbn;
+  int skip_store;       // timing experiment (debug_flags 70): no latent store -- results become wrong
   float l1;
   int tile_id;
   __device__ void tile_begin(int row0, int col0, int) {
@@ -172,7 +173,7 @@ struct EpiEnc {
       l1 += cv;
       o[j] = (bf16_t)cv;
     }
-    EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
+    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256(l1, scratch);
