@@ -16,6 +16,13 @@ Pipeline per rank: a worker thread gathers the next batch's rows from the memory
 `depth` pinned host buffers; the consumer issues the H2D copy on a dedicated copy stream into the
 matching HBM buffer and makes the compute stream wait on its event, so the copy of batch i+1
 overlaps the train step of batch i.
+
+Delivery dtype: the collector writes fp32 shards and the host -> HBM link is what bounds a real
+training run, so the gather threads can down-convert fp32 rows to bf16 on the way into the pinned
+ring (deliver_dtype="bfloat16" / FREUD_LOADER_DELIVER=bfloat16; libfreud_host.so, round to nearest even, exact -1.0
+-- the mse_loss mask value -- never created by rounding): half the PCIe bytes.  The engine's GEMMs read bf16(x) in any
+case; what changes is that the residual x_hat - x is taken against bf16(x), one more rounding of the size the bf16
+arithmetic already has.  Default: rows travel in the shard's own dtype (reference semantics bit for bit).
 """
 from __future__ import annotations
 
@@ -27,6 +34,35 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+_HOST_LIB = None
+
+
+def _host_lib():
+    """libfreud_host.so (freud_amd/csrc/host_convert.c): fp32 -> bf16 row gather for the staging threads."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes as C
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfreud_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C freud_amd/csrc` (loader bf16 delivery needs it)")
+        lib = C.CDLL(path)
+        lib.freud_gather_f32_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        lib.freud_gather_f32_to_bf16.restype = None
+        lib.freud_f32_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.freud_f32_to_bf16.restype = None
+        _HOST_LIB = lib
+    return _HOST_LIB
+
+
+def _mem_available_bytes() -> int:
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return 16 << 30
 
 
 class MemoryMappedActivationsDataset:
@@ -64,7 +100,8 @@ class MemoryMappedActivationDataLoader:
 
     def __init__(self, data_path: str, layer_name: str, batch_size: int, dl_max_workers: int = 0,
                  subset_size: Optional[int] = None, dl_kwargs: Optional[dict] = None, *,
-                 device: torch.device | str = "cpu", rank: int = 0, world_size: int = 1, depth: int = 3):
+                 device: torch.device | str = "cpu", rank: int = 0, world_size: int = 1, depth: int = 3,
+                 deliver_dtype: Optional[str] = None):
         dl_kwargs = dict(dl_kwargs or {})
         self._dataset = MemoryMappedActivationsDataset(data_path, layer_name, subset_size)
         self.dataset = self._dataset
@@ -77,16 +114,27 @@ class MemoryMappedActivationDataLoader:
         self.device = torch.device(device)
         self.rank, self.world_size, self.depth = rank, world_size, max(2, depth)
         self.dl_max_workers = dl_max_workers
+        # delivery dtype (module docstring): None / "native" = the shard's own dtype; "bfloat16" = fp32 rows are converted in
+        # the gather threads (shards that already hold 2-byte values travel as they are)
+        deliver = deliver_dtype if deliver_dtype is not None else os.environ.get("FREUD_LOADER_DELIVER", "native")
+        if deliver not in ("native", "bfloat16"):
+            raise ValueError(f"deliver_dtype must be 'native' or 'bfloat16', got {deliver!r}")
+        self._convert = deliver == "bfloat16" and self._dataset.mmap.dtype == np.float32
         # direct mode: the shard mapping is host-registered (pinned in place) so that rows travel to HBM by DMA straight
         # from the page cache, without a CPU gather into staging buffers (measured on the MI355X host: the whole train()
         # loop 25.5 M fp16 activations/s against 18-22 M staged, with no gather threads).  Registration faults in and pins
-        # the whole file, so it is automatic only up to 8 GiB; FREUD_LOADER_DIRECT=1 forces it, =0 disables it; any
-        # failure to register (no GPU, locked-memory limit, mapping larger than RAM) silently keeps the staged path.
+        # the whole file, so it is automatic only while the shard fits in half of the host's available memory
+        # (FREUD_LOADER_DIRECT_MAX_GB overrides the limit; train-other-500 at ~342 GB stays staged on most hosts and is
+        # disk-bound anyway); FREUD_LOADER_DIRECT=1 forces it, =0 disables it; any failure to register (no GPU,
+        # locked-memory limit, mapping larger than RAM) silently keeps the staged path.  Converting delivery needs the
+        # CPU pass, so it is always staged.
         self._direct = False
         self._registered = None
         mode = os.environ.get("FREUD_LOADER_DIRECT", "auto")
-        small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= (8 << 30)
-        if self.device.type == "cuda" and (mode == "1" or (mode not in ("0",) and small)):
+        limit = os.environ.get("FREUD_LOADER_DIRECT_MAX_GB")
+        limit = int(float(limit) * (1 << 30)) if limit else _mem_available_bytes() // 2
+        small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= limit
+        if self.device.type == "cuda" and not self._convert and (mode == "1" or (mode not in ("0",) and small)):
             self._try_register()
         self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else min(8, max(1, (os.cpu_count() or 1) // 4))
         self._pool = None
@@ -149,6 +197,23 @@ class MemoryMappedActivationDataLoader:
         torch's DataLoader as num_workers, train_sae.py:51-63); 0 = automatic."""
         mm = self._dataset.mmap
         nthreads = self._gather_threads
+        if self._convert:        # fp32 rows -> bf16 bit patterns (out is a uint16 / bf16-viewed buffer), libfreud_host.so
+            lib, row = _host_lib(), mm.shape[1]
+            idx64 = np.ascontiguousarray(np.asarray(idxs, dtype=np.int64))
+            out16 = out.view(np.uint16) if out.dtype != np.uint16 else out
+
+            def conv(t):
+                sel = idx64[t::nthreads]
+                for q, j in enumerate(range(t, len(idx64), nthreads)):
+                    lib.freud_gather_f32_to_bf16(mm.ctypes.data, sel[q:q + 1].ctypes.data, 1, row, out16[j].ctypes.data)
+            if nthreads <= 1 or len(idxs) < 2 * nthreads:
+                lib.freud_gather_f32_to_bf16(mm.ctypes.data, idx64.ctypes.data, len(idx64), row, out16.ctypes.data)
+                return
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="shard-gather")
+            list(self._pool.map(conv, range(nthreads)))
+            return
         if nthreads <= 1 or len(idxs) < 2 * nthreads:
             for j, i in enumerate(idxs):
                 out[j] = mm[i]
@@ -172,6 +237,11 @@ class MemoryMappedActivationDataLoader:
         np_dtype = self._dataset.mmap.dtype
         if self.device.type != "cuda":
             for idxs in batches:
+                if self._convert:
+                    t = torch.empty((len(idxs), T * d), dtype=torch.bfloat16)
+                    self._gather(idxs, t.view(torch.int16).numpy().view(np.uint16))
+                    yield t.reshape(len(idxs), T, d), [names[i] for i in idxs]
+                    continue
                 buf = np.empty((len(idxs), T * d), dtype=np_dtype)
                 self._gather(idxs, buf)
                 yield torch.from_numpy(buf).reshape(len(idxs), T, d), [names[i] for i in idxs]
@@ -228,7 +298,7 @@ class MemoryMappedActivationDataLoader:
             yield from self._iter_cuda_direct(batches, T, d, names)
             return
         B, depth, dev = self.batch_size, self.depth, self.device
-        tdtype = torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+        tdtype = torch.bfloat16 if self._convert else torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
         pinned = [torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)]
         hbm = [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)]
         free = [threading.Semaphore(1) for _ in range(depth)]
@@ -242,7 +312,10 @@ class MemoryMappedActivationDataLoader:
                     while not free[slot].acquire(timeout=0.1):
                         if stop.is_set():
                             return
-                    self._gather(idxs, pinned[slot].numpy()[: len(idxs)])
+                    if self._convert:
+                        self._gather(idxs, pinned[slot].view(torch.int16).numpy().view(np.uint16)[: len(idxs)])
+                    else:
+                        self._gather(idxs, pinned[slot].numpy()[: len(idxs)])
                     ready.put((slot, idxs))
                 ready.put(None)
             except BaseException as e:  # surface loader errors in the training thread

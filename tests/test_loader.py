@@ -70,3 +70,35 @@ def test_data_parallel_partition(tmp_path):
     assert len(per_rank[0]) == len(per_rank[1]) == 6            # (13 // 2) // 3 batches of 3
     assert not set(per_rank[0]) & set(per_rank[1])
     assert per_rank[0] == order[0::2][:6] and per_rank[1] == order[1::2][:6]
+
+
+def test_bf16_delivery_of_fp32_shards(tmp_path):
+    """deliver_dtype="bfloat16": fp32 shard rows arrive as bf16, rounded to nearest even like torch's cast, except that a
+    value which is not exactly -1.0 never BECOMES -1.0 (the mse_loss mask value, l1autoencoder.py:31) and exact -1.0
+    stays; same batch order as the native delivery; fp16 shards travel unchanged."""
+    import numpy as np
+    import torch
+    from freud_amd.loader import MemoryMappedActivationDataLoader, write_shards
+    T, d, n_files = 5, 16, 9
+    g = torch.Generator().manual_seed(0)
+    rows = torch.randn(n_files, T * d, generator=g) * 2
+    rows[0, :4] = torch.tensor([-1.0, -1.0009765, -0.9990234, -0.99999])
+    folder = str(tmp_path / "f32")
+    write_shards(folder, "L", rows.numpy().astype(np.float32), [T, d])
+    torch.manual_seed(1)
+    native = list(MemoryMappedActivationDataLoader(folder, "L", 2, dl_kwargs={"shuffle": True, "drop_last": True}))
+    torch.manual_seed(1)
+    conv = list(MemoryMappedActivationDataLoader(folder, "L", 2, dl_kwargs={"shuffle": True, "drop_last": True},
+                                                 deliver_dtype="bfloat16"))
+    assert len(native) == len(conv) == 4
+    for (xa, na), (xb, nb) in zip(native, conv):
+        assert na == nb and xb.dtype == torch.bfloat16 and xa.dtype == torch.float32 and xb.shape == xa.shape
+        ref = xa.to(torch.bfloat16)
+        near = (xa + 1).abs() < 0.01
+        assert torch.equal(xb[~near], ref[~near])
+        assert torch.equal(xb == -1.0, xa == -1.0)                 # the mask set is unchanged
+        assert ((xb.float() - xa).abs()[near] <= 2.0 ** -6).all()
+    folder16 = str(tmp_path / "f16")
+    write_shards(folder16, "L", rows.numpy().astype(np.float16), [T, d])
+    x16, _ = next(iter(MemoryMappedActivationDataLoader(folder16, "L", 2, deliver_dtype="bfloat16")))
+    assert x16.dtype == torch.float16

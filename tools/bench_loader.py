@@ -33,7 +33,12 @@ def main():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--expansion", type=int, default=8)
     ap.add_argument("--sweep", action="store_true", help="loader-only rate over gather threads x pipeline depth, and raw H2D")
+    ap.add_argument("--deliver", default="native", choices=["native", "bfloat16"],
+                    help="bfloat16: fp32 shard rows are down-converted in the gather threads (half the PCIe bytes)")
+    ap.add_argument("--direct", default="auto", choices=["auto", "0", "1"], help="FREUD_LOADER_DIRECT")
     args = ap.parse_args()
+    os.environ["FREUD_LOADER_DELIVER"] = args.deliver
+    os.environ["FREUD_LOADER_DIRECT"] = args.direct
     tmp = tempfile.mkdtemp(prefix="freud_loader_", dir="/tmp")
     try:
         layer = "encoder.blocks.2"
@@ -44,11 +49,13 @@ def main():
         write_shards(folder, layer, rows, [args.T, args.d], [f"/data/f{i}.flac" for i in range(args.files)])
         nbytes = rows.nbytes
         del rows, z
-        out = {"files": args.files, "T": args.T, "d": args.d, "dtype": args.dtype, "shard_GB": nbytes / 1e9,
-               "batch_size_files": args.batch_size, "host_cores": os.cpu_count()}
+        out = {"files": args.files, "T": args.T, "d": args.d, "dtype": args.dtype, "deliver": args.deliver, "direct": args.direct,
+               "shard_GB": nbytes / 1e9, "batch_size_files": args.batch_size, "host_cores": os.cpu_count()}
 
         dl = MemoryMappedActivationDataLoader(folder, layer, args.batch_size, 0, None, {"shuffle": True, "drop_last": True},
                                               device="cuda")
+        out["mode"] = "direct (registered mapping, one DMA per file)" if dl._direct else (
+            "staged (gather threads -> pinned ring)" + (" + fp32->bf16 conversion" if dl._convert else ""))
         for epoch in range(3):           # epoch 0 warms the page cache; report the best of the rest
             t0 = time.perf_counter()
             nb = 0
