@@ -138,7 +138,7 @@ def main():
         out["train_loop_ms_per_step"] = per_step * 1e3
         out["train_run_fixed_cost_ms"] = (times[0] - per_step * args.steps) * 1e3
         out["rows_per_step"] = args.batch_size * args.T
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
