@@ -139,7 +139,7 @@ def main():
     x = x_cpu.cuda()
     if args.variant == "topk":
         eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
-                        clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128)
+                        clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128, debug_flags=args.dbg)
         eng.set_topk_options(args.dead_threshold, 1024)
         g = torch.Generator().manual_seed(0)
         We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5

@@ -1213,7 +1213,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         auto launch_sb = [&](auto np_tag) {
           constexpr int NP = decltype(np_tag)::value;
           hipLaunchKernelGGL(sparse_bwd_kernel<NP>, dim3(blocks), dim3(256), 0, s, ps, c->xs, c->Wd_b, c->csc_entries, c->csc_start,
-                             c->csc_item_start, c->csc_item_latent, n_p, c->csc_part, c->csc_pbe);
+                             c->csc_item_start, c->csc_item_latent, n_p, c->csc_part, c->csc_pbe, gWd, gWe, gbe, c->db_part);
         };
         if (d_p == 384) launch_sb(std::integral_constant<int, 3>{});
         else if (d_p == 768) launch_sb(std::integral_constant<int, 6>{});

@@ -284,18 +284,22 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
     u32x4 w = {0u, 0u, 0u, 0u};
     unsigned cb = 0;
     if (g < nvec) {
-      w = src[g];
+      w = __builtin_nontemporal_load(src + g);     // read exactly once (3.2 GB at C3): keep it out of the caches' way
+      if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
+        cb = 0xFFu;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = 8 * g + e;
-        const bool ok = col < n && (!dead || dead[col]);
-        cb |= ok ? (1u << e) : 0u;
-      }
-      // zero the keys of non-candidates
+        for (int e = 0; e < 8; ++e) {
+          const int col = 8 * g + e;
+          const bool ok = col < n && (!dead || dead[col]);
+          cb |= ok ? (1u << e) : 0u;
+        }
+        // zero the keys of non-candidates
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned m = ((cb >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((cb >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
-        w[q] &= m;
+        for (int q = 0; q < 4; ++q) {
+          const unsigned m = ((cb >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((cb >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
+          w[q] &= m;
+        }
       }
     }
     keys[v] = w;
@@ -339,11 +343,11 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   //   (key << 17 | (0x1FFFF - column): larger = larger value, then lower column, the tie rule), every candidate counts
   //   the candidates above it -- its rank IS its output slot (sorted by value), ranks below k are the selection.
   //   This replaces ~18 block-wide counting probes over all n keys (the old path below, kept for rows it cannot take:
-  //   L == 0, k > 256, or more than TOPK_CAND_CAP candidates).
-  constexpr int TOPK_CAND_CAP = 1024;
-  __shared__ unsigned int cand_pk[TOPK_CAND_CAP];
+  //   L == 0, k > 256, or a wave with more than TOPK_SEG_CAP candidates).
+  constexpr int TOPK_SEG_CAP = 256;                    // candidates per wave
+  __shared__ unsigned int cand_pk[4 * TOPK_SEG_CAP];
   __shared__ unsigned int wave_lb[4];
-  __shared__ int cand_cnt;
+  __shared__ int wave_cnt[4];
   __shared__ unsigned int thr_pk;
   bool done = false;
   if (k <= 256) {
@@ -364,35 +368,54 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       if (__popcll(__ballot(tmax >= mid)) >= kw) lo = mid; else hi = mid - 1;
     }
     if ((t & 63) == 0) wave_lb[t >> 6] = lo;
-    if (t == 0) cand_cnt = 0;
     __syncthreads();
     const unsigned int L = min(min(wave_lb[0], wave_lb[1]), min(wave_lb[2], wave_lb[3]));
     if (L > 0) {                                       // block-uniform
+      // Append the keys >= L to this WAVE's segment of the candidate list: positions come from a ballot + lane prefix and a
+      // wave-uniform running count -- no LDS atomics (an add-with-return per hit cost a ~100-cycle round trip each; this
+      // loop was 60 % of the kernel), and the scalar branch skips the pairs in which no lane of the wave has a hit.
       const unsigned int lp = L * 0x00010001u;
+      const int wv = t >> 6, lane = t & 63;
+      unsigned int* seg = cand_pk + wv * TOPK_SEG_CAP;
+      int wcount = 0;                                  // wave-uniform
 #pragma unroll
       for (int v = 0; v < MAXV; ++v)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const unsigned int w = keys[v][q];
-          if ((((w | 0x80008000u) - lp) & 0x80008000u) != 0u) {        // at least one of the pair is >= L (rare)
+          const unsigned int hit = ((w | 0x80008000u) - lp) & 0x80008000u;       // bit 15 / 31: low / high key >= L
+          const unsigned long long any = __ballot(hit != 0u);
+          if (any != 0ull) {                           // wave-uniform
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const unsigned int key = (w >> (16 * h)) & 0xFFFFu;
-              if (key >= L) {                          // (non-candidates carry key 0 < L)
+              const bool mine = (hit >> (15 + 16 * h)) & 1u;
+              const unsigned long long bm = __ballot(mine);
+              if (mine) {
+                const int pos = wcount + (int)__popcll(bm & ((1ull << lane) - 1ull));
+                const unsigned int key = (w >> (16 * h)) & 0xFFFFu;
                 const int col = 8 * (v * 256 + t) + 2 * q + h;
-                const int pos = atomicAdd(&cand_cnt, 1);
-                if (pos < TOPK_CAND_CAP) cand_pk[pos] = (key << 17) | (0x1FFFFu - (unsigned int)col);
+                if (pos < TOPK_SEG_CAP) seg[pos] = (key << 17) | (0x1FFFFu - (unsigned int)col);
               }
+              wcount += (int)__popcll(bm);
             }
           }
         }
+      if (lane == 0) wave_cnt[wv] = wcount;
       __syncthreads();
-      const int C = cand_cnt;
-      if (C <= TOPK_CAND_CAP) {                        // block-uniform; C >= k by construction
+      const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+      const int C = c0 + c1 + c2 + c3;
+      const bool fits = c0 <= TOPK_SEG_CAP && c1 <= TOPK_SEG_CAP && c2 <= TOPK_SEG_CAP && c3 <= TOPK_SEG_CAP;
+      if (fits) {                                      // block-uniform; C >= k by construction
         for (int i = t; i < C; i += 256) {
-          const unsigned int my = cand_pk[i];
+          // candidate i of the concatenated segments
+          const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
+          const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
+          const unsigned int my = cand_pk[sg * TOPK_SEG_CAP + li];
           int rank = 0;
-          for (int j = 0; j < C; ++j) rank += cand_pk[j] > my ? 1 : 0;
+          for (int j = 0; j < c0; ++j) rank += cand_pk[j] > my ? 1 : 0;
+          for (int j = 0; j < c1; ++j) rank += cand_pk[TOPK_SEG_CAP + j] > my ? 1 : 0;
+          for (int j = 0; j < c2; ++j) rank += cand_pk[2 * TOPK_SEG_CAP + j] > my ? 1 : 0;
+          for (int j = 0; j < c3; ++j) rank += cand_pk[3 * TOPK_SEG_CAP + j] > my ? 1 : 0;
           if (rank < k) {
             const int col = (int)(0x1FFFFu - (my & 0x1FFFFu));
             if (rank < kcap) {

@@ -52,12 +52,16 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
-    for (int r = 0; r < CSC_ROWS && r0 + r < M; ++r) {
-      const int* ri = ps.idx[pass] + (r0 + r) * kcap;
-      for (int q = lane; q < kcap; q += 64) {
-        const int j = ri[q];
-        if (j >= 0) atomicAdd(&ctr32[j >> 1], (j & 1) ? 0x10000u : 1u);      // (a block holds < 65536 entries of a latent)
-      }
+    for (int q0 = 0; q0 < kcap; q0 += 64) {
+      // the block's CSC_ROWS rows of this 64-wide index chunk: every load is issued before the first LDS add (one memory
+      // latency per chunk instead of one per row)
+      int v[CSC_ROWS];
+      const int q = q0 + lane;
+#pragma unroll
+      for (int r = 0; r < CSC_ROWS; ++r) v[r] = (q < kcap && r0 + r < M) ? ps.idx[pass][(r0 + r) * kcap + q] : -1;
+#pragma unroll
+      for (int r = 0; r < CSC_ROWS; ++r)
+        if (v[r] >= 0) atomicAdd(&ctr32[v[r] >> 1], (v[r] & 1) ? 0x10000u : 1u);   // (a block holds < 65536 entries of a latent)
     }
   }
   __syncthreads();
@@ -132,19 +136,26 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
-    for (int r = 0; r < CSC_ROWS && r0 + r < M; ++r) {
-      const int64_t row = r0 + r;
-      const int* ri = ps.idx[pass] + row * kcap;
-      const bf16_t* rv = ps.vals[pass] + row * kcap;
-      for (int q = lane; q < kcap; q += 64) {
-        const int j = ri[q];
+    for (int q0 = 0; q0 < kcap; q0 += 64) {     // order inside (block, latent): pass, index chunk, row -- fixed, never timing
+      int v[CSC_ROWS];
+      unsigned short a[CSC_ROWS];
+      const int q = q0 + lane;
+#pragma unroll
+      for (int r = 0; r < CSC_ROWS; ++r) {
+        const bool ok = q < kcap && r0 + r < M;
+        v[r] = ok ? ps.idx[pass][(r0 + r) * kcap + q] : -1;
+        a[r] = ok ? reinterpret_cast<const unsigned short*>(ps.vals[pass])[(r0 + r) * kcap + q] : (unsigned short)0;
+      }
+#pragma unroll
+      for (int r = 0; r < CSC_ROWS; ++r) {
+        const int j = v[r];
         if (j < 0) continue;
         // rank inside (block, latent): LDS add with return; one wave, program order, distinct j within a (row, pass)
         const unsigned int old = atomicAdd(&ctr32[j >> 1], (j & 1) ? 0x10000u : 1u);
         const unsigned int rank = (j & 1) ? (old >> 16) : (old & 0xFFFFu);
         CscEntry e;
-        e.row_pass = (unsigned int)row | ((unsigned int)pass << 30);
-        e.act = (float)rv[q];
+        e.row_pass = (unsigned int)(r0 + r) | ((unsigned int)pass << 30);
+        e.act = __uint_as_float((unsigned int)a[r] << 16);
         entries[start[j] + boff[j] + rank] = e;
       }
     }
@@ -158,7 +169,9 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const 
                                                          const CscEntry* __restrict__ entries, const unsigned int* __restrict__ start,
                                                          const unsigned int* __restrict__ item_start,
                                                          const unsigned int* __restrict__ item_latent, int n_p,
-                                                         float* __restrict__ part, float* __restrict__ pbe) {
+                                                         float* __restrict__ part, float* __restrict__ pbe,
+                                                         float* __restrict__ gWd, float* __restrict__ gWe, float* __restrict__ gbe,
+                                                         float* __restrict__ dbe_exact) {
   constexpr int d_p = 128 * NPAIR, CPL = 2 * NPAIR;           // columns per lane
   const int lane = threadIdx.x & 63;
   const unsigned int nitems = item_start[n_p];
@@ -212,6 +225,20 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const 
       acce[2 * p + 1] += da * __uint_as_float(va[p] & 0xFFFF0000u) + db * __uint_as_float(vb[p] & 0xFFFF0000u);
     }
   }
+  if (item_start[j + 1] - item_start[j] == 1) {     // the latent's only work item: these ARE its gradient rows
+    float* od = gWd + (int64_t)j * d_p + c0;
+    float* oe = gWe + (int64_t)j * d_p + c0;
+#pragma unroll
+    for (int p = 0; p < CPL; ++p) {
+      od[p] = accd[p];
+      oe[p] = acce[p];
+    }
+    if (lane == 0) {
+      dbe_exact[j] = dbe;
+      gbe[j] = bf16_round(dbe);
+    }
+    return;
+  }
   float* po = part + (int64_t)item * 2 * d_p + c0;
 #pragma unroll
   for (int p = 0; p < CPL; ++p) {
@@ -221,13 +248,15 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const 
   if (lane == 0) pbe[item] = dbe;
 }
 
-// ---- 6. per latent: its items' partial sums in order -> dW_dec[j], dW_enc[j], d b_enc[j] (bf16-rounded) + exact copy ------------
+// ---- 6. per latent with no or several work items: zero rows / its items' partial sums in order -> dW_dec[j], dW_enc[j],
+//         d b_enc[j] (bf16-rounded) + exact copy
 __global__ __launch_bounds__(256) void sparse_combine_kernel(const float* __restrict__ part, const float* __restrict__ pbe,
                                                              const unsigned int* __restrict__ item_start, int n_p, int d_p,
                                                              float* __restrict__ gWd, float* __restrict__ gWe, float* __restrict__ gbe,
                                                              float* __restrict__ dbe_exact) {
   const int j = blockIdx.x;
   const unsigned int i0 = item_start[j], i1 = item_start[j + 1];
+  if (i1 - i0 == 1) return;                           // written by its single work item itself
   for (int c = threadIdx.x; c < d_p; c += 256) {
     float a = 0.f, b = 0.f;
     for (unsigned int i = i0; i < i1; ++i) {
