@@ -139,10 +139,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
     glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
   };
 
-  // Tile t lives in stage t & 1.  The hand-over barrier B_t sits before the LAST MFMA group of tile t: by then every
-  // fragment of tile t is in registers and tile t+1 has landed, so the gaps after B_t already read tile t+1's first
+  // Tile t lives in stage t & 1.  The hand-over barrier B_t sits inside the LAST MFMA group of tile t: by then every
+  // fragment of tile t is in registers and tile t+1 has landed, so the slots after B_t already read tile t+1's first
   // fragments (no tile starts with an exposed LDS round trip) and refill the freed stage with tile t+2 (half of its
   // pieces right after B_t, half in the first group of tile t+1: a full tile of lead time).
+  // Every group is 8 MFMAs with ONE piece of other work in the slot behind each (an LDS-DMA pair, or the read of one
+  // fragment of the next group): clustered in front of the group, the 6 fragment reads and the DMA pairs left the matrix
+  // pipe idle while they issued (tools/kbench: without the reads the K = 1280 GEMM ran 22 % faster, without the DMA 15 %),
+  // and the last group ran its barrier + 4 DMA pieces + 6 reads before its first MFMA.
   const int kt_last = kt_end - 1;
   auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
   bf16x8 fa[2][4], fb[2][2];
@@ -167,34 +171,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
     const char* sb = sa + G2_OPER_BYTES;
     const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
     const char* nb = na + G2_OPER_BYTES;
+    // fragment f (0..3: A rows 32 f, 4..5: B columns 32 (f - 4)) of K step `ks` of the tile whose images are (ia, ib)
+    auto ldfrag = [&](const char* ia, const char* ib, int ks, int f) {
+      if (f < 4) fa[ks & 1][f] = g2_frag<AMODE>(ia, 128 * wm + 32 * f, ks, lane);
+      else fb[ks & 1][f - 4] = g2_frag<BMODE>(ib, 64 * wn + 32 * (f - 4), ks, lane);
+    };
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (kk == 0) {          // second half of tile kt+1's pieces (its first half left right after B_{kt-1})
-        issue(clampk(kt + 1), cur ^ 1, 2);
-        issue(clampk(kt + 1), cur ^ 1, 3);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][m >> 1], fb[kk & 1][m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) {            // second half of tile kt+1's pieces + the fragments of K step 1
+          if (m == 0) issue(clampk(kt + 1), cur ^ 1, 2);
+          else if (m == 3) issue(clampk(kt + 1), cur ^ 1, 3);
+          else ldfrag(sa, sb, 1, m < 3 ? m - 1 : m - 2);
+        } else if (kk < 3) {      // the fragments of K step kk + 1
+          if (m < 6) ldfrag(sa, sb, kk + 1, m);
+        } else {                  // hand-over, first half of tile kt+2's pieces, tile kt+1's first fragments
+          if (m == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+            __syncthreads();                                    // B_kt: ... and everybody's; all reads of this stage are done
+          } else if (m == 2) {
+            issue(clampk(kt + 2), cur, 0);
+          } else if (m == 3) {
+            ldfrag(na, nb, 0, 0);
+            ldfrag(na, nb, 0, 1);
+          } else if (m == 4) {
+            ldfrag(na, nb, 0, 2);
+            ldfrag(na, nb, 0, 3);
+          } else if (m == 5) {
+            ldfrag(na, nb, 0, 4);
+            ldfrag(na, nb, 0, 5);
+          } else if (m == 6) {
+            issue(clampk(kt + 2), cur, 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[(kk + 1) & 1][i] = g2_frag<AMODE>(sa, 128 * wm + 32 * i, kk + 1, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[(kk + 1) & 1][j] = g2_frag<BMODE>(sb, 64 * wn + 32 * j, kk + 1, lane);
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
-        __syncthreads();                                    // B_kt: ... and everybody's; all reads of this stage are done
-        issue(clampk(kt + 2), cur, 0);
-        issue(clampk(kt + 2), cur, 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(na, 128 * wm + 32 * i, 0, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(nb, 64 * wn + 32 * j, 0, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     cur ^= 1;
   }

@@ -1,0 +1,82 @@
+// Stand-alone timing of the 256x256 GEMM skeleton (freud_amd/csrc/gemm256.h) at the shapes of the d = 1280 / d = 768 paths,
+// for A/B experiments on the K loop (compile-time switches G2X_*).  Build here (hipcc cross-compiles), run on the GPU box:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DG2X_...] -o build/kbench/gemm_bench tools/kbench/gemm_bench.hip
+//   build/kbench/gemm_bench M N K [kmajor] [splits]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../../freud_amd/csrc/gemm256.h"
+#include "../../freud_amd/csrc/l1_kernels.h"
+
+struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias / ReLU)
+  bf16_t* out;
+  int64_t ld;
+  __device__ void tile_begin(int, int, int) {}
+  struct Pre {};
+  __device__ Pre prefetch(int, int) const { return Pre{}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre&) {
+    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(out + (int64_t)row * ld + col));
+  }
+  __device__ void tile_end(float*) {}
+};
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  const int64_t M = argc > 1 ? atoll(argv[1]) : 65536, N = argc > 2 ? atoll(argv[2]) : 40960, K = argc > 3 ? atoll(argv[3]) : 1280;
+  const int kmajor = argc > 4 ? atoi(argv[4]) : 0, splits = argc > 5 ? atoi(argv[5]) : 1;
+  bf16_t *A, *B, *C;
+  float* slab = nullptr;
+  CK(hipMalloc(&A, M * K * 2));
+  CK(hipMalloc(&B, N * K * 2));
+  CK(hipMalloc(&C, M * N * 2));
+  std::vector<unsigned short> h(1 << 20);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned short)(0x3C00 + (rand() & 0x3FF) + ((rand() & 1) << 15));   // ~ +-[0.0078, 0.03]
+  for (int64_t off = 0; off < M * K; off += (int64_t)h.size()) CK(hipMemcpy(A + off, h.data(), (size_t)std::min<int64_t>(h.size(), M * K - off) * 2, hipMemcpyHostToDevice));
+  for (int64_t off = 0; off < N * K; off += (int64_t)h.size()) CK(hipMemcpy(B + off, h.data(), (size_t)std::min<int64_t>(h.size(), N * K - off) * 2, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.A0 = A; g.B0 = B; g.splits = splits;
+  if (!kmajor) {          // C[M][N] = A[M][K] B[N][K]^T
+    g.lda = K; g.ldb = K; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
+  } else {                // weight-gradient shape: C[M][N] = sum_k A[k][M] B[k][N], K rows
+    g.lda = M; g.ldb = N; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
+    CK(hipMalloc(&slab, (size_t)splits * M * N * 4));
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto run = [&]() {
+    if (!kmajor) {
+      EpiBf16 e{C, N};
+      auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16>;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
+    } else {
+      EpiSlab e{};
+      e.slab = slab; e.slab_stride = M * N; e.ld = (int)N;
+      auto kern = gemm256_bf16_kernel<OP_KMAJOR, OP_KMAJOR, EpiSlab>;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
+    }
+  };
+  for (int i = 0; i < 3; ++i) run();
+  CK(hipDeviceSynchronize());
+  // hold the clocks with the workload itself for ~0.3 s, then time
+  float ms = 0;
+  int reps = 0;
+  do {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 5; ++i) run();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    reps += 5;
+  } while (reps < 40);
+  const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
+  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", kmajor ? "kmajor" : "row", (long long)M, (long long)N,
+         (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
+  return 0;
+}
