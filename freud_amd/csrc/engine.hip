@@ -295,7 +295,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->e2_part, Mp * 4);
   TALLOC(c->a2_part, Mp * 4);
   TALLOC(c->dbd_part, (Mp / 128 + 1) * c->d_p * 4);
-  TALLOC(c->ds_part, (int64_t)((c->n_p + 255) / 256) * c->d_p * 4);
+  TALLOC(c->ds_part, (int64_t)((c->n_p + 63) / 64) * c->d_p * 4);
   TALLOC(c->db_part, (Mp / 128) * c->n_p * 4);
   TALLOC(c->tkf, 64);
   TALLOC(c->tk, 64);
@@ -1120,7 +1120,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     const int64_t chunks = Mp * (d_p / 8);
     int g2 = (int)((chunks + 255) / 256);
     if (g2 > 4096) g2 = 4096;
-    hipLaunchKernelGGL(topk_prep_x_kernel<T>, dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
+    if (d % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+      hipLaunchKernelGGL((topk_prep_x_kernel<T, true>), dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
+    else
+      hipLaunchKernelGGL((topk_prep_x_kernel<T, false>), dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
     const int64_t TD = T_rows * d;
     if (!gs)   // (data parallel: the variance comes from the column statistics summed over the ranks, below)
       hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
@@ -1182,7 +1185,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     if (c->dist) HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));     // the summed statistics have arrived
     hipLaunchKernelGGL(dp_topk_tv_kernel, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, gs, TD, c->tv_part);
   }
-  hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(256), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
+  hipLaunchKernelGGL(topk_finalize_kernel, dim3(1), dim3(1024), 0, s, c->tv_part, (int)((TD + 255) / 256), c->e2_part,
                      aux ? c->a2_part : (const float*)nullptr, c->multi ? c->m2_part : (const float*)nullptr, Mp, M, d, alpha,
                      c->tk, c->tkf, metrics, (float)n, gs, c->dp_world);
   ev_end(c, KID_TK_DECODE, s);
@@ -1201,7 +1204,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       const int lds = n_p * 2;
       ev_begin(c, KID_TK_DDENSE, s);
       hipLaunchKernelGGL(csc_count_kernel, dim3(nb), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_counts);
-      hipLaunchKernelGGL(csc_scan_blocks_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_counts, nb, n_p, c->csc_block_off,
+      hipLaunchKernelGGL(csc_scan_blocks_kernel, dim3((n_p + 63) / 64), dim3(1024), 0, s, c->csc_counts, nb, n_p, c->csc_block_off,
                          c->csc_total);
       hipLaunchKernelGGL(csc_scan_latents_kernel, dim3(1), dim3(1024), 0, s, c->csc_total, n_p, c->csc_start, c->csc_item_start);
       hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent);
@@ -1221,8 +1224,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       ev_end(c, KID_TK_DWD, s);
       ev_begin(c, KID_TK_DWE, s);
-      hipLaunchKernelGGL(sparse_combine_kernel, dim3(n_p), dim3(256), 0, s, c->csc_part, c->csc_pbe, c->csc_item_start, n_p, d_p, gWd,
-                         gWe, gbe, c->db_part);
+      hipLaunchKernelGGL(sparse_combine_kernel, dim3(n_p, d_p / 64), dim3(256), 0, s, c->csc_part, c->csc_pbe, c->csc_item_start, n_p,
+                         d_p, gWd, gWe, gbe, c->db_part);
       ev_end(c, KID_TK_DWE, s);
       HIP_TRY(hipGetLastError());
       notify_grads(c, c->nW + c->n_p, c->nW, s);                 // d W_dec
@@ -1327,11 +1330,11 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       hipLaunchKernelGGL(reduce_db_kernel, dim3(n_p / 32), dim3(256), 0, s, c->db_part, gbe, (int)(Mp / 128), n_p);
     // d b_dec also receives -sum_rows(dpre W_enc) through sae_in = x - b_dec; that row sum is a GEMV on d b_enc
     ev_begin(c, KID_TK_DSAE, s);
-    const int nchunks = (n_p + 255) / 256;
+    const int nchunks = (n_p + 63) / 64;
     hipLaunchKernelGGL(topk_dsae_colsum_kernel, dim3((d_p + 255) / 256, nchunks), dim3(256), 0, s,
                        (use_csc || c->topk_sparse_da) ? c->db_part : gbe, c->We_b, c->ds_part, n_p, d_p);
     ev_end(c, KID_TK_DSAE, s);
-    hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 255) / 256), dim3(256), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
+    hipLaunchKernelGGL(topk_dbd_kernel, dim3((d_p + 63) / 64), dim3(1024), 0, s, c->dbd_part, nrb, c->ds_part, nchunks, gbd, d_p);
     ev_end(c, KID_REDUCE, s);
     notify_grads(c, 0, c->nW + c->n_p, s);                                                     // d W_enc | d b_enc
     notify_grads(c, 2 * c->nW + c->n_p, c->d_p + SAE_NUM_METRICS + c->n_p, s);                 // d b_dec | scalars | did_fire

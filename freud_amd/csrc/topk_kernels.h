@@ -15,8 +15,9 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-// sae_in = bf16(x - b_dec) (topkautoencoder.py:74), zero padded to [M_p][d_p]
-template <typename T>
+// sae_in = bf16(x - b_dec) (topkautoencoder.py:74), zero padded to [M_p][d_p]; 8 elements per thread, one vector load when
+// d % 8 == 0 and x is 16-byte aligned (VEC)
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void topk_prep_x_kernel(const T* __restrict__ x, const float* __restrict__ b_dec,
                                                            bf16_t* __restrict__ xs, int64_t M, int d, int64_t M_p, int d_p) {
   const unsigned int cpr = (unsigned int)d_p >> 3;
@@ -25,11 +26,18 @@ __global__ __launch_bounds__(256) void topk_prep_x_kernel(const T* __restrict__ 
     const int64_t row = i / cpr;
     const int c0 = (int)(i - (unsigned int)row * cpr) * 8;
     bf16x8 o;
+    if (VEC && row < M && c0 + 8 <= d) {
+      const typename Vec8<T>::type v = *reinterpret_cast<const typename Vec8<T>::type*>(x + row * d + c0);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b_dec + c0), b1 = *reinterpret_cast<const f32x4*>(b_dec + c0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = 0.f;
-      if (row < M && c0 + j < d) v = (float)x[row * d + c0 + j] - b_dec[c0 + j];
-      o[j] = (bf16_t)v;
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)v[j] - (j < 4 ? b0[j] : b1[j - 4]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (row < M && c0 + j < d) v = (float)x[row * d + c0 + j] - b_dec[c0 + j];
+        o[j] = (bf16_t)v;
+      }
     }
     *reinterpret_cast<bf16x8*>(xs + row * d_p + c0) = o;
   }
@@ -655,17 +663,17 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
 
 // tkf: [0] aux scale, [1] total_variance, [5] coef = alpha*scale*2/tv
 // metrics: [0] fvu, [1] auxk*alpha, [2] mse, [5] dead fraction, [6] multi_topk_fvu
-__global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __restrict__ tv_part, int n_tv,
+__global__ __launch_bounds__(1024) void topk_finalize_kernel(const double* __restrict__ tv_part, int n_tv,
                                                              const float* __restrict__ e2_part, const float* __restrict__ a2_part,
                                                              const float* __restrict__ m2_part,
                                                              int64_t Mp, int64_t M, int d, float auxk_alpha, const int* tk,
                                                              float* __restrict__ tkf, float* __restrict__ metrics,
                                                              float dead_frac_n, const double* __restrict__ gstats, int world) {
-  __shared__ double red[4][4];
+  __shared__ double red[4][16];
   double a = 0, b = 0, c = 0, m = 0;
   const bool have_aux = a2_part != nullptr && tk[0] > 0;     // with no dead latent the AuxK kernels did not run
-  for (int i = threadIdx.x; i < n_tv; i += 256) a += tv_part[i];
-  for (int64_t i = threadIdx.x; i < Mp; i += 256) {
+  for (int i = threadIdx.x; i < n_tv; i += 1024) a += tv_part[i];
+  for (int64_t i = threadIdx.x; i < Mp; i += 1024) {
     b += (double)e2_part[i];
     if (have_aux) c += (double)a2_part[i];
     if (m2_part) m += (double)m2_part[i];
@@ -682,10 +690,13 @@ __global__ __launch_bounds__(256) void topk_finalize_kernel(const double* __rest
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double tv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const double e2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const double a2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-    const double m2 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+    double tv = 0, e2 = 0, a2 = 0, m2 = 0;
+    for (int q = 0; q < 16; ++q) {
+      tv += red[0][q];
+      e2 += red[1][q];
+      a2 += red[2][q];
+      m2 += red[3][q];
+    }
     if (tv == 0) tv = 1.0;
     const float tvf = (float)tv;
     const float scale = tkf[0];
@@ -926,26 +937,36 @@ struct EpiTopkDsaeIn {
 };
 
 // sum over rows of dsae_in = dpre W_enc without the [M][d] GEMM: sum_m sum_n dpre[m][n] We[n][c] = sum_n dbe[n] We[n][c]
-// (dbe = column sums of dpre = the encoder-bias gradient).  Partials over 256-latent chunks, fixed order.
+// (dbe = column sums of dpre = the encoder-bias gradient).  Partials over 64-latent chunks, fixed order.
 __global__ __launch_bounds__(256) void topk_dsae_colsum_kernel(const float* __restrict__ dbe, const bf16_t* __restrict__ We_b,
                                                                 float* __restrict__ part, int n_p, int d_p) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  const int n0 = blockIdx.y * 256;
+  const int n0 = blockIdx.y * 64;
   if (c >= d_p) return;
   float s = 0.f;
-  for (int i = 0; i < 256 && n0 + i < n_p; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
+  for (int i = 0; i < 64 && n0 + i < n_p; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
   part[(int64_t)blockIdx.y * d_p + c] = s;
 }
 
-// d b_dec[c] = sum_blocks dbd_part[.][c] - sum_tiles dsae_part[.][c]
-__global__ __launch_bounds__(256) void topk_dbd_kernel(const float* __restrict__ dbd_part, int nb, const float* __restrict__ ds_part,
-                                                        int nt, float* __restrict__ out, int d_p) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d_p) return;
+// d b_dec[c] = sum_blocks dbd_part[.][c] - sum_tiles dsae_part[.][c]: 64 columns x 16 waves per workgroup, each wave a
+// slice of the partial rows, combined through LDS in wave order (fixed order -> deterministic)
+__global__ __launch_bounds__(1024) void topk_dbd_kernel(const float* __restrict__ dbd_part, int nb, const float* __restrict__ ds_part,
+                                                         int nt, float* __restrict__ out, int d_p) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int i = 0; i < nb; ++i) s += dbd_part[(int64_t)i * d_p + c];
-  for (int i = 0; i < nt; ++i) s -= ds_part[(int64_t)i * d_p + c];
-  out[c] = s;
+  if (c < d_p) {
+    for (int i = w; i < nb; i += 16) s += dbd_part[(int64_t)i * d_p + c];
+    for (int i = w; i < nt; i += 16) s -= ds_part[(int64_t)i * d_p + c];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < d_p) {
+    float t = 0.f;
+    for (int ww = 0; ww < 16; ++ww) t += red[ww][lane];
+    out[c] = t;
+  }
 }
 
 // num_frames_since_fired += rows; [did_fire] = 0 (train_sae.py:443-446).  did_fire may be a data-parallel SUM.

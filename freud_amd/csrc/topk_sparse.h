@@ -70,16 +70,33 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
 }
 
 // ---- 2. per latent: exclusive prefix over the row blocks, total -----------------------------------------------------------
-__global__ __launch_bounds__(256) void csc_scan_blocks_kernel(const unsigned short* __restrict__ counts, int nblocks, int n_p,
-                                                              unsigned int* __restrict__ block_off, unsigned int* __restrict__ total) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_p) return;
+// One workgroup = 64 latents (lane) x 16 waves; wave w owns the row blocks [w nb/16, (w+1) nb/16): partial sums, an exclusive
+// prefix over the 16 waves through LDS, then the same walk again writing the offsets (a single thread per latent walking
+// all 1024 blocks was a 236 us latency chain).
+__global__ __launch_bounds__(1024) void csc_scan_blocks_kernel(const unsigned short* __restrict__ counts, int nblocks, int n_p,
+                                                               unsigned int* __restrict__ block_off, unsigned int* __restrict__ total) {
+  __shared__ unsigned int part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int b0 = (int)((int64_t)nblocks * w / 16), b1 = (int)((int64_t)nblocks * (w + 1) / 16);
   unsigned int run = 0;
-  for (int b = 0; b < nblocks; ++b) {
+  if (j < n_p)
+    for (int b = b0; b < b1; ++b) run += counts[(int64_t)b * n_p + j];
+  part[w][lane] = run;
+  __syncthreads();
+  unsigned int base = 0, tot = 0;
+  for (int ww = 0; ww < 16; ++ww) {
+    const unsigned int v = part[ww][lane];
+    base += ww < w ? v : 0u;
+    tot += v;
+  }
+  if (j >= n_p) return;
+  run = base;
+  for (int b = b0; b < b1; ++b) {
     block_off[(int64_t)b * n_p + j] = run;
     run += counts[(int64_t)b * n_p + j];
   }
-  total[j] = run;
+  if (w == 0) total[j] = tot;
 }
 
 // ---- 3. one block: list starts and work-item starts (exclusive prefixes over the latents) ---------------------------------
@@ -254,19 +271,26 @@ __global__ __launch_bounds__(256) void sparse_combine_kernel(const float* __rest
                                                              const unsigned int* __restrict__ item_start, int n_p, int d_p,
                                                              float* __restrict__ gWd, float* __restrict__ gWe, float* __restrict__ gbe,
                                                              float* __restrict__ dbe_exact) {
+  // grid (n_p, d_p / 64): 64 columns per block; the 4 waves take the items i0 + w, i0 + w + 4, ... and their sums meet in LDS
+  // in wave order (fixed order -> deterministic); a latent that fires on most rows has hundreds of items
+  __shared__ float red[2][4][64];
   const int j = blockIdx.x;
   const unsigned int i0 = item_start[j], i1 = item_start[j + 1];
   if (i1 - i0 == 1) return;                           // written by its single work item itself
-  for (int c = threadIdx.x; c < d_p; c += 256) {
-    float a = 0.f, b = 0.f;
-    for (unsigned int i = i0; i < i1; ++i) {
-      a += part[(int64_t)i * 2 * d_p + c];
-      b += part[(int64_t)i * 2 * d_p + d_p + c];
-    }
-    gWd[(int64_t)j * d_p + c] = a;
-    gWe[(int64_t)j * d_p + c] = b;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y * 64 + lane;
+  float a = 0.f, b = 0.f;
+  for (unsigned int i = i0 + w; i < i1; i += 4) {
+    a += part[(int64_t)i * 2 * d_p + c];
+    b += part[(int64_t)i * 2 * d_p + d_p + c];
   }
-  if (threadIdx.x == 0) {
+  red[0][w][lane] = a;
+  red[1][w][lane] = b;
+  __syncthreads();
+  if (w == 0) {
+    gWd[(int64_t)j * d_p + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    gWe[(int64_t)j * d_p + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
     float s = 0.f;
     for (unsigned int i = i0; i < i1; ++i) s += pbe[i];
     dbe_exact[j] = s;
