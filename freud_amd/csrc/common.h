@@ -27,6 +27,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// max over the 32 lanes of a wave half (lanes 0-31 / 32-63), valid in the lanes 16-31 / 48-63 of the half: DPP only (quad
+// swaps, row_half_mirror / row_mirror bring in the other quad pair / the other half row, row_bcast15 hands the first row's
+// result to the second) -- five ds_bpermute shuffles cost the TopK encoder epilogue +28 % of the whole GEMM, this +5 %
+__device__ __forceinline__ float half_wave_max_hi(float v) {
+  int x = __float_as_int(v);
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false))));    // quad_perm [1,0,3,2]
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false))));    // quad_perm [2,3,0,1]
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false))));   // row_half_mirror
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false))));   // row_mirror
+  // rows 1 and 3 (lanes 16-31, 48-63) take lane 15 of the row before them; the other rows keep their own value
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false))));   // row_bcast15
+  return __int_as_float(x);
+}
+
 // Sum over a group of 256 consecutive threads (4 waves); result valid in the group's first thread.  blockDim.x is 256
 // (one group) or 512 (two groups, each with its own `red`); every thread of the block must call it.
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {

@@ -143,6 +143,8 @@ struct sae_ctx {
   float *e = nullptr, *dh = nullptr, *e2_part = nullptr, *a2_part = nullptr, *dbd_part = nullptr, *ds_part = nullptr, *tkf = nullptr;
   int *top_idx = nullptr, *aux_idx = nullptr, *tk = nullptr;
   bf16_t *top_vals = nullptr, *aux_vals = nullptr, *multi_vals = nullptr;   // selected activations, compact [M_p][kcap]
+  unsigned short* tile_max = nullptr;   // [M_p][n_p / 128] maxima of the pre-activation tiles (tile-driven select)
+  unsigned char* sel_flag = nullptr;    // [M_p] rows the tile-driven select left to the general kernel
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
   int* dead_hint = nullptr;     // pinned host copy of tk[0] (number of dead latents), refreshed asynchronously every step
   double* tv_part = nullptr;
@@ -302,6 +304,8 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->top_idx, Mp * c->k * 4);
   TALLOC(c->aux_idx, Mp * c->k_aux_cap * 4);
   TALLOC(c->top_vals, Mp * c->k * 2);
+  TALLOC(c->tile_max, Mp * (c->n_p / 128) * 2);
+  TALLOC(c->sel_flag, Mp);
   TALLOC(c->aux_vals, Mp * c->k_aux_cap * 2);
   HIP_TRY(hipHostMalloc((void**)&c->dead_hint, 64, hipHostMallocDefault));
   c->dead_hint[0] = 0;
@@ -362,7 +366,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
-                  c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
+                  c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1110,6 +1114,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   // the masked DENSE rows [M x n] are only written for those who read them: the dense fallbacks and validation / inference
   const bool write_dense = !use_csc;
   c->dense_valid = write_dense;
+  // tile-driven main select (topk_select_tiles_kernel): when no dense row is wanted, every column is a candidate and k fits
+  // (rows it cannot take -- too many qualifying tiles or candidates -- fall to the register kernel: n_p <= 2048 * 44)
+  const bool tile_select = !write_dense && n == n_p && k <= n_p / 128 && n_p / 128 <= TSEL_MAX_TILES && n_p <= 2048 * 44 &&
+                           c->cfg.debug_flags != 75;
 
   {
     const int64_t n8 = c->nW / 8;
@@ -1134,6 +1142,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
     EpiTopkEnc e{};
     e.pre = c->pre; e.bias = be; e.M = M; e.n_p = n_p;
+    e.tmax = tile_select ? c->tile_max : nullptr;
     ev_begin(c, KID_TK_ENC, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
     ev_end(c, KID_TK_ENC, s);
@@ -1141,23 +1150,30 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   }
   ev_begin(c, KID_TK_SELECT, s);
   {
+    const unsigned char* only_flagged = nullptr;
     auto launch_select = [&](bf16_t* dense_out, int* idx_out, bf16_t* vals_out, float* fire, const unsigned char* dead_mask,
                              const int* k_ptr, int k_fixed, int kcap) {
       unsigned short* vo = reinterpret_cast<unsigned short*>(vals_out);
       const int wd = write_dense ? 1 : 0;
       if (n_p <= 2048 * 12)
         hipLaunchKernelGGL(topk_select_reg_kernel<12>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd, only_flagged);
       else if (n_p <= 2048 * 44)
         hipLaunchKernelGGL(topk_select_reg_kernel<44>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire,
-                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
+                           dead_mask, k_ptr, k_fixed, kcap, n, n_p, M, vo, wd, only_flagged);
       else
         hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, dense_out, idx_out, fire, dead_mask,
                            k_ptr, k_fixed, kcap, n, n_p, M, vo, wd);
     };
     // did_fire follows out.encoded.top_indices (train_sae.py:442), which forward() re-binds to the 4k selection when
     // cfg.multi_topk is set (topkautoencoder.py:135)
+    if (tile_select) {
+      hipLaunchKernelGGL(topk_select_tiles_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->tile_max, c->top_idx,
+                         reinterpret_cast<unsigned short*>(c->top_vals), c->multi ? (float*)nullptr : did_fire, k, k, n_p, M, c->sel_flag);
+      only_flagged = c->sel_flag;      // the general kernel below then only takes the rows flagged as left over
+    }
     launch_select(c->dense, c->top_idx, c->top_vals, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
+    only_flagged = nullptr;
     if (c->multi) launch_select(c->multi_dense, c->multi_idx, c->multi_vals, did_fire, nullptr, nullptr, c->k4, c->k4);
     if (aux) launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
   }

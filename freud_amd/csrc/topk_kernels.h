@@ -91,24 +91,34 @@ __global__ __launch_bounds__(1024) void dead_mask_kernel(const long long* __rest
 }
 
 // encoder epilogue: pre = relu(bf16(acc + bias)) (Linear under autocast: bf16 addmm, one rounding), rows >= M zero
+// tmax != null: also the maximum of every (row, 128-column tile) -- the 32 lanes of an apply() call cover exactly one such
+// tile of one row -- for the tile-driven select (topk_select_tiles_kernel), which then reads only the tiles that can hold
+// one of the row's k largest values.
 struct EpiTopkEnc {
   bf16_t* pre;          // [M_p][n_p]
   const float* bias;    // [n_p] (fp32 master; rounded to bf16 as autocast casts it)
   int64_t M;
   int n_p;
+  unsigned short* tmax; // [M_p][n_p / 128] bf16 bit patterns (values are >= 0: the pattern orders like the value), or null
   __device__ void tile_begin(int, int, int) {}
   struct Pre { f32x4 b; };
   __device__ Pre prefetch(int, int col) const { return Pre{*reinterpret_cast<const f32x4*>(bias + col)}; }
   __device__ void apply(int row, int col, f32x4 v, const Pre& pf) {
     const f32x4 b = pf.b;
     bf16x4 o;
+    float m = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float p = fmaxf(bf16_round(v[j] + bf16_round(b[j])), 0.f);
       if (row >= M) p = 0.f;
+      m = fmaxf(m, p);
       o[j] = (bf16_t)p;
     }
     EPI_STORE(reinterpret_cast<bf16x4*>(pre + (int64_t)row * n_p + col), o);
+    if (tmax) {
+      m = half_wave_max_hi(m);                            // the 32 lanes of this row's tile; complete in lanes 16-31
+      if ((threadIdx.x & 31) == 16) tmax[(int64_t)row * (n_p >> 7) + (col >> 7)] = (unsigned short)(__float_as_uint(m) >> 16);
+    }
   }
   __device__ void tile_end(float*) {}
 };
@@ -264,11 +274,12 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
                                                                int n_p, int64_t M, unsigned short* __restrict__ vals,
-                                                               int write_dense) {
+                                                               int write_dense, const unsigned char* __restrict__ only_flagged = nullptr) {
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
+  if (only_flagged && !only_flagged[row]) return;     // the tile-driven kernel already selected this row
   const int k_req = k_ptr ? *k_ptr : k_fixed;
   if (k_ptr && k_req <= 0) return;      // AuxK pass without dead latents: nothing downstream reads its outputs (block-uniform)
   const int nvec = n_p >> 3;                       // 16-byte vectors in the row
@@ -553,6 +564,118 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
     }
   }
   for (int j = sel_tot + t; j < kcap; j += 256) ti[j] = -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile-driven select (training, main selection: no dead filter, no dense row): the encoder GEMM's epilogue left the
+// maximum of every 128-column tile of the row (EpiTopkEnc::tmax).  The k-th largest tile maximum L is a provable lower
+// bound of the k-th largest value (k tiles hold a value >= L each), so only the tiles whose maximum reaches L can hold a
+// selected value: typically a third of the row is read instead of all of it.  The keys >= L of those tiles are ranked
+// exactly like in topk_select_reg_kernel's fast path (one sortable word per candidate: value, then lowest column).
+// Returns 0 work for rows it cannot take (flag[row] = 1: more than the candidate capacity, or L == 0) -- the caller runs
+// topk_select_reg_kernel afterwards with `only_flagged`, which skips the rows done here.
+// ------------------------------------------------------------------------------------------
+constexpr int TSEL_MAX_TILES = 1024;     // n_p <= 131072
+constexpr int TSEL_VEC = 12;             // 16-byte vectors per thread at most (3072 vectors = 192 tiles)
+__global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __restrict__ pre, const unsigned short* __restrict__ tmax,
+                                                                int* __restrict__ top_idx, unsigned short* __restrict__ vals,
+                                                                float* __restrict__ did_fire, int k, int kcap, int n_p, int64_t M,
+                                                                unsigned char* __restrict__ flag) {
+  constexpr int SEG = 256;
+  __shared__ unsigned short tm[TSEL_MAX_TILES];
+  __shared__ unsigned short tlist[TSEL_MAX_TILES];
+  __shared__ unsigned int cand_pk[4 * SEG];
+  __shared__ int wave_cnt[4];
+  __shared__ int nq_s;
+  __shared__ unsigned int L_s;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t row = blockIdx.x;
+  const int ntiles = n_p >> 7;
+  int* ti = top_idx + row * kcap;
+  unsigned short* tv = vals + row * kcap;
+  if (t == 0) flag[row] = 0;
+  if (row >= M) {
+    for (int j = t; j < kcap; j += 256) ti[j] = -1;
+    return;
+  }
+  for (int i = t; i < ntiles; i += 256) tm[i] = tmax[row * ntiles + i];
+  if (t == 0) nq_s = 0;
+  __syncthreads();
+  // L = k-th largest tile maximum: every tile ranks itself (ties by index) -- ntiles <= 1024 broadcast reads
+  for (int i = t; i < ntiles; i += 256) {
+    const unsigned int my = ((unsigned int)tm[i] << 16) | (unsigned int)(0xFFFF - i);
+    int rank = 0;
+    for (int j = 0; j < ntiles; ++j) rank += ((((unsigned int)tm[j] << 16) | (unsigned int)(0xFFFF - j)) > my) ? 1 : 0;
+    if (rank == k - 1) L_s = tm[i];
+  }
+  __syncthreads();
+  const unsigned int L = L_s;
+  if (L == 0) {                                     // fewer than k tiles with a positive value: the general kernel takes the row
+    if (t == 0) flag[row] = 1;
+    return;
+  }
+  for (int i = t; i < ntiles; i += 256)
+    if (tm[i] >= L) tlist[atomicAdd(&nq_s, 1)] = (unsigned short)i;      // order irrelevant (candidates are ranked by value / column)
+  __syncthreads();
+  const int nv = nq_s * 16;                          // 16-byte vectors to read
+  const unsigned int lp = L * 0x00010001u;
+  unsigned int* seg = cand_pk + wv * SEG;
+  int wcount = 0;
+#pragma unroll
+  for (int v = 0; v < TSEL_VEC; ++v) {
+    const int vi = v * 256 + t;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    int col0 = 0;
+    if (vi < nv) {
+      col0 = (int)tlist[vi >> 4] * 128 + (vi & 15) * 8;
+      w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + row * n_p + col0));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned int hit = ((w[q] | 0x80008000u) - lp) & 0x80008000u;
+      const unsigned long long any = __ballot(hit != 0u);
+      if (any != 0ull) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool mine = (hit >> (15 + 16 * h)) & 1u;
+          const unsigned long long bm = __ballot(mine);
+          if (mine) {
+            const int pos = wcount + (int)__popcll(bm & ((1ull << lane) - 1ull));
+            const unsigned int key = (w[q] >> (16 * h)) & 0xFFFFu;
+            if (pos < SEG) seg[pos] = (key << 17) | (0x1FFFFu - (unsigned int)(col0 + 2 * q + h));
+          }
+          wcount += (int)__popcll(bm);
+        }
+      }
+    }
+  }
+  if (lane == 0) wave_cnt[wv] = wcount;
+  __syncthreads();
+  const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+  const int C = c0 + c1 + c2 + c3;
+  if (nq_s * 16 > TSEL_VEC * 256 || c0 > SEG || c1 > SEG || c2 > SEG || c3 > SEG) {     // block-uniform
+    if (t == 0) flag[row] = 1;
+    return;
+  }
+  for (int i = t; i < C; i += 256) {
+    const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
+    const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
+    const unsigned int my = cand_pk[sg * SEG + li];
+    int rank = 0;
+    for (int j = 0; j < c0; ++j) rank += cand_pk[j] > my ? 1 : 0;
+    for (int j = 0; j < c1; ++j) rank += cand_pk[SEG + j] > my ? 1 : 0;
+    for (int j = 0; j < c2; ++j) rank += cand_pk[2 * SEG + j] > my ? 1 : 0;
+    for (int j = 0; j < c3; ++j) rank += cand_pk[3 * SEG + j] > my ? 1 : 0;
+    if (rank < k) {
+      const int col = (int)(0x1FFFFu - (my & 0x1FFFFu));
+      if (rank < kcap) {
+        ti[rank] = col;
+        tv[rank] = (unsigned short)(my >> 17);
+      }
+      if (did_fire) did_fire[col] = 1.0f;
+    }
+  }
+  for (int j = k + t; j < kcap; j += 256) ti[j] = -1;
 }
 
 // masked dense row from the compact selection (only when somebody asks for it: sae_latent_buffer, sae_latent_colmax,
