@@ -1,7 +1,9 @@
 #!/bin/bash
-for v in ${KB_VARIANTS:-v2}; do
+build/kbench/gemm_m32 512 512 256 3
+build/kbench/gemm_m32 4096 4096 1280 3
+for v in m32 m32_NOGLOAD m32_NOSTAGE; do
   echo "== $v"
-  build/kbench/gemm_$v 65536 40960 1280
-  build/kbench/gemm_$v 65536 24576 768
-  build/kbench/gemm_$v 1280 40960 131072 1 8
+  build/kbench/gemm_$v 65536 40960 1280 2
+  build/kbench/gemm_$v 65536 1280 40960 2
 done
+build/kbench/gemm_m32 65536 24576 768 2

@@ -1,13 +1,15 @@
 // Stand-alone timing of the 256x256 GEMM skeleton (freud_amd/csrc/gemm256.h) at the shapes of the d = 1280 / d = 768 paths,
 // for A/B experiments on the K loop (compile-time switches G2X_*).  Build here (hipcc cross-compiles), run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DG2X_...] -o build/kbench/gemm_bench tools/kbench/gemm_bench.hip
-//   build/kbench/gemm_bench M N K [kmajor] [splits]
+//   build/kbench/gemm_bench M N K [mode: 0 row (8-wave kernel), 1 kmajor, 2 row (4-wave gemm256w4.h), 3 compare 0 against 2] [splits]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <math.h>
 #include <vector>
 
-#include "../../freud_amd/csrc/gemm256.h"
+#include "gemm256w4.h"
 #include "../../freud_amd/csrc/l1_kernels.h"
 
 struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias / ReLU)
@@ -27,7 +29,10 @@ struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias
 
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536, N = argc > 2 ? atoll(argv[2]) : 40960, K = argc > 3 ? atoll(argv[3]) : 1280;
-  const int kmajor = argc > 4 ? atoi(argv[4]) : 0, splits = argc > 5 ? atoi(argv[5]) : 1;
+  int kmajor = argc > 4 ? atoi(argv[4]) : 0;
+  const int splits = argc > 5 ? atoi(argv[5]) : 1;
+  const bool compare = kmajor == 3;
+  if (compare) kmajor = 0;
   bf16_t *A, *B, *C;
   float* slab = nullptr;
   CK(hipMalloc(&A, M * K * 2));
@@ -39,7 +44,7 @@ int main(int argc, char** argv) {
   for (int64_t off = 0; off < N * K; off += (int64_t)h.size()) CK(hipMemcpy(B + off, h.data(), (size_t)std::min<int64_t>(h.size(), N * K - off) * 2, hipMemcpyHostToDevice));
   GemmArgs g{};
   g.A0 = A; g.B0 = B; g.splits = splits;
-  if (!kmajor) {          // C[M][N] = A[M][K] B[N][K]^T
+  if (kmajor != 1) {      // C[M][N] = A[M][K] B[N][K]^T
     g.lda = K; g.ldb = K; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
   } else {                // weight-gradient shape: C[M][N] = sum_k A[k][M] B[k][N], K rows
     g.lda = M; g.ldb = N; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
@@ -48,8 +53,21 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  const int mode = kmajor;
+  auto run_w4 = [&](bf16_t* out) {
+    EpiBf16 e{out, N};
+#ifdef KB_M32
+    auto kern = gemm256w4m_bf16_kernel<EpiBf16>;
+#else
+    auto kern = gemm256w4_bf16_kernel<EpiBf16>;
+#endif
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(256), G2_LDS_BYTES, 0, g, e);
+  };
   auto run = [&]() {
-    if (!kmajor) {
+    if (mode == 2) {
+      run_w4(C);
+    } else if (!kmajor) {
       EpiBf16 e{C, N};
       auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16>;
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
@@ -62,6 +80,31 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
     }
   };
+  if (compare) {
+    bf16_t* C2;
+    CK(hipMalloc(&C2, M * N * 2));
+    CK(hipMemset(C, 0, M * N * 2));
+    CK(hipMemset(C2, 0xFF, M * N * 2));
+    run();
+    run_w4(C2);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned short> c1((size_t)M * N), c2((size_t)M * N);
+    CK(hipMemcpy(c1.data(), C, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c2.data(), C2, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+    auto f = [](unsigned short b) { unsigned u = (unsigned)b << 16; float x; memcpy(&x, &u, 4); return x; };
+    double maxd = 0, maxv = 0;
+    size_t bad = 0, diff = 0;
+    for (size_t i = 0; i < c1.size(); ++i) {
+      const double a = f(c1[i]), b = f(c2[i]);
+      if (!(fabs(a - b) <= 0.01 * fabs(a) + 1e-6)) ++bad;     // one bf16 ulp is 0.4-0.8 %
+      if (c1[i] != c2[i]) ++diff;
+      if (fabs(a - b) > maxd) maxd = fabs(a - b);
+      if (fabs(a) > maxv) maxv = fabs(a);
+    }
+    printf("compare 8-wave vs 4-wave: %zu of %zu elements differ (bf16 bits), %zu beyond 1 %%, max |diff| %.3g, max |value| %.3g\n", diff,
+           c1.size(), bad, maxd, maxv);
+    return bad ? 1 : 0;
+  }
   for (int i = 0; i < 3; ++i) run();
   CK(hipDeviceSynchronize());
   // hold the clocks with the workload itself for ~0.3 s, then time
@@ -76,7 +119,7 @@ int main(int argc, char** argv) {
     reps += 5;
   } while (reps < 40);
   const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
-  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", kmajor ? "kmajor" : "row", (long long)M, (long long)N,
+  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
          (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
   return 0;
 }
