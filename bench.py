@@ -306,7 +306,7 @@ def main():
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "
                                      "resident in HBM (BASELINE configs[2] shape)")
-        out["loss"] = {"fvu": float(metrics[0]), "auxk": float(metrics[1]), "grad_norm": float(metrics[3])}
+        out["loss"] = {"fvu": float(metrics[0]), "auxk": float(metrics[1]), "grad_norm": float(metrics[3]), "dead_frac": float(metrics[5])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.variant == "l1":
         out["cpu_baseline"] = cpu_baseline(x_cpu, W, b, args.cpu_steps, base_lr)
     elif rank == 0:

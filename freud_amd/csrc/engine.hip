@@ -24,6 +24,7 @@ static thread_local int g_device = 0;  // device of the context the current call
 #include "fwd_fused.h"
 #include "topk_kernels.h"
 #include "topk_sparse.h"
+#include "topk_aux.h"
 
 // ------------------------------------------------------------------------------------------
 // error handling
@@ -85,13 +86,14 @@ enum KernelId {
   KID_TK_DWD,
   KID_TK_DWE,
   KID_TK_DSAE,
+  KID_TK_AUX,
   KID_STEP_TOTAL,
   KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x", "enc_fwd_gemm", "dec_fwd_gemm", "fwd_fused_gemm", "dpre_gemm",
                                               "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "topk_enc_gemm", "topk_select",
                                               "topk_decode", "topk_ddense_gemm", "topk_dwdec_gemm", "topk_dwenc_gemm",
-                                              "topk_dsaein_colsum", "fwd_bwd_total"};
+                                              "topk_dsaein_colsum", "topk_auxk_backward", "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
 struct EvRing {
@@ -146,6 +148,12 @@ struct sae_ctx {
   unsigned short* tile_max = nullptr;   // [M_p][n_p / 128] maxima of the pre-activation tiles (tile-driven select)
   unsigned char* sel_flag = nullptr;    // [M_p] rows the tile-driven select left to the general kernel
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
+  // AuxK on the compacted dead set (topk_aux.h)
+  bool aux_compact = false;
+  int *tkd = nullptr, *dead_cols = nullptr, *vec_rank = nullptr;
+  unsigned char* vec_bits = nullptr;
+  bf16_t* Wdd_b = nullptr;          // [n_p][d_p] rows of W_dec of the dead latents, compact
+  float* aux_dbe_part = nullptr;    // [M_p / 128][n_p] column sums of the AuxK d pre-activations, compact columns
   int* dead_hint = nullptr;     // pinned host copy of tk[0] (number of dead latents), refreshed asynchronously every step
   double* tv_part = nullptr;
   long long* nfsf = nullptr;
@@ -343,6 +351,17 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
     TALLOC(c->csc_part, (size_t)c->csc_max_items * 2 * c->d_p * 4);
     TALLOC(c->csc_pbe, (size_t)c->csc_max_items * 4);
   }
+  // AuxK as dense GEMMs over the compacted dead latents: with the CSC main path and the register select kernel
+  c->aux_compact = c->topk_csc && c->cfg.auxk_alpha != 0.0 && c->n_p <= 2048 * 44 && c->cfg.debug_flags != 76;
+  if (c->aux_compact) {
+    TALLOC(c->tkd, 64);
+    TALLOC(c->dead_cols, (size_t)c->n_p * 4);
+    TALLOC(c->vec_rank, (size_t)(c->n_p / 8) * 4);
+    TALLOC(c->vec_bits, (size_t)(c->n_p / 8));
+    TALLOC(c->Wdd_b, c->nW * 2);
+    TALLOC(c->aux_dbe_part, (Mp / 128) * c->n_p * 4);
+    HIP_TRY(hipMemset(c->tkd, 0, 64));
+  }
   // the multi-TopK weight gradient is a second GEMM launch into its own split-K slabs
   TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * (c->multi ? 2 : 1) * c->nW * 4);
   TALLOC(c->gn_part, 1024 * 8);
@@ -367,7 +386,8 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
-                  c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe};
+                  c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
+                  c->aux_dbe_part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
@@ -1102,14 +1122,20 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   // ON THE DEVICE: the aux kernels are always enqueued and exit at once when tk[0] == 0, the weight-gradient GEMM drops its
   // second K segment through GemmArgs::seg1_gate -- no device->host copy, no stream synchronisation in the step.
   // validate() passes no dead_mask (train_sae.py:168-171): without a backward the AuxK branch is off.
-  hipLaunchKernelGGL(dead_mask_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
-                     c->tkf);
+  if (c->aux_compact)
+    hipLaunchKernelGGL(dead_compact_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
+                       c->tkf, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits);
+  else
+    hipLaunchKernelGGL(dead_mask_kernel, dim3(1), dim3(1024), 0, s, c->nfsf, c->dead, did_fire, n, n_p, c->dead_threshold, d, c->tk,
+                       c->tkf);
   const bool aux = alpha != 0.f && backward;      // "possible": the device gates it on tk[0] > 0
+  // AuxK as dense GEMMs over the compacted dead latents (topk_aux.h) next to the CSC backward of the main selection
+  const bool auxc = aux && c->aux_compact;
   // Which backward: the CSC one (topk_sparse.h) wins by a wide margin while no latent is dead, the dense-GEMM one once the
   // AuxK pass brings d/2 more entries per row.  Both are correct for any number of dead latents (each gates its AuxK part
   // on the device), so the choice may rest on a STALE count: the last value of tk[0] that an asynchronous copy happened to
   // land in pinned host memory (this step's copy is enqueued now and read by some later step; never waited for).
-  const bool use_csc = c->topk_csc && backward && !(aux && c->dead_hint[0] > 0);
+  const bool use_csc = c->topk_csc && backward && (auxc || !(aux && c->dead_hint[0] > 0));
   HIP_TRY(hipMemcpyAsync(c->dead_hint, c->tk, 4, hipMemcpyDeviceToHost, s));
   // the masked DENSE rows [M x n] are only written for those who read them: the dense fallbacks and validation / inference
   const bool write_dense = !use_csc;
@@ -1125,6 +1151,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, We, c->We_b, n8);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, Wd, c->Wd_b, n8);
+    if (auxc) hipLaunchKernelGGL(aux_gather_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->Wd_b, c->dead_cols, c->tkd, c->Wdd_b, d_p);
     const int64_t chunks = Mp * (d_p / 8);
     int g2 = (int)((chunks + 255) / 256);
     if (g2 > 4096) g2 = 4096;
@@ -1175,7 +1202,19 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     launch_select(c->dense, c->top_idx, c->top_vals, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
     only_flagged = nullptr;
     if (c->multi) launch_select(c->multi_dense, c->multi_idx, c->multi_vals, did_fire, nullptr, nullptr, c->k4, c->k4);
-    if (aux) launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
+    if (auxc) {         // compact masked rows over the dead columns only
+      unsigned short* vo = reinterpret_cast<unsigned short*>(c->aux_vals);
+      if (n_p <= 2048 * 12)
+        hipLaunchKernelGGL((topk_select_reg_kernel<12, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
+                           c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
+                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd);
+      else
+        hipLaunchKernelGGL((topk_select_reg_kernel<44, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
+                           c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
+                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd);
+    } else if (aux) {
+      launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
+    }
   }
   ev_end(c, KID_TK_SELECT, s);
   ev_begin(c, KID_TK_DECODE, s);
@@ -1184,7 +1223,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       constexpr int NP = decltype(np_tag)::value;
       hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->top_vals, c->top_idx, k, c->Wd_b,
                          bd, c->e, c->dh, c->e2_part, M, d, d_p, n_p, 0, (const int*)nullptr);
-      if (aux)
+      if (aux && !auxc)
         hipLaunchKernelGGL((topk_decode_kernel<T, NP>), dim3((unsigned)(Mp / 4)), dim3(256), 0, s, x, c->aux_vals, c->aux_idx,
                            c->k_aux_cap, c->Wd_b, bd, c->e, c->dh, c->a2_part, M, d, d_p, n_p, 1, (const int*)c->tk);
       if (c->multi)     // e_multi = decode(top-4k) - x into its own residual buffer
@@ -1195,6 +1234,17 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     else if (d_p == 768) launch_decode(std::integral_constant<int, 6>{});
     else if (d_p == 1280) launch_decode(std::integral_constant<int, 10>{});
     else launch_decode(std::integral_constant<int, 0>{});
+    if (auxc) {   // e_hat = A_aux W_dec[dead] over the compact dead set: K = ND_p (device side), e_hat - e and its squares in the epilogue
+      HIP_TRY(hipMemsetAsync(c->a2_part, 0, (size_t)Mp * 4, s));
+      GemmArgs g{};
+      g.A0 = c->aux_dense; g.B0 = c->Wdd_b; g.lda = n_p; g.ldb = d_p;
+      g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
+      g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_K;
+      EpiAuxDecode e{};
+      e.e = c->e; e.b_dec = bd; e.dh = c->dh; e.part = c->a2_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = d_p / 128;
+      rc = launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
+      if (rc) return rc;
+    }
   }
   const int64_t TD = T_rows * d;
   if (gs) {
@@ -1214,7 +1264,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       // ---- CSC backward: selection sorted by latent, then d W_dec, d W_enc and d b_enc as gathered row sums (topk_sparse.h)
       SparsePasses ps{};
       if (c->multi) { ps.idx[0] = c->multi_idx; ps.vals[0] = c->multi_vals; ps.g[0] = c->dm_b; ps.kcap[0] = c->k4; }
-      if (aux) { ps.idx[1] = c->aux_idx; ps.vals[1] = c->aux_vals; ps.g[1] = c->dh_b; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
+      if (aux && !auxc) { ps.idx[1] = c->aux_idx; ps.vals[1] = c->aux_vals; ps.g[1] = c->dh_b; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
       ps.idx[2] = c->top_idx; ps.vals[2] = c->top_vals; ps.g[2] = c->de_b; ps.kcap[2] = k;
       const int nb = (int)((M + CSC_ROWS - 1) / CSC_ROWS);
       const int lds = n_p * 2;
@@ -1244,6 +1294,37 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
                          d_p, gWd, gWe, gbe, c->db_part);
       ev_end(c, KID_TK_DWE, s);
       HIP_TRY(hipGetLastError());
+      if (auxc) {
+        // ---- AuxK backward over the compact dead set (every launch covers the static maximum and gates itself on the device)
+        ev_begin(c, KID_TK_AUX, s);
+        {   // d A = [selected, > 0] bf16(d e_hat W_dec[dead]^T), column sums
+          GemmArgs g{};
+          g.A0 = c->dh_b; g.B0 = c->Wdd_b; g.lda = d_p; g.ldb = d_p;
+          g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+          g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_N;
+          EpiTopkDpre e{};
+          e.sel = c->aux_dense; e.dpre = c->dpre; e.dbe_part = c->aux_dbe_part; e.n_p = n_p; e.accumulate = 0; e.last = 1;
+          rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
+          if (rc) return rc;
+        }
+        for (int which = 0; which < 2; ++which) {   // d W_dec[dead] += A_aux^T d e_hat ; d W_enc[dead] += d A^T sae_in
+          GemmArgs g{};
+          g.A0 = which == 0 ? c->aux_dense : c->dpre; g.B0 = which == 0 ? c->dh_b : c->xs; g.lda = n_p; g.ldb = d_p;
+          g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
+          g.splits = c->dw_splits > g.ktiles ? g.ktiles : c->dw_splits;
+          g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_M;
+          EpiSlab e{};
+          e.slab = c->slab; e.slab_stride = c->nW; e.ld = d_p;
+          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+          if (rc) return rc;
+          hipLaunchKernelGGL(aux_scatter_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->slab, c->nW, g.splits, c->dead_cols, c->tkd,
+                             which == 0 ? gWd : gWe, d_p);
+        }
+        hipLaunchKernelGGL(aux_scatter_dbe_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->aux_dbe_part, (int)(Mp / 128), n_p,
+                           c->dead_cols, c->tkd, c->db_part, gbe);
+        ev_end(c, KID_TK_AUX, s);
+        HIP_TRY(hipGetLastError());
+      }
       notify_grads(c, c->nW + c->n_p, c->nW, s);                 // d W_dec
     } else {
     if (c->topk_sparse_da) {   // dpre only where a latent was selected: k (+ k_aux) gathered dot products per row

@@ -29,7 +29,29 @@ struct GemmArgs {
   int ktiles;        // total K tiles (segment 0 + segment 1)
   int splits;        // split-K factor (grid = nbm*nbn*splits)
   const int* seg1_gate;  // device flag (may be null): *seg1_gate == 0 drops K segment 1 (the TopK AuxK pair when no latent is dead)
+  // One dimension of the problem may be known only on the device (the number of dead latents of the TopK AuxK branch,
+  // padded to 256): dyn points to {count, count_p / 128, count_p / 256, count_p / 64} and dyn_dim says what it replaces --
+  // GEMM_DYN_M: the output tile rows (nbm), GEMM_DYN_N: the output tile columns (nbn), GEMM_DYN_K: the K tiles (one
+  // segment).  The launch covers the static maximum; workgroups beyond the dynamic extent exit at once (count 0: all).
+  const int* dyn;
+  int dyn_dim;
 };
+enum { GEMM_DYN_NONE = 0, GEMM_DYN_M = 1, GEMM_DYN_N = 2, GEMM_DYN_K = 3 };
+
+// Resolves the device-side dimension; TILE128 = 1 for the 128x128 kernel, 2 for the 256x256 kernels.  False = nothing to do.
+__device__ __forceinline__ bool gemm_dyn_dims(const GemmArgs& g, int tile_idx, int& nbm, int& nbn, int& ktiles0, int& ktiles) {
+  nbm = g.nbm;
+  nbn = g.nbn;
+  ktiles0 = g.ktiles0;
+  ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
+  if (g.dyn != nullptr) {
+    if (g.dyn[0] <= 0) return false;
+    if (g.dyn_dim == GEMM_DYN_M) nbm = g.dyn[tile_idx];
+    else if (g.dyn_dim == GEMM_DYN_N) nbn = g.dyn[tile_idx];
+    else ktiles0 = ktiles = g.dyn[3];
+  }
+  return (int)blockIdx.x < nbm * nbn * g.splits;
+}
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
 constexpr int GEMM_STAGE_BYTES = 32768;              // A 16 KiB + B 16 KiB
@@ -116,13 +138,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
 
-  const int nblk = g.nbm * g.nbn * g.splits;
+  int nbm, nbn, ktiles0, ktiles;
+  if (!gemm_dyn_dims(g, 1, nbm, nbn, ktiles0, ktiles)) return;
+  const int nblk = nbm * nbn * g.splits;
   int id = xcd_remap(blockIdx.x, nblk);
-  const int split = id / (g.nbm * g.nbn);
-  id -= split * (g.nbm * g.nbn);
+  const int split = id / (nbm * nbn);
+  id -= split * (nbm * nbn);
   int bm, bn;
-  tile_coords(id, g.nbm, g.nbn, bm, bn);
-  const int ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
+  tile_coords(id, nbm, nbn, bm, bn);
   const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
   const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
 
@@ -135,16 +158,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto a_ptr = [&](int kt) -> const bf16_t* {
-    const bool s1 = kt >= g.ktiles0;
+    const bool s1 = kt >= ktiles0;
     const bf16_t* base = s1 ? g.A1 : g.A0;
-    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    const int k = (s1 ? kt - ktiles0 : kt) * GEMM_BK;
     if constexpr (AMODE == OP_ROW) return base + (int64_t)(bm * GEMM_BM) * g.lda + k;
     else return base + (int64_t)k * g.lda + bm * GEMM_BM;
   };
   auto b_ptr = [&](int kt) -> const bf16_t* {
-    const bool s1 = kt >= g.ktiles0;
+    const bool s1 = kt >= ktiles0;
     const bf16_t* base = s1 ? g.B1 : g.B0;
-    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    const int k = (s1 ? kt - ktiles0 : kt) * GEMM_BK;
     if constexpr (BMODE == OP_ROW) return base + (int64_t)(bn * GEMM_BN) * g.ldb + k;
     else return base + (int64_t)k * g.ldb + bn * GEMM_BN;
   };

@@ -91,13 +91,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
 
-  const int nblk = g.nbm * g.nbn * g.splits;
+  int nbm, nbn, ktiles0, ktiles;
+  if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles)) return;
+  const int nblk = nbm * nbn * g.splits;
   int id = xcd_remap(blockIdx.x, nblk);
-  const int split = id / (g.nbm * g.nbn);
-  id -= split * (g.nbm * g.nbn);
+  const int split = id / (nbm * nbn);
+  id -= split * (nbm * nbn);
   int bm, bn;
-  tile_coords(id, g.nbm, g.nbn, bm, bn);
-  const int ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
+  tile_coords(id, nbm, nbn, bm, bn);
   const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
   const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
 
@@ -110,16 +111,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto a_ptr = [&](int kt) -> const bf16_t* {
-    const bool s1 = kt >= g.ktiles0;
+    const bool s1 = kt >= ktiles0;
     const bf16_t* base = s1 ? g.A1 : g.A0;
-    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    const int k = (s1 ? kt - ktiles0 : kt) * GEMM_BK;
     if constexpr (AMODE == OP_ROW) return base + (int64_t)(bm * G2_BM) * g.lda + k;
     else return base + (int64_t)k * g.lda + bm * G2_BM;
   };
   auto b_ptr = [&](int kt) -> const bf16_t* {
-    const bool s1 = kt >= g.ktiles0;
+    const bool s1 = kt >= ktiles0;
     const bf16_t* base = s1 ? g.B1 : g.B0;
-    const int k = (s1 ? kt - g.ktiles0 : kt) * GEMM_BK;
+    const int k = (s1 ? kt - ktiles0 : kt) * GEMM_BK;
     if constexpr (BMODE == OP_ROW) return base + (int64_t)(bn * G2_BN) * g.ldb + k;
     else return base + (int64_t)k * g.ldb + bn * G2_BN;
   };

@@ -268,13 +268,47 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* wave_tot /* >= 4 
   return base + inc - v;
 }
 
-template <int MAXV>
+// COMPACT (the AuxK selection on the compacted dead set, topk_aux.h): instead of the masked dense row over all n_p columns
+// the kernel writes the masked row over the dead columns only -- dense[row * n_p + r] for r < ND_p, r = rank of the column
+// among the dead ones (vec_rank / vec_bits: dead_compact_kernel): the compact row is zero-filled first (the block scans'
+// barriers drain those stores before anything is emitted), then every selected POSITIVE value is stored at its rank.
+// Selected zeros (ties at 0 when a row has fewer positive dead latents than k_aux) carry neither activation nor
+// gradient, so they are not ranked at all here; `write_dense` is implied.
+// Candidates above `my` in the four per-wave candidate segments (c0..c3 entries, each segment zero-padded to a multiple of
+// 8 by its wave: packed candidates are > 0).  Every lane reads the same addresses (LDS broadcast), 8 candidates per pair
+// of 16-byte reads: one candidate per dependent 4-byte read made this loop the longest phase of the select kernels
+// (~64 cycles of LDS latency per candidate, 150-1000 candidates per row).
+template <int SEGSZ>
+__device__ __forceinline__ int topk_rank_among(const unsigned int* cand_pk, int c0, int c1, int c2, int c3, unsigned int my) {
+  int rank = 0;
+  const int cnt[4] = {c0, c1, c2, c3};
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(cand_pk + sg * SEGSZ);
+    const int n8 = (cnt[sg] + 7) >> 3;
+    for (int j = 0; j < n8; ++j) {
+      const u32x4 a = p[2 * j], b = p[2 * j + 1];
+      rank += (a[0] > my) + (a[1] > my) + (a[2] > my) + (a[3] > my) + (b[0] > my) + (b[1] > my) + (b[2] > my) + (b[3] > my);
+    }
+  }
+  return rank;
+}
+// the pad: lanes 0..7 of the wave zero the 8 entries behind its last candidate (no-op past the segment's end)
+template <int SEGSZ>
+__device__ __forceinline__ void topk_pad_segment(unsigned int* seg, int wcount, int lane) {
+  if (lane < 8 && wcount + lane < SEGSZ) seg[wcount + lane] = 0u;
+}
+
+template <int MAXV, bool COMPACT = false>
 __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
                                                                int n_p, int64_t M, unsigned short* __restrict__ vals,
-                                                               int write_dense, const unsigned char* __restrict__ only_flagged = nullptr) {
+                                                               int write_dense, const unsigned char* __restrict__ only_flagged = nullptr,
+                                                               const int* __restrict__ vec_rank = nullptr,
+                                                               const unsigned char* __restrict__ vec_bits = nullptr,
+                                                               const int* __restrict__ tkd = nullptr) {
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
@@ -287,11 +321,20 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
   unsigned short* tv = vals + row * kcap;     // the selected activations, compact: tv[p] belongs to ti[p]
+  const int cvec = COMPACT ? tkd[4] >> 3 : 0;      // 16-byte vectors of the compact row (ND_p / 8)
+  if (COMPACT) write_dense = 0;
+  auto cpos = [&](int col) { return vec_rank[col >> 3] + __popc((unsigned)vec_bits[col >> 3] & ((1u << (col & 7)) - 1u)); };
   if (row >= M) {                       // padding rows (all-zero pre) select nothing and must not mark any latent as fired
     if (write_dense)
       for (int g = t; g < nvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
+    if (COMPACT)
+      for (int g = t; g < cvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
+  }
+  unsigned short* crow = reinterpret_cast<unsigned short*>(dense + row * n_p);
+  if (COMPACT) {                        // (__syncthreads = s_waitcnt vmcnt(0) + barrier: these stores have landed before any emission)
+    for (int g = t; g < cvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
   }
 
   // ---- load + candidate filter.  keys[v][q] packs columns 8 g + 2 q (low half) and 8 g + 2 q + 1 (high half)
@@ -307,11 +350,15 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
         cb = 0xFFu;
       } else {
+        if (COMPACT) {                                 // the dead bits of the vector's 8 columns, one byte (dead implies col < n)
+          cb = vec_bits[g];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int col = 8 * g + e;
-          const bool ok = col < n && (!dead || dead[col]);
-          cb |= ok ? (1u << e) : 0u;
+          for (int e = 0; e < 8; ++e) {
+            const int col = 8 * g + e;
+            const bool ok = col < n && (!dead || dead[col]);
+            cb |= ok ? (1u << e) : 0u;
+          }
         }
         // zero the keys of non-candidates
 #pragma unroll
@@ -351,6 +398,8 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       for (int v = 0; v < MAXV; ++v)
         if (v * 256 + t < nvec) dst[v * 256 + t] = u32x4{0u, 0u, 0u, 0u};
     }
+    if (COMPACT)
+      for (int g = t; g < cvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
@@ -362,29 +411,43 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
   //   (key << 17 | (0x1FFFF - column): larger = larger value, then lower column, the tie rule), every candidate counts
   //   the candidates above it -- its rank IS its output slot (sorted by value), ranks below k are the selection.
   //   This replaces ~18 block-wide counting probes over all n keys (the old path below, kept for rows it cannot take:
-  //   L == 0, k > 256, or a wave with more than TOPK_SEG_CAP candidates).
+  //   L == 0, k > 1024, or a wave with more than TOPK_SEG_CAP candidates).  For 256 < k <= 1024 (the AuxK selection, k_aux =
+  //   d / 2) the bound comes from FOUR values per lane instead of one.
   constexpr int TOPK_SEG_CAP = 256;                    // candidates per wave
-  __shared__ unsigned int cand_pk[4 * TOPK_SEG_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned int cand_pk[4 * TOPK_SEG_CAP];
   __shared__ unsigned int wave_lb[4];
   __shared__ int wave_cnt[4];
   __shared__ unsigned int thr_pk;
   bool done = false;
-  if (k <= 256) {
-    unsigned int m2 = 0;                               // packed max of the thread's keys (two 16-bit lanes)
+  if (k <= 1024) {
+    // packed largest (m1) and second largest (m2) key of the thread's even columns (low halves) and odd columns (high halves)
+    typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+    us2 m1 = {0, 0}, m2 = {0, 0};
 #pragma unroll
     for (int v = 0; v < MAXV; ++v)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        typedef __attribute__((ext_vector_type(2))) unsigned short us2;
-        const us2 a = __builtin_bit_cast(us2, m2), b = __builtin_bit_cast(us2, keys[v][q]);
-        m2 = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
+        const us2 b = __builtin_bit_cast(us2, keys[v][q]);
+        m2 = __builtin_elementwise_max(m2, __builtin_elementwise_min(m1, b));
+        m1 = __builtin_elementwise_max(m1, b);
       }
-    const unsigned int tmax = max(m2 & 0xFFFFu, m2 >> 16);
+    // k <= 256: one value per lane (its maximum), the kw-th largest of 64 with kw = ceil(k / 4) <= 64;
+    // k  > 256: four values per lane (two largest of each half: four different elements of the row), kw-th largest of 256
+    const bool four = k > 256;
+    unsigned int tv4[4] = {max((unsigned int)m1[0], (unsigned int)m1[1]), 0u, 0u, 0u};
+    if (four) {
+      tv4[0] = m1[0];
+      tv4[1] = m1[1];
+      tv4[2] = m2[0];
+      tv4[3] = m2[1];
+    }
     const int kw = (k + 3) >> 2;
-    unsigned int lo = 0, hi = 0x8000u;                 // largest lw with #(lane maxima >= lw) >= kw (lw = 0 always qualifies)
+    unsigned int lo = 0, hi = 0x8000u;                 // largest lw with #(values >= lw) >= kw (lw = 0 always qualifies)
     while (lo < hi) {
       const unsigned int mid = (lo + hi + 1) >> 1;
-      if (__popcll(__ballot(tmax >= mid)) >= kw) lo = mid; else hi = mid - 1;
+      int cnt = __popcll(__ballot(tv4[0] >= mid));
+      if (four) cnt += __popcll(__ballot(tv4[1] >= mid)) + __popcll(__ballot(tv4[2] >= mid)) + __popcll(__ballot(tv4[3] >= mid));
+      if (cnt >= kw) lo = mid; else hi = mid - 1;
     }
     if ((t & 63) == 0) wave_lb[t >> 6] = lo;
     __syncthreads();
@@ -420,6 +483,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
           }
         }
       if (lane == 0) wave_cnt[wv] = wcount;
+      topk_pad_segment<TOPK_SEG_CAP>(seg, wcount, lane);
       __syncthreads();
       const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
       const int C = c0 + c1 + c2 + c3;
@@ -430,11 +494,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
           const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
           const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
           const unsigned int my = cand_pk[sg * TOPK_SEG_CAP + li];
-          int rank = 0;
-          for (int j = 0; j < c0; ++j) rank += cand_pk[j] > my ? 1 : 0;
-          for (int j = 0; j < c1; ++j) rank += cand_pk[TOPK_SEG_CAP + j] > my ? 1 : 0;
-          for (int j = 0; j < c2; ++j) rank += cand_pk[2 * TOPK_SEG_CAP + j] > my ? 1 : 0;
-          for (int j = 0; j < c3; ++j) rank += cand_pk[3 * TOPK_SEG_CAP + j] > my ? 1 : 0;
+          const int rank = topk_rank_among<TOPK_SEG_CAP>(cand_pk, c0, c1, c2, c3, my);
           if (rank < k) {
             const int col = (int)(0x1FFFFu - (my & 0x1FFFFu));
             if (rank < kcap) {
@@ -443,6 +503,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
             }
             if (did_fire) did_fire[col] = 1.0f;
             if (rank == k - 1) thr_pk = my;
+            if (COMPACT && (my >> 17) != 0u) crow[cpos(col)] = (unsigned short)(my >> 17);
           }
         }
         for (int j = k + t; j < kcap; j += 256) ti[j] = -1;
@@ -504,7 +565,8 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
     }
   int tie_tot;
   (void)block_excl_scan_256(tie_l, sc, &tie_tot);
-  const bool rank_ties = tie_tot > need_ties;
+  const bool skip_zero = COMPACT && T == 0;          // zero-valued ties: nothing downstream of the compact row sees them
+  const bool rank_ties = !skip_zero && tie_tot > need_ties;
   // ---- emit
   int sel_l = 0, tie_base = 0;
   unsigned selmask[MAXV];
@@ -518,6 +580,7 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       gm |= (c && key > T) ? (1u << e) : 0u;
       tm |= (c && key == T) ? (1u << e) : 0u;
     }
+    if (skip_zero) tm = 0;
     if (rank_ties) {
       int row_tot;
       const int before = block_excl_scan_256(__popc(tm), sc, &row_tot);
@@ -554,12 +617,14 @@ __global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __re
       for (int e = 0; e < 8; ++e)
         if ((selmask[v] >> e) & 1u) {
           const int col = 8 * g + e;
+          const unsigned short key = (unsigned short)((keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
           if (pos < kcap) {
             ti[pos] = col;
-            tv[pos] = (unsigned short)((keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+            tv[pos] = key;
           }
           ++pos;
           if (did_fire) did_fire[col] = 1.0f;
+          if (COMPACT && key != 0) crow[vec_rank[g] + __popc(cand[v] & ((1u << e) - 1u))] = key;
         }
     }
   }
@@ -582,9 +647,9 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
                                                                 float* __restrict__ did_fire, int k, int kcap, int n_p, int64_t M,
                                                                 unsigned char* __restrict__ flag) {
   constexpr int SEG = 256;
-  __shared__ unsigned short tm[TSEL_MAX_TILES];
+  __shared__ __attribute__((aligned(16))) unsigned short tm[TSEL_MAX_TILES + 8];
   __shared__ unsigned short tlist[TSEL_MAX_TILES];
-  __shared__ unsigned int cand_pk[4 * SEG];
+  __shared__ __attribute__((aligned(16))) unsigned int cand_pk[4 * SEG];
   __shared__ int wave_cnt[4];
   __shared__ int nq_s;
   __shared__ unsigned int L_s;
@@ -599,13 +664,21 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
     return;
   }
   for (int i = t; i < ntiles; i += 256) tm[i] = tmax[row * ntiles + i];
+  if (t < 8) tm[ntiles + t] = 0;                    // pad to a multiple of 8 (a zero behind the last tile never outranks anything)
   if (t == 0) nq_s = 0;
   __syncthreads();
-  // L = k-th largest tile maximum: every tile ranks itself (ties by index) -- ntiles <= 1024 broadcast reads
+  // L = k-th largest tile maximum: every tile ranks itself (ties by index) -- broadcast reads, 8 tile maxima per 16 bytes
   for (int i = t; i < ntiles; i += 256) {
     const unsigned int my = ((unsigned int)tm[i] << 16) | (unsigned int)(0xFFFF - i);
     int rank = 0;
-    for (int j = 0; j < ntiles; ++j) rank += ((((unsigned int)tm[j] << 16) | (unsigned int)(0xFFFF - j)) > my) ? 1 : 0;
+    for (int j = 0; j < ntiles; j += 8) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(&tm[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned int key = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+        rank += (((key << 16) | (unsigned int)(0xFFFF - (j + e))) > my) ? 1 : 0;
+      }
+    }
     if (rank == k - 1) L_s = tm[i];
   }
   __syncthreads();
@@ -650,6 +723,7 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
     }
   }
   if (lane == 0) wave_cnt[wv] = wcount;
+  topk_pad_segment<SEG>(seg, wcount, lane);
   __syncthreads();
   const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
   const int C = c0 + c1 + c2 + c3;
@@ -661,11 +735,7 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
     const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
     const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
     const unsigned int my = cand_pk[sg * SEG + li];
-    int rank = 0;
-    for (int j = 0; j < c0; ++j) rank += cand_pk[j] > my ? 1 : 0;
-    for (int j = 0; j < c1; ++j) rank += cand_pk[SEG + j] > my ? 1 : 0;
-    for (int j = 0; j < c2; ++j) rank += cand_pk[2 * SEG + j] > my ? 1 : 0;
-    for (int j = 0; j < c3; ++j) rank += cand_pk[3 * SEG + j] > my ? 1 : 0;
+    const int rank = topk_rank_among<SEG>(cand_pk, c0, c1, c2, c3, my);
     if (rank < k) {
       const int col = (int)(0x1FFFFu - (my & 0x1FFFFu));
       if (rank < kcap) {

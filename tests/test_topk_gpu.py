@@ -267,6 +267,47 @@ def test_sparse_dacts_matches_dense_ddense():
     eng.close()
 
 
+@pytest.mark.parametrize("d,n,n_dead", [(768, 2048, 100), (768, 2048, 700), (384, 1024, 1024), (1280, 1536, 900)])
+def test_auxk_compact_dead_set_matches_gather_path_and_oracle(d, n, n_dead):
+    """AuxK as dense GEMMs over the compacted dead latents (topk_aux.h, the default) against the gather kernels it replaces
+    (debug_flags 76 switches the compaction off) and against the oracle under the engine's tie rule: fewer dead latents
+    than k_aux = d/2 (everything dead is taken), more (a real selection), and ALL latents dead.  Some dead latents are
+    also picked by the main selection of this step (their rows receive both gradients)."""
+    from freud_amd.engine import SaeEngine
+    k, B, T, aux = 16, 2, 96, 0.03125
+    P, x = _make_case(d, n, k, B, T, 11)
+    M = B * T
+    thr = 100.0
+    g = torch.Generator().manual_seed(2)
+    nfsf = torch.zeros(n, dtype=torch.long)
+    nfsf[torch.randperm(n, generator=g)[:n_dead]] = 1000
+    dead = nfsf > thr
+    out = []
+    for flags in (0, 76):
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=aux, debug_flags=flags)
+        eng.set_topk_options(thr, T)
+        eng.set_params({kk: v.numpy() for kk, v in P.items()})
+        eng.set_topk_state(nfsf.numpy())
+        eng.forward_backward(x.cuda())
+        graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+        eng.optimizer_step(1e-4)
+        out.append((graw, eng.metrics().copy(), eng.get_topk_state()))
+        eng.close()
+    (g0, m0, s0), (g1, m1, s1) = out
+    assert m0[1] > 0 and m0[5] == pytest.approx(n_dead / n, abs=1e-7)
+    assert m0[1] == pytest.approx(m1[1], rel=2e-3) and m0[0] == pytest.approx(m1[0], rel=1e-5)
+    assert np.array_equal(s0, s1)
+    for kk in KEYS:
+        assert _rel(g0[kk], g1[kk]) < 2e-3, kk
+    ref = O.topk_train_step(x, P, O.OptState(), k=k, lr=1e-4, clip_thresh=1.0, dead_mask=dead, auxk_alpha=aux, optimizer="adam",
+                            stable_ties=True)
+    assert m0[0] == pytest.approx(ref["fvu"].item(), rel=5e-3)
+    assert m0[1] == pytest.approx(ref["auxk_loss"].item(), rel=2e-2)
+    assert m0[3] == pytest.approx(ref["grad_norm"].item(), rel=2e-2)
+    for kk in KEYS:
+        assert _rel(g0[kk], ref["grads"][kk].numpy()) < 2e-2, kk
+
+
 def _tie_free_case(d, n, k, B, T, seeds=200, k_also=None):
     for seed in range(seeds):
         P, x = _make_case(d, n, k, B, T, seed)
