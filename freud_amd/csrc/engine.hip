@@ -1320,7 +1320,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           hipLaunchKernelGGL(aux_scatter_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->slab, c->nW, g.splits, c->dead_cols, c->tkd,
                              which == 0 ? gWd : gWe, d_p);
         }
-        hipLaunchKernelGGL(aux_scatter_dbe_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->aux_dbe_part, (int)(Mp / 128), n_p,
+        hipLaunchKernelGGL(aux_scatter_dbe_kernel, dim3((n_p + 63) / 64), dim3(1024), 0, s, c->aux_dbe_part, (int)(Mp / 128), n_p,
                            c->dead_cols, c->tkd, c->db_part, gbe);
         ev_end(c, KID_TK_AUX, s);
         HIP_TRY(hipGetLastError());

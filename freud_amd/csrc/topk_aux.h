@@ -142,16 +142,27 @@ __global__ __launch_bounds__(256) void aux_scatter_rows_kernel(const float* __re
 }
 
 // d b_enc of the dead latents: exact[j] += sum_tiles part[tile][r], gbe[j] = bf16(exact[j]) (the encoder bias enters the bf16
-// addmm as a bf16 cast: its gradient is one rounding of the whole column sum, main + aux)
-__global__ __launch_bounds__(256) void aux_scatter_dbe_kernel(const float* __restrict__ part, int ntiles, int ld,
-                                                               const int* __restrict__ dead_cols, const int* __restrict__ tkd,
-                                                               float* __restrict__ exact, float* __restrict__ gbe) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= tkd[TKD_ND]) return;
+// addmm as a bf16 cast: its gradient is one rounding of the whole column sum, main + aux).  64 compact columns per
+// workgroup, 16 waves each a slice of the row tiles, combined through LDS in wave order (fixed order: deterministic).
+__global__ __launch_bounds__(1024) void aux_scatter_dbe_kernel(const float* __restrict__ part, int ntiles, int ld,
+                                                                const int* __restrict__ dead_cols, const int* __restrict__ tkd,
+                                                                float* __restrict__ exact, float* __restrict__ gbe) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
+  const int nd = tkd[TKD_ND];
+  if (blockIdx.x * 64 >= nd) return;
   float s = 0.f;
-  for (int i = 0; i < ntiles; ++i) s += part[(int64_t)i * ld + r];
-  const int j = dead_cols[r];
-  const float v = exact[j] + s;
-  exact[j] = v;
-  gbe[j] = bf16_round(v);
+  if (r < nd)
+    for (int i = w; i < ntiles; i += 16) s += part[(int64_t)i * ld + r];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && r < nd) {
+    float tot = 0.f;
+    for (int ww = 0; ww < 16; ++ww) tot += red[ww][lane];
+    const int j = dead_cols[r];
+    const float v = exact[j] + tot;
+    exact[j] = v;
+    gbe[j] = bf16_round(v);
+  }
 }

@@ -286,6 +286,7 @@ __device__ __forceinline__ int topk_rank_among(const unsigned int* cand_pk, int 
   for (int sg = 0; sg < 4; ++sg) {
     const u32x4* p = reinterpret_cast<const u32x4*>(cand_pk + sg * SEGSZ);
     const int n8 = (cnt[sg] + 7) >> 3;
+#pragma unroll 4
     for (int j = 0; j < n8; ++j) {
       const u32x4 a = p[2 * j], b = p[2 * j + 1];
       rank += (a[0] > my) + (a[1] > my) + (a[2] > my) + (a[3] > my) + (b[0] > my) + (b[1] > my) + (b[2] > my) + (b[3] > my);
@@ -300,7 +301,7 @@ __device__ __forceinline__ void topk_pad_segment(unsigned int* seg, int wcount, 
 }
 
 template <int MAXV, bool COMPACT = false>
-__global__ __launch_bounds__(256) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
+__global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
