@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
           const int k = e >> 2;
           const bf16x4 o = {cfn[e >> 3][(e & 7) - 3], cfn[e >> 3][(e & 7) - 2], cfn[e >> 3][(e & 7) - 1], cfn[e >> 3][e & 7]};
           const int chunk = 4 * (PH & 1) + k;              // 16-B chunk of the 128-B row; +8 bytes for h = 1
-          *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * ah) = o;
+          // (+ row bit 3 on the 8-byte half: rows r and r + 8 of a 16-lane ds_write_b64 group otherwise share a bank pair,
+          // the 2-way conflict behind SQ_LDS_BANK_CONFLICT = 7.7 % of this kernel's LDS cycles in round 1)
+          *reinterpret_cast<bf16x4*>(cst_w + arow * 128 + ((chunk ^ (arow & 7)) << 4) + 8 * (ah ^ ((arow >> 3) & 1))) = o;
         }
       }
       // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 8 gaps later
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       if (i == 37 || i == 42) {
         const int p = 2 * (PH & 1) + (i == 42);
         // written once, read once by the backward after 400 MB more of it: non-temporal, it must not evict W^T / x lines
-        __builtin_nontemporal_store(dr[i == 42], reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride));
+        // odd pieces hold rows with bit 3 set: their 8-byte halves were stored swapped (see the staging write)
+        const u32x4 dv = dr[i == 42];
+        const u32x4 ov = (i == 42) ? u32x4{dv[2], dv[3], dv[0], dv[1]} : dv;
+        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride));
       }
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8 fa = ring[i % RING];
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int r = 8 * p + drow_l;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
+      const u32x4 dv = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
+      const u32x4 v = (p & 1) ? u32x4{dv[2], dv[3], dv[0], dv[1]} : dv;       // rows with bit 3 set: halves stored swapped
       __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)));
     }
   }
