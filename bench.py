@@ -158,10 +158,19 @@ def main():
     if use_dist and not args.dp_host:
         ids = [SaeEngine.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        eng.dist_init(ids[0], rank, world)
-        if args.dp_payload == "bfloat16":
-            eng.dist_set_payload("bfloat16")
-    elif use_dist:
+        ok = 1
+        try:
+            eng.dist_init(ids[0], rank, world)
+            if args.dp_payload == "bfloat16":
+                eng.dist_set_payload("bfloat16")
+        except Exception as e:              # the engine's communicator could not be created here: say so and keep going
+            print(f"[rank {rank}] in-engine RCCL unavailable ({e}); falling back to the host-driven protocol", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if int(flag.item()) == 0:
+            args.dp_host = True
+    if use_dist and args.dp_host:
         eng.set_dp_world(world)
         grads = eng.grad_tensor()
         eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))

@@ -380,8 +380,16 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         if in_engine:
             ids = [eng.dist_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            eng.dist_init(ids[0], rank, world)
-        else:
+            ok = 1
+            try:
+                eng.dist_init(ids[0], rank, world)
+            except Exception as e:          # no communicator here: every rank falls back to the host-driven protocol together
+                print(f"[rank {rank}] in-engine RCCL unavailable ({e}); using torch.distributed for the exchange")
+                ok = 0
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            in_engine = int(flag.item()) == 1
+        if not in_engine:
             eng.set_dp_world(world)
             grads = eng.grad_tensor()
             overlap = hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
