@@ -149,6 +149,7 @@ struct sae_ctx {
   unsigned char* sel_flag = nullptr;    // [M_p] rows the tile-driven select left to the general kernel
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
   // AuxK on the compacted dead set (topk_aux.h)
+  float* be_r = nullptr;            // encoder bias rounded to bf16 (as float), refreshed every step
   bool aux_compact = false;
   int *tkd = nullptr, *dead_cols = nullptr, *vec_rank = nullptr;
   unsigned char* vec_bits = nullptr;
@@ -325,6 +326,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   // topk_dense_backward keeps the dense ddense GEMM (tests cover both)
   c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.topk_dense_backward != 1;
   TALLOC(c->dead, c->n_p);
+  TALLOC(c->be_r, (size_t)c->n_p * 4);
   c->multi = c->cfg.multi_topk != 0;
   c->k4 = 4 * c->k;
   if (c->multi) {
@@ -387,7 +389,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
-                  c->aux_dbe_part};
+                  c->aux_dbe_part, c->be_r};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
@@ -1167,8 +1169,9 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     GemmArgs g{};
     g.A0 = c->xs; g.B0 = c->We_b; g.lda = d_p; g.ldb = d_p;
     g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
+    hipLaunchKernelGGL(round_bias_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, be, c->be_r, n_p);
     EpiTopkEnc e{};
-    e.pre = c->pre; e.bias = be; e.M = M; e.n_p = n_p;
+    e.pre = c->pre; e.bias = c->be_r; e.M = M; e.n_p = n_p;
     e.tmax = tile_select ? c->tile_max : nullptr;
     ev_begin(c, KID_TK_ENC, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);

@@ -128,6 +128,18 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int base32, int kk,
   }
 }
 
+// apply() dispatch: a functor that keeps per-call state (EpiTopkEnc's row maxima) offers apply_it(it, ...) with the index of
+// the call within the tile -- a compile-time constant in the unrolled epilogue loops, so that state stays in registers.
+template <class Epi>
+__device__ __forceinline__ auto epi_apply(Epi& e, int it, int row, int col, f32x4 v, const typename Epi::Pre& p, int)
+    -> decltype(e.apply_it(it, row, col, v, p)) {
+  return e.apply_it(it, row, col, v, p);
+}
+template <class Epi>
+__device__ __forceinline__ void epi_apply(Epi& e, int, int row, int col, f32x4 v, const typename Epi::Pre& p, long) {
+  e.apply(row, col, v, p);
+}
+
 // Epi requirements:
 //   __device__ void tile_begin(int row0, int col0, int split);
 //   struct Pre;  __device__ Pre prefetch(int row, int col) const;      // the global loads of apply(), issued early
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
     for (int it = 0; it < 16; ++it) {
       const int row = (t >> 5) + 8 * it;
       const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * GEMM_EPI_PITCH + c4]);
-      epi.apply(bm * GEMM_BM + row, bn * GEMM_BN + c4, v, pre[it]);
+      epi_apply(epi, it, bm * GEMM_BM + row, bn * GEMM_BN + c4, v, pre[it], 0);
     }
   }
   __syncthreads();

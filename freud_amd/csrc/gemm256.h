@@ -76,7 +76,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int row = (tl >> 5) + 8 * it;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
-        epi.apply(row0 + row, col0 + c4, v, pre[it]);
+        epi_apply(epi, it, row0 + row, col0 + c4, v, pre[it], 0);
       }
     }
     __syncthreads();

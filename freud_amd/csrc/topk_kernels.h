@@ -91,37 +91,77 @@ __global__ __launch_bounds__(1024) void dead_mask_kernel(const long long* __rest
 }
 
 // encoder epilogue: pre = relu(bf16(acc + bias)) (Linear under autocast: bf16 addmm, one rounding), rows >= M zero
-// tmax != null: also the maximum of every (row, 128-column tile) -- the 32 lanes of an apply() call cover exactly one such
-// tile of one row -- for the tile-driven select (topk_select_tiles_kernel), which then reads only the tiles that can hold
-// one of the row's k largest values.
+// tmax != null: also the maximum of every (row, 128-column tile) for the tile-driven select (topk_select_tiles_kernel), which
+// then reads only the tiles that can hold one of the row's k largest values.
+// The arithmetic is done on PACKED bf16 pairs: v_cvt_pk_bf16_f32 rounds two sums at once, ReLU is a signed 16-bit max with 0
+// (negative floats are negative as int16), the maximum is an unsigned 16-bit max (values >= 0: the pattern orders like the
+// value) -- 12 vector instructions per 4 columns.  The per-row maximum over the 32 threads that share a row is NOT reduced
+// per call (five DPP steps + hazard nops each: that was 40 % of this epilogue, itself a third of the GEMM at K = 768): each
+// thread keeps its 16 row maxima and tile_end() reduces them through the (by then free) LDS tile, one row per thread.
 struct EpiTopkEnc {
   bf16_t* pre;          // [M_p][n_p]
-  const float* bias;    // [n_p] (fp32 master; rounded to bf16 as autocast casts it)
+  const float* bias;    // [n_p] fp32 master ALREADY ROUNDED to bf16 (round_bias_kernel: autocast casts it)
   int64_t M;
   int n_p;
-  unsigned short* tmax; // [M_p][n_p / 128] bf16 bit patterns (values are >= 0: the pattern orders like the value), or null
-  __device__ void tile_begin(int, int, int) {}
+  unsigned short* tmax; // [M_p][n_p / 128] bf16 bit patterns, or null
+  typedef __attribute__((ext_vector_type(2))) short s16x2;
+  typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  unsigned int rmax[16];
+  int row0_, col0_;
+  bool partial_;        // the tile holds rows >= M (block-uniform)
+  __device__ void tile_begin(int row0, int col0, int) {
+    row0_ = row0;
+    col0_ = col0;
+    partial_ = row0 + GEMM_BM > M;
+  }
   struct Pre { f32x4 b; };
   __device__ Pre prefetch(int, int col) const { return Pre{*reinterpret_cast<const f32x4*>(bias + col)}; }
-  __device__ void apply(int row, int col, f32x4 v, const Pre& pf) {
+  // `it` = index of the call within the tile (0..15), a compile-time constant at the call sites (epi_apply)
+  __device__ void apply_it(int it, int row, int col, f32x4 v, const Pre& pf) {
     const f32x4 b = pf.b;
-    bf16x4 o;
-    float m = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float p = fmaxf(bf16_round(v[j] + bf16_round(b[j])), 0.f);
-      if (row >= M) p = 0.f;
-      m = fmaxf(m, p);
-      o[j] = (bf16_t)p;
-    }
-    EPI_STORE(reinterpret_cast<bf16x4*>(pre + (int64_t)row * n_p + col), o);
+    const s16x2 zero = {0, 0};
+    s16x2 p0 = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v[0] + b[0], v[1] + b[1]}, bf16x2));
+    s16x2 p1 = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v[2] + b[2], v[3] + b[3]}, bf16x2));
+    p0 = __builtin_elementwise_max(p0, zero);
+    p1 = __builtin_elementwise_max(p1, zero);
+    if (partial_ && row >= M) p0 = p1 = zero;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    EPI_STORE(reinterpret_cast<u32x2*>(pre + (int64_t)row * n_p + col),
+              (u32x2{__builtin_bit_cast(unsigned int, p0), __builtin_bit_cast(unsigned int, p1)}));
     if (tmax) {
-      m = half_wave_max_hi(m);                            // the 32 lanes of this row's tile; complete in lanes 16-31
-      if ((threadIdx.x & 31) == 16) tmax[(int64_t)row * (n_p >> 7) + (col >> 7)] = (unsigned short)(__float_as_uint(m) >> 16);
+      const unsigned int mm = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(u16x2, p0), __builtin_bit_cast(u16x2, p1)));
+      rmax[it] = max(mm & 0xFFFFu, mm >> 16);
     }
   }
-  __device__ void tile_end(float*) {}
+  // scratch: the 128 x 132-float LDS tile of this 256-thread group, free once the apply() loop has read it
+  __device__ void tile_end(float* scratch) {
+    if (!tmax) return;                                  // (uniform over the launch)
+    constexpr int PITCH = 36;                           // 144-byte rows: the 16-byte row reads below are conflict-free
+    unsigned int* sc = reinterpret_cast<unsigned int*>(scratch);
+    const int t = threadIdx.x & 255;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) sc[((t >> 5) + 8 * it) * PITCH + (t & 31)] = rmax[it];
+    __syncthreads();
+    if (t < 128) {
+      const u32x4* r = reinterpret_cast<const u32x4*>(sc + t * PITCH);
+      unsigned int m = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const u32x4 w = r[q];
+        m = max(max(m, w[0]), max(max(w[1], w[2]), w[3]));
+      }
+      tmax[(int64_t)(row0_ + t) * (n_p >> 7) + (col0_ >> 7)] = (unsigned short)m;
+    }
+  }
 };
+
+// bias rounded to bf16 and kept as float (what the autocast addmm adds): once per step, n_p values
+__global__ __launch_bounds__(256) void round_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n_p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_p) out[i] = bf16_round(b[i]);
+}
 
 // ------------------------------------------------------------------------------------------
 // per-row top-k: one workgroup per row.  Values are non-negative bf16 (post-ReLU), so their 16-bit patterns
