@@ -2,8 +2,9 @@
 # rocprofv3 evidence for one round, run ON the GPU box from the repo root (gpurun -- bash tools/profile_round.sh r02):
 #   1. bench lines (un-profiled): default C2, forced data-parallel (in-engine RCCL fp32 / bf16 payload, host-driven),
 #      C3 (TopK), C4, C5 bf16 and fp8 shapes                                  -> gpurun_out/prof_<tag>/bench_*.json
-#   2. --kernel-trace --stats of the default bench (program directly after "--", default spin-up, 2000 timed steps so
-#      that the ~100 ramp launches of the spin-up are ~1 % of what the per-kernel averages cover) + the timed-region
+#   2. --kernel-trace --stats of the default bench (program directly after "--", a SHORT spin-up of 0.2 s and 3000 timed
+#      steps: the --stats averages cover every launch of the run, and the ~300 launches on ramping clocks of the spin-up
+#      must stay a small share of them for the CSV itself to agree with the HIP-event figure) + the timed-region
 #      timeline / averages from the trace (tools/trace_timeline.py)          -> stats/, timeline.txt
 #   3. short --kernel-trace --stats runs of the C3 / C4 / C5-fp8 shapes       -> stats_c3/, stats_c4/, stats_c5fp8/
 #   4. PMC passes of the default bench, each in its own run (never combined with traces): FETCH_SIZE, WRITE_SIZE, SQ
@@ -28,13 +29,14 @@ $B --no-cpu-baseline --d 1280 --n 81920 --steps 10 --warmup 2 --breakdown > "$OU
 $B --no-cpu-baseline --d 1280 --n 81920 --steps 10 --warmup 2 --precision fp8 > "$OUT/bench_c5_fp8.json" 2>> "$OUT/bench_c5.err"
 $B --no-cpu-baseline --n 12288 --steps 100 --warmup 10 > "$OUT/bench_d384_n12288.json" 2> "$OUT/bench_n12288.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $B --no-cpu-baseline --steps 2000 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-python3 $ROOT/tools/trace_timeline.py $(find "$OUT/stats" -name "*kernel_trace.csv" | head -1) 2000 > "$OUT/timeline.txt" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $B --no-cpu-baseline --steps 3000 --warmup 20 --spinup 0.2 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+python3 $ROOT/tools/trace_timeline.py $(find "$OUT/stats" -name "*kernel_trace.csv" | head -1) 3000 > "$OUT/timeline.txt" 2>&1
 rm -f $(find "$OUT/stats" -name "*kernel_trace.csv")        # 20 MB of per-dispatch rows; the summary above is what is kept
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_c3" -o stats --output-format csv -- $B --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 30 --warmup 5 --spinup 0.3 --dead-threshold 1e15 > "$OUT/bench_c3_under_rocprof.json" 2> "$OUT/stats_c3.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_c3auxk" -o stats --output-format csv -- $B --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 30 --warmup 5 --spinup 0.3 --dead-threshold 1e5 > "$OUT/bench_c3auxk_under_rocprof.json" 2> "$OUT/stats_c3auxk.log"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_c4" -o stats --output-format csv -- $B --no-cpu-baseline --d 1280 --n 40960 --steps 10 --warmup 2 --spinup 0.3 > "$OUT/bench_c4_under_rocprof.json" 2> "$OUT/stats_c4.log"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_c5fp8" -o stats --output-format csv -- $B --no-cpu-baseline --d 1280 --n 81920 --steps 6 --warmup 2 --spinup 0.3 --precision fp8 > "$OUT/bench_c5fp8_under_rocprof.json" 2> "$OUT/stats_c5fp8.log"
-for d in stats_c3 stats_c4 stats_c5fp8; do rm -f $(find "$OUT/$d" -name "*kernel_trace.csv"); done
+for d in stats_c3 stats_c3auxk stats_c4 stats_c5fp8; do rm -f $(find "$OUT/$d" -name "*kernel_trace.csv"); done
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o pmc --output-format csv -- $B --no-cpu-baseline --steps 5 --warmup 2 --spinup 0 > /dev/null 2> "$OUT/pmc_$c.log"
 done
