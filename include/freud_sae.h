@@ -65,9 +65,12 @@ typedef struct sae_config {
   double eps;             /* 1e-5 RAdam (train_sae.py:376), 1e-8 Adam (torch default)    */
   /* development / test switches (zero in production): */
   int32_t force_generic;  /* 1: generic GEMM path even where a fused d=384 kernel exists (tests cover both)          */
-  int32_t debug_flags;    /* kernel timing experiments of bench.py --dbg (results become wrong)                      */
+  int32_t debug_flags;    /* kernel timing experiments of bench.py --dbg (65, 66, 70: results become wrong) and A/B    */
+                          /* paths that stay correct: 75 = no tile-driven TopK select, 76 = AuxK through the gather   */
+                          /* kernels instead of the compacted dead-set GEMMs (tests compare both)                     */
   int32_t force_gemm128;  /* 1: 128x128 GEMM tiles even where the 256x256 kernel applies (A/B timing, tests)        */
-  int32_t topk_dense_backward; /* 1: TopK d pre-activations by the dense GEMM + mask instead of the sparse kernel   */
+  int32_t topk_dense_backward; /* TopK backward A/B (tests): 0 CSC sparse backward, 1 dense GEMMs + mask, 2 sparse d      */
+                          /* pre-activations + dense weight-gradient GEMMs                                            */
   /* model / numerics options: */
   int32_t multi_topk;     /* TopK only: cfg.multi_topk (topkautoencoder.py:134-140, loss term train_sae.py:442)     */
   int32_t precision;      /* SAE_PREC_*: operand type of the L1 encoder / decoder GEMMs                             */

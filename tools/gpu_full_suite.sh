@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=$PWD/gpurun_out/r02r
+O=$PWD/gpurun_out/full_suite
 mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest.txt 2>&1
 tail -6 $O/pytest.txt

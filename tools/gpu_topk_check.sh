@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=$PWD/gpurun_out/r02o
+O=$PWD/gpurun_out/topk_check
 mkdir -p $O
 timeout 1500 python -m pytest tests/test_topk_gpu.py -m gpu -q -x -p no:cacheprovider > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt
