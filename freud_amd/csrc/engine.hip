@@ -1259,7 +1259,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
                      c->tk, c->tkf, metrics, (float)n, gs, c->dp_world);
   ev_end(c, KID_TK_DECODE, s);
   if (backward) {
-    const int rpb = 256;
+    const int rpb = 128;
     const int nrb = (int)((Mp + rpb - 1) / rpb);
     hipLaunchKernelGGL(topk_de_kernel, dim3((d_p + 255) / 256, nrb), dim3(256), 0, s, c->e, c->dh, c->tkf, c->de_b, c->dh_b,
                        c->dbd_part, Mp, d_p, rpb, aux ? 1 : 0, c->tk, c->multi ? c->em : (const float*)nullptr, c->dm_b);

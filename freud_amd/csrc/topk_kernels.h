@@ -381,18 +381,25 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
   // ---- load + candidate filter.  keys[v][q] packs columns 8 g + 2 q (low half) and 8 g + 2 q + 1 (high half)
   u32x4 keys[MAXV];
   unsigned cand[MAXV];                             // 8 candidate bits per vector
+  unsigned cbits[MAXV];
+  if (COMPACT) {                                       // the dead bits of each vector's 8 columns, one byte (dead implies col < n)
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) cbits[v] = (v * 256 + t < nvec) ? (unsigned)vec_bits[v * 256 + t] : 0u;
+  }
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int g = v * 256 + t;
     u32x4 w = {0u, 0u, 0u, 0u};
     unsigned cb = 0;
     if (g < nvec) {
-      w = __builtin_nontemporal_load(src + g);     // read exactly once (3.2 GB at C3): keep it out of the caches' way
+      // read exactly once (3.2 GB at C3): keep it out of the caches' way.  COMPACT: vectors without a dead column are not
+      // read at all (with few dead latents that is most of the row)
+      if (!COMPACT || cbits[v] != 0u) w = __builtin_nontemporal_load(src + g);
       if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
         cb = 0xFFu;
       } else {
-        if (COMPACT) {                                 // the dead bits of the vector's 8 columns, one byte (dead implies col < n)
-          cb = vec_bits[g];
+        if (COMPACT) {
+          cb = cbits[v];
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
