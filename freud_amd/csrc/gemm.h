@@ -14,6 +14,8 @@
 // tiles, 64 accumulator registers); two LDS stages of 32 KiB; register-staged global loads issued one
 // K-tile ahead (loads for tile t+1 are in flight while tile t is multiplied).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 enum { OP_ROW = 0, OP_KMAJOR = 1 };
@@ -140,6 +142,15 @@ __device__ __forceinline__ void epi_apply(Epi& e, int, int row, int col, f32x4 v
   e.apply(row, col, v, p);
 }
 
+// How many of a thread's 16 (row, 4-column) elements of a tile have their global loads in flight at once: all 16 unless the
+// functor says otherwise (static constexpr int PREFETCH_BATCH).  In the 256x256 kernel half of the waves still hold their
+// 128 accumulator registers while the first two sub-tiles are processed, so a functor with a large `Pre` (16 x 4-8
+// registers) spilled 30-70 registers to scratch right there.
+template <class E, class = void>
+struct epi_prefetch_batch { static constexpr int value = 16; };
+template <class E>
+struct epi_prefetch_batch<E, std::void_t<decltype(E::PREFETCH_BATCH)>> { static constexpr int value = E::PREFETCH_BATCH; };
+
 // Epi requirements:
 //   __device__ void tile_begin(int row0, int col0, int split);
 //   struct Pre;  __device__ Pre prefetch(int row, int col) const;      // the global loads of apply(), issued early
@@ -252,14 +263,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   epi.tile_begin(bm * GEMM_BM, bn * GEMM_BN, split);
   {
     const int c4 = (t & 31) * 4;
-    typename Epi::Pre pre[16];
+    constexpr int NB = epi_prefetch_batch<Epi>::value;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(bm * GEMM_BM + (t >> 5) + 8 * it, bn * GEMM_BN + c4);
+    for (int b0 = 0; b0 < 16; b0 += NB) {
+      typename Epi::Pre pre[NB];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = (t >> 5) + 8 * it;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * GEMM_EPI_PITCH + c4]);
-      epi_apply(epi, it, bm * GEMM_BM + row, bn * GEMM_BN + c4, v, pre[it], 0);
+      for (int it = 0; it < NB; ++it) pre[it] = epi.prefetch(bm * GEMM_BM + (t >> 5) + 8 * (b0 + it), bn * GEMM_BN + c4);
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        const int row = (t >> 5) + 8 * (b0 + it);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[row * GEMM_EPI_PITCH + c4]);
+        epi_apply(epi, b0 + it, bm * GEMM_BM + row, bn * GEMM_BN + c4, v, pre[it], 0);
+      }
     }
   }
   __syncthreads();

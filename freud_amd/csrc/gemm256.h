@@ -69,14 +69,18 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
     epi.tile_begin(row0, col0, split);
     {
       const int c4 = (tl & 31) * 4;
-      typename Epi::Pre pre[16];
+      constexpr int NB = epi_prefetch_batch<Epi>::value;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * it, col0 + c4);
+      for (int b0 = 0; b0 < 16; b0 += NB) {
+        typename Epi::Pre pre[NB];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = (tl >> 5) + 8 * it;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
-        epi_apply(epi, it, row0 + row, col0 + c4, v, pre[it], 0);
+        for (int it = 0; it < NB; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * (b0 + it), col0 + c4);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const int row = (tl >> 5) + 8 * (b0 + it);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&src[row * GEMM_EPI_PITCH + c4]);
+          epi_apply(epi, b0 + it, row0 + row, col0 + c4, v, pre[it], 0);
+        }
       }
     }
     __syncthreads();

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
 // Store of a large output that is next read only after it has left every cache (the [M x n] latent / pre / dpre
 // streams): non-temporal, so that it does not evict the operand tiles the co-resident workgroups share (same-box A/B at
 // d=1280 n=40960: encoder GEMM 7.1 -> 6.4 ms, dpre 7.85 -> 7.55; TopK encoder at d=768 3.03 -> 2.55 ms)
+#ifndef EPI_BATCH_HEAVY
+#define EPI_BATCH_HEAVY 8      // prefetch batch of the functors with a large Pre (gemm.h: epi_prefetch_batch)
+#endif
 #define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 // ... and the matching read of such a stream inside an epilogue (dpre GEMM reading the latent: 7.6 -> 7.1 ms)
 #define EPI_LOAD(ptr) __builtin_nontemporal_load(ptr)
@@ -185,6 +188,7 @@ struct EpiEnc {
 // (l1autoencoder.py:84,86,29-36 and its backward).  Partial sums: masked sq-err, unmasked sq-err.
 template <typename T>
 struct EpiDec {
+  static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const T* x;           // original activations [M][d]
   bf16_t* dxh;          // [M_p][d_p]
   const float* scal;    // scal[1] = alpha / count
@@ -237,6 +241,7 @@ struct EpiDec {
 
 // dpre = (bf16(dx_hat W) + sign(c)/M) * [c > 0]; db partial column sums per row-tile.
 struct EpiDpre {
+  static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const bf16_t* c;      // [M_p][n_p]
   bf16_t* dpre;         // [M_p][n_p]
   float* db_part;       // [nbm][n_p]

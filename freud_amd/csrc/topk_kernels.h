@@ -536,7 +536,46 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
       const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
       const int C = c0 + c1 + c2 + c3;
       const bool fits = c0 <= TOPK_SEG_CAP && c1 <= TOPK_SEG_CAP && c2 <= TOPK_SEG_CAP && c3 <= TOPK_SEG_CAP;
-      if (fits) {                                      // block-uniform; C >= k by construction
+      if (fits && COMPACT) {
+        // The compact row needs MEMBERSHIP only (a selected value goes to the rank of its column among the dead ones, not to
+        // the rank of its value): the k-th largest packed candidate by binary search on the 32-bit word -- ballots per wave,
+        // one LDS exchange and ONE barrier per probe (double-buffered counters) -- instead of C comparisons per candidate
+        // (that ranking was 60 % of this kernel's instructions at k_aux = 384, C ~ 450).  The packed words are distinct
+        // (they carry the column), so the probe that counts exactly k ends the search.
+        __shared__ int bs_cnt[2][4];
+        unsigned int mine[4] = {0u, 0u, 0u, 0u};           // C <= 4 * TOPK_SEG_CAP = 1024: at most 4 candidates per thread
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = t + 256 * u;
+          if (i < C) {
+            const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
+            const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
+            mine[u] = cand_pk[sg * TOPK_SEG_CAP + li];
+          }
+        }
+        unsigned int lo = 1u, hi = 0xFFFFFFFFu;             // largest T with #(candidates >= T) >= k; C >= k, candidates > 0
+        int probe = 0;
+        while (lo < hi) {
+          const unsigned int mid = lo + ((hi - lo) >> 1) + 1u;
+          int cw = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cw += (int)__popcll(__ballot(mine[u] >= mid));
+          if (lane == 0) bs_cnt[probe & 1][wv] = cw;
+          __syncthreads();
+          const int cnt = bs_cnt[probe & 1][0] + bs_cnt[probe & 1][1] + bs_cnt[probe & 1][2] + bs_cnt[probe & 1][3];
+          ++probe;
+          if (cnt >= k) {
+            lo = mid;
+            if (cnt == k) break;
+          } else {
+            hi = mid - 1u;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (mine[u] >= lo && mine[u] != 0u) crow[cpos((int)(0x1FFFFu - (mine[u] & 0x1FFFFu)))] = (unsigned short)(mine[u] >> 17);
+        done = true;
+      } else if (fits) {                               // block-uniform; C >= k by construction
         for (int i = t; i < C; i += 256) {
           // candidate i of the concatenated segments
           const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
@@ -1098,6 +1137,7 @@ __global__ __launch_bounds__(256) void topk_dbe_from_fx_kernel(const long long* 
 
 // ddense epilogue: dpre = [selected] * bf16(de . W_dec^T) (+ aux part), gated by pre > 0; column sums -> d b_enc
 struct EpiTopkDpre {
+  static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const bf16_t* sel;    // masked dense activations of this pass (selection mask = value > 0)
   bf16_t* dpre;         // [M_p][n_p]
   float* dbe_part;      // [nbm][n_p] (only written when `last`)
