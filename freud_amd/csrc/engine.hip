@@ -828,11 +828,12 @@ template <int AM, int BM_, class Epi>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   if (!g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0) {   // both output dimensions are multiples of 256
     auto kern256 = gemm256_bf16_kernel<AM, BM_, Epi>;
-    LDS_ATTR(kern256, G2_LDS_BYTES, g_device);
+    constexpr int lds256 = (epi_rounds_first<Epi>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES) ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
+    LDS_ATTR(kern256, lds256, g_device);
     GemmArgs g2 = g;
     g2.nbm = g.nbm / 2;
     g2.nbn = g.nbn / 2;
-    hipLaunchKernelGGL(kern256, dim3(g2.nbm * g2.nbn * g2.splits), dim3(512), G2_LDS_BYTES, s, g2, epi);
+    hipLaunchKernelGGL(kern256, dim3(g2.nbm * g2.nbn * g2.splits), dim3(512), lds256, s, g2, epi);
     HIP_TRY(hipGetLastError());
     return SAE_OK;
   }

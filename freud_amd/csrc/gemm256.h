@@ -89,6 +89,67 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
   }
 }
 
+// Epilogue for functors whose first act on an accumulator is its rounding to bf16 (static constexpr bool
+// ROUNDS_BF16_FIRST: the bf16-autocast GEMM outputs -- c, x_hat, dc, d acts): the WHOLE 256x256 tile goes to LDS as bf16
+// (pitch 264 elements: 135 168 bytes) in one step, so no wave sits on its 128 accumulator registers while others are
+// served (that cost the functors with global loads 30-70 spilled registers or a shallower prefetch), the fp32 round trip
+// through LDS is halved, and a tile needs 3 barriers less.  The functor still receives fp32 values (exactly the rounded
+// ones) and works on 128x128 sub-tiles: half h of the workgroup takes rows 128 h.., first the columns 0..127, then 128..255.
+constexpr int G2_BF16_PITCH = 264;
+constexpr int G2_BF16_TILE_BYTES = 256 * G2_BF16_PITCH * 2;            // 135 168
+constexpr int G2_BF16_SCRATCH_FLOATS = 1024;                           // per 256-thread half, for tile_end()
+constexpr int G2_BF16_LDS_BYTES = G2_BF16_TILE_BYTES + 2 * G2_BF16_SCRATCH_FLOATS * 4;
+
+template <class E, class = void>
+struct epi_rounds_first { static constexpr bool value = false; };
+template <class E>
+struct epi_rounds_first<E, std::void_t<decltype(E::ROUNDS_BF16_FIRST)>> { static constexpr bool value = E::ROUNDS_BF16_FIRST; };
+
+template <class Epi>
+__device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+  {
+    const int h = lane >> 5, c = lane & 31;
+    bf16_t* dst = tile + (128 * wm + 4 * h) * G2_BF16_PITCH + 64 * wn + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[(32 * i + (r & 3) + 8 * (r >> 2)) * G2_BF16_PITCH + 32 * j] = (bf16_t)acc[i][j][r];
+  }
+  __syncthreads();
+  const int half = t >> 8, tl = t & 255;
+  float* scratch = reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + half * G2_BF16_SCRATCH_FLOATS;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
+    const bf16_t* src = tile + (128 * half) * G2_BF16_PITCH + 128 * pass;
+    epi.tile_begin(row0, col0, split);
+    {
+      const int c4 = (tl & 31) * 4;
+      constexpr int NB = epi_prefetch_batch<Epi>::value;
+#pragma unroll
+      for (int b0 = 0; b0 < 16; b0 += NB) {
+        typename Epi::Pre pre[NB];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * (b0 + it), col0 + c4);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const int row = (tl >> 5) + 8 * (b0 + it);
+          const bf16x4 q = *reinterpret_cast<const bf16x4*>(&src[row * G2_BF16_PITCH + c4]);
+          const f32x4 v = {(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+          epi_apply(epi, b0 + it, row0 + row, col0 + c4, v, pre[it], 0);
+        }
+      }
+    }
+    epi.tile_end(scratch);
+    __syncthreads();        // scratch is free again (and, after the second pass, the tile)
+  }
+}
+
 // g.nbm / g.nbn count 256-wide tiles here.
 template <int AMODE, int BMODE, class Epi>
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
@@ -220,5 +281,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
   __syncthreads();
 
-  g2_epilogue(acc, smem, bm, bn, split, epi);
+  if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16(acc, smem, bm, bn, split, epi);
+  else g2_epilogue(acc, smem, bm, bn, split, epi);
 }

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
 // ------------------------------------------------------------------------------------------
 // c = relu(bf16(x W) + b)  (l1autoencoder.py:74), rows >= M forced to 0; L1 partial sum per tile.
 struct EpiEnc {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256.h: the tile goes through LDS as bf16
   bf16_t* c;            // [M_p][n_p]
   const float* bias;    // [n_p]
   float* l1_part;       // [tiles]
@@ -189,6 +190,7 @@ struct EpiEnc {
 template <typename T>
 struct EpiDec {
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // consulted by the bf16 kernel only, where vs == 1 (the fp8 kernel scales first)
   const T* x;           // original activations [M][d]
   bf16_t* dxh;          // [M_p][d_p]
   const float* scal;    // scal[1] = alpha / count
@@ -241,6 +243,7 @@ struct EpiDec {
 
 // dpre = (bf16(dx_hat W) + sign(c)/M) * [c > 0]; db partial column sums per row-tile.
 struct EpiDpre {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256.h: the tile goes through LDS as bf16
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const bf16_t* c;      // [M_p][n_p]
   bf16_t* dpre;         // [M_p][n_p]

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void aux_gather_rows_kernel(const bf16_t* __re
 // AuxK decode epilogue: e_hat = bf16(acc) + b_dec; dh = e_hat - e (the aux decode predicts the main residual); sum of
 // squares per 128x128 tile -> part[tile] (the caller zero-fills part[0 .. M_p) first; topk_finalize_kernel sums all of it).
 struct EpiAuxDecode {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256.h: the tile goes through LDS as bf16
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const float* e;       // [M_p][d_p]
   const float* b_dec;   // [d_p]

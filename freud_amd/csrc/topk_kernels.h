@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(256) void topk_dbe_from_fx_kernel(const long long* 
 
 // ddense epilogue: dpre = [selected] * bf16(de . W_dec^T) (+ aux part), gated by pre > 0; column sums -> d b_enc
 struct EpiTopkDpre {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256.h: the tile goes through LDS as bf16
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const bf16_t* sel;    // masked dense activations of this pass (selection mask = value > 0)
   bf16_t* dpre;         // [M_p][n_p]
