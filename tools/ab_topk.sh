@@ -3,7 +3,7 @@
 for i in 1 2; do
   for lib in "" "$@"; do
     echo -n "${lib:-current} "
-    FREUD_SAE_LIB=$lib python bench.py --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 30 --warmup 5 --dead-threshold 1e5 --breakdown 2>/dev/null | python -c "
+    FREUD_SAE_LIB=$lib python bench.py --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 30 --warmup 5 --dead-threshold ${DT:-1e5} --breakdown 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); km=d['kernel_ms']
 print(round(d['ms_per_step'],3), {k:round(v,3) for k,v in km.items() if v and k.startswith('topk')})"
