@@ -179,6 +179,9 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
   }
 }
 
+#ifndef SB_E
+#define SB_E 4          // entries in flight per wave and trip of sparse_bwd_kernel (even)
+#endif
 // ---- 5. gradient work items -----------------------------------------------------------------------------------------------
 // item -> (latent j = item_latent[item], chunk item - item_start[j]); partial sums to part[item][2][d_p] and pbe[item].
 template <int NPAIR>
@@ -210,43 +213,60 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const 
     }
   }
   float dbe = 0.f;
-  // two entries in flight; the NEXT pair's (row, activation) words are requested one trip ahead, so that a trip's gathers do
-  // not start behind another dependent load (the kernel waits on memory 83 % of its wave time)
-  CscEntry na = entries[e0 < e1 ? e0 : 0], nb = entries[e0 + 1 < e1 ? e0 + 1 : (e0 < e1 ? e0 : 0)];
-  for (unsigned int e = e0; e < e1; e += 2) {
-    const bool two = e + 1 < e1;
-    const CscEntry ea = na, eb = nb;
-    if (e + 2 < e1) {
-      na = entries[e + 2];
-      nb = entries[e + 3 < e1 ? e + 3 : e + 2];
+  // SB_E entries in flight per trip; the NEXT trip's (row, activation) words are requested one trip ahead, so that a trip's
+  // gathers do not start behind another dependent load (the kernel waits on memory 83 % of its wave time)
+  constexpr int E = SB_E;
+  CscEntry nx[E];
+#pragma unroll
+  for (int u = 0; u < E; ++u) nx[u] = entries[e0 + u < e1 ? e0 + u : (e0 < e1 ? e1 - 1 : 0)];
+  for (unsigned int e = e0; e < e1; e += E) {
+    CscEntry en[E];
+    float act[E];
+    unsigned ug[E][NPAIR], ux[E][NPAIR];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      en[u] = nx[u];
+      act[u] = e + u < e1 ? en[u].act : 0.f;            // entries past the end repeat the last one with weight 0
     }
-    const int64_t ma = ea.row_pass & 0x3FFFFFFFu, mb = eb.row_pass & 0x3FFFFFFFu;
-    const unsigned* ga = reinterpret_cast<const unsigned*>(ps.g[ea.row_pass >> 30] + ma * d_p + c0);
-    const unsigned* gb = reinterpret_cast<const unsigned*>(ps.g[eb.row_pass >> 30] + mb * d_p + c0);
-    const unsigned* xa = reinterpret_cast<const unsigned*>(xs + ma * d_p + c0);
-    const unsigned* xb = reinterpret_cast<const unsigned*>(xs + mb * d_p + c0);
-    unsigned ua[NPAIR], ub[NPAIR], va[NPAIR], vb[NPAIR];
+    if (e + E < e1) {
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) { ua[p] = ga[p]; ub[p] = gb[p]; }
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) { va[p] = xa[p]; vb[p] = xb[p]; }
-    float sa = 0.f, sb = 0.f;
-#pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-      sa += __uint_as_float(ua[p] << 16) * wd[2 * p] + __uint_as_float(ua[p] & 0xFFFF0000u) * wd[2 * p + 1];
-      sb += __uint_as_float(ub[p] << 16) * wd[2 * p] + __uint_as_float(ub[p] & 0xFFFF0000u) * wd[2 * p + 1];
+      for (int u = 0; u < E; ++u) nx[u] = entries[e + E + u < e1 ? e + E + u : e1 - 1];
     }
-    sa = wave_sum(sa);
-    sb = wave_sum(sb);
-    const float aa = ea.act, ab = two ? eb.act : 0.f;
-    const float da = aa > 0.f ? bf16_round(sa) : 0.f, db = ab > 0.f ? bf16_round(sb) : 0.f;    // ReLU gate
-    dbe += da + db;
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) {
-      accd[2 * p] += aa * __uint_as_float(ua[p] << 16) + ab * __uint_as_float(ub[p] << 16);
-      accd[2 * p + 1] += aa * __uint_as_float(ua[p] & 0xFFFF0000u) + ab * __uint_as_float(ub[p] & 0xFFFF0000u);
-      acce[2 * p] += da * __uint_as_float(va[p] << 16) + db * __uint_as_float(vb[p] << 16);
-      acce[2 * p + 1] += da * __uint_as_float(va[p] & 0xFFFF0000u) + db * __uint_as_float(vb[p] & 0xFFFF0000u);
+    for (int u = 0; u < E; ++u) {
+      const int64_t m = en[u].row_pass & 0x3FFFFFFFu;
+      const unsigned* gp = reinterpret_cast<const unsigned*>(ps.g[en[u].row_pass >> 30] + m * d_p + c0);
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) ug[u][p] = gp[p];
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int64_t m = en[u].row_pass & 0x3FFFFFFFu;
+      const unsigned* xp = reinterpret_cast<const unsigned*>(xs + m * d_p + c0);
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) ux[u][p] = xp[p];
+    }
+    float da[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p)
+        sdot += __uint_as_float(ug[u][p] << 16) * wd[2 * p] + __uint_as_float(ug[u][p] & 0xFFFF0000u) * wd[2 * p + 1];
+      sdot = wave_sum(sdot);
+      da[u] = act[u] > 0.f ? bf16_round(sdot) : 0.f;      // ReLU gate
+    }
+    // (the sums below keep the two-entries-per-trip association of the first version of this kernel: (a + b), then (c + d))
+#pragma unroll
+    for (int u = 0; u < E; u += 2) {
+      dbe += da[u] + da[u + 1];
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        accd[2 * p] += act[u] * __uint_as_float(ug[u][p] << 16) + act[u + 1] * __uint_as_float(ug[u + 1][p] << 16);
+        accd[2 * p + 1] += act[u] * __uint_as_float(ug[u][p] & 0xFFFF0000u) + act[u + 1] * __uint_as_float(ug[u + 1][p] & 0xFFFF0000u);
+        acce[2 * p] += da[u] * __uint_as_float(ux[u][p] << 16) + da[u + 1] * __uint_as_float(ux[u + 1][p] << 16);
+        acce[2 * p + 1] += da[u] * __uint_as_float(ux[u][p] & 0xFFFF0000u) + da[u + 1] * __uint_as_float(ux[u + 1][p] & 0xFFFF0000u);
+      }
     }
   }
   if (item_start[j + 1] - item_start[j] == 1) {     // the latent's only work item: these ARE its gradient rows
