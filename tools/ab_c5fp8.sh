@@ -1,0 +1,11 @@
+#!/bin/bash
+# same-box A/B of the C5 shape with fp8 encoder / decoder GEMMs
+for i in 1 2; do
+  for lib in "" "$@"; do
+    echo -n "${lib:-current} "
+    FREUD_SAE_LIB=$lib python bench.py --no-cpu-baseline --d 1280 --n 81920 --steps 6 --warmup 2 --precision fp8 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); km=d['kernel_ms']
+print(round(d['ms_per_step'],3), {k:round(v,3) for k,v in km.items() if v and v > 1})"
+  done
+done
