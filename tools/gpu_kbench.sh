@@ -1,9 +1,9 @@
 #!/bin/bash
-build/kbench/gemm_m32 512 512 256 3
-build/kbench/gemm_m32 4096 4096 1280 3
-for v in m32 m32_NOGLOAD m32_NOSTAGE; do
+# 8-wave 256x256 GEMM: committed K loop against the variants named in KB_VARIANTS (build/kbench/gemm_<name>)
+for v in bench ${KB_VARIANTS:-stagger}; do
   echo "== $v"
-  build/kbench/gemm_$v 65536 40960 1280 2
-  build/kbench/gemm_$v 65536 1280 40960 2
+  build/kbench/gemm_$v 65536 40960 1280 0
+  build/kbench/gemm_$v 65536 1280 40960 0
+  build/kbench/gemm_$v 65536 24576 768 0
+  build/kbench/gemm_$v 1280 40960 131072 1 8
 done
-build/kbench/gemm_m32 65536 24576 768 2
