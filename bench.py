@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--dead-threshold", type=float, default=1e6,
                     help="TopK dead_feature_threshold in frames (configs use 1e6: AuxK switches on after ~16 steps of 65536 "
                          "rows once latents stay silent; 1e15 keeps AuxK off)")
+    ap.add_argument("--dead-latents", type=int, default=0,
+                    help="TopK: start with this many latents marked dead (counters far beyond --dead-threshold), e.g. with "
+                         "--dead-threshold 1e15 to time the AuxK branch at a chosen number of dead latents")
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
     ap.add_argument("--dp-payload", default="float32", choices=["float32", "bfloat16"],
                     help="gradient payload of the in-engine all-reduce (bfloat16: fused d=384 path only, half the bytes)")
@@ -146,6 +149,10 @@ def main():
         Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
         eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
                         "b_dec": np.zeros(d, np.float32)})
+        if args.dead_latents > 0:
+            nf = np.zeros(n, np.int64)
+            nf[np.random.default_rng(0).permutation(n)[:args.dead_latents]] = np.int64(4e18)
+            eng.set_topk_state(nf)
     else:
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
                         clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128,

@@ -150,6 +150,7 @@ struct sae_ctx {
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
   // AuxK on the compacted dead set (topk_aux.h)
   float* be_r = nullptr;            // encoder bias rounded to bf16 (as float), refreshed every step
+  int slab_splits = 1;              // slabs allocated in c->slab (TopK)
   bool aux_compact = false;
   int *tkd = nullptr, *dead_cols = nullptr, *vec_rank = nullptr;
   unsigned char* vec_bits = nullptr;
@@ -365,7 +366,10 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
     HIP_TRY(hipMemset(c->tkd, 0, 64));
   }
   // the multi-TopK weight gradient is a second GEMM launch into its own split-K slabs
-  TALLOC(c->slab, (int64_t)(splits > 1 ? splits : 1) * (c->multi ? 2 : 1) * c->nW * 4);
+  // (the AuxK weight-gradient GEMMs over a SMALL dead set split K up to 32 times to fill the chip: slabs [split][n_p][d_p])
+  c->slab_splits = (splits > 1 ? splits : 1) * (c->multi ? 2 : 1);
+  if (c->aux_compact && c->slab_splits < 32) c->slab_splits = 32;
+  TALLOC(c->slab, (int64_t)c->slab_splits * c->nW * 4);
   TALLOC(c->gn_part, 1024 * 8);
 #undef TALLOC
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
@@ -833,7 +837,15 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     GemmArgs g2 = g;
     g2.nbm = g.nbm / 2;
     g2.nbn = g.nbn / 2;
-    hipLaunchKernelGGL(kern256, dim3(g2.nbm * g2.nbn * g2.splits), dim3(512), lds256, s, g2, epi);
+    const int grid_max = g2.nbm * g2.nbn * g2.splits;
+    const int grid_est = (((g.grid_hint + 3) / 4 + 7) / 8) * 8;          // 256x256 tiles, a multiple of 8
+    if (g.dyn && g.grid_hint > 0 && grid_est * 2 < grid_max) {
+      auto kernp = gemm256_bf16_kernel<AM, BM_, Epi, true>;
+      LDS_ATTR(kernp, lds256, g_device);
+      hipLaunchKernelGGL(kernp, dim3(grid_est < 256 ? 256 : grid_est), dim3(512), lds256, s, g2, epi);
+    } else {
+      hipLaunchKernelGGL(kern256, dim3(grid_max), dim3(512), lds256, s, g2, epi);
+    }
     HIP_TRY(hipGetLastError());
     return SAE_OK;
   }
@@ -1211,11 +1223,11 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (n_p <= 2048 * 12)
         hipLaunchKernelGGL((topk_select_reg_kernel<12, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
                            c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
-                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd);
+                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd, c->dead_cols);
       else
         hipLaunchKernelGGL((topk_select_reg_kernel<44, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
                            c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
-                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd);
+                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd, c->dead_cols);
     } else if (aux) {
       launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
     }
@@ -1301,11 +1313,17 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (auxc) {
         // ---- AuxK backward over the compact dead set (every launch covers the static maximum and gates itself on the device)
         ev_begin(c, KID_TK_AUX, s);
+        // launch sizes from the STALE dead count (pinned copy of an earlier step, never waited for) plus a margin: only an
+        // estimate is needed (GemmArgs::grid_hint), the kernels cover whatever the real extent is
+        const int nd_hint = c->dead_hint[0];
+        int ndp_hint = (nd_hint + nd_hint / 4 + 511) & ~255;
+        if (ndp_hint > n_p) ndp_hint = n_p;
         {   // d A = [selected, > 0] bf16(d e_hat W_dec[dead]^T), column sums
           GemmArgs g{};
           g.A0 = c->dh_b; g.B0 = c->Wdd_b; g.lda = d_p; g.ldb = d_p;
           g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
           g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_N;
+          g.grid_hint = (int)((Mp / 128) * (ndp_hint / 128));
           EpiTopkDpre e{};
           e.sel = c->aux_dense; e.dpre = c->dpre; e.dbe_part = c->aux_dbe_part; e.n_p = n_p; e.accumulate = 0; e.last = 1;
           rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
@@ -1315,8 +1333,18 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           GemmArgs g{};
           g.A0 = which == 0 ? c->aux_dense : c->dpre; g.B0 = which == 0 ? c->dh_b : c->xs; g.lda = n_p; g.ldb = d_p;
           g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
-          g.splits = c->dw_splits > g.ktiles ? g.ktiles : c->dw_splits;
+          // split-K from the ESTIMATED extent: a few hundred dead latents are a handful of output tiles, and K = M is long --
+          // aim at two workgroups per CU, at least 8 K tiles per split, at most what the slab buffer holds
+          {
+            const int64_t tiles_est = (int64_t)(ndp_hint / 256 > 0 ? ndp_hint / 256 : 1) * ((d_p + 255) / 256);
+            int sp = (int)((512 + tiles_est - 1) / tiles_est);
+            if (sp < c->dw_splits) sp = c->dw_splits;
+            if (sp > c->slab_splits) sp = c->slab_splits;
+            if (sp > g.ktiles / 8) sp = g.ktiles / 8 > 0 ? g.ktiles / 8 : 1;
+            g.splits = sp;
+          }
           g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_M;
+          g.grid_hint = (ndp_hint / 128) * (d_p / 128) * g.splits;
           EpiSlab e{};
           e.slab = c->slab; e.slab_stride = c->nW; e.ld = d_p;
           rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);

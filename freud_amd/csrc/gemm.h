@@ -37,6 +37,8 @@ struct GemmArgs {
   // segment).  The launch covers the static maximum; workgroups beyond the dynamic extent exit at once (count 0: all).
   const int* dyn;
   int dyn_dim;
+  int grid_hint;         // dyn launches of the 256x256 kernel: an ESTIMATE of the 128x128 tiles of the dynamic extent (0 = none).
+                         // Well below the static maximum it selects the PERSIST instantiation with a grid of that size.
 };
 enum { GEMM_DYN_NONE = 0, GEMM_DYN_M = 1, GEMM_DYN_N = 2, GEMM_DYN_K = 3 };
 

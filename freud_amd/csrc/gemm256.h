@@ -150,16 +150,13 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
   }
 }
 
-// g.nbm / g.nbn count 256-wide tiles here.
+// One 256x256 output tile (workgroup-level id `blk` of nblk).  g.nbm / g.nbn count 256-wide tiles here.
 template <int AMODE, int BMODE, class Epi>
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* smem, int blk, int nbm, int nbn, int ktiles0,
+                                             int ktiles) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
-
-  int nbm, nbn, ktiles0, ktiles;
-  if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles)) return;
   const int nblk = nbm * nbn * g.splits;
-  int id = xcd_remap(blockIdx.x, nblk);
+  int id = xcd_remap(blk, nblk);
   const int split = id / (nbm * nbn);
   id -= split * (nbm * nbn);
   int bm, bn;
@@ -282,5 +279,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   __syncthreads();
 
   if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16(acc, smem, bm, bn, split, epi);
-  else g2_epilogue(acc, smem, bm, bn, split, epi);
+  else g2_epilogue(acc, smem, bm, bn, split, epi);      // (both end with a barrier: LDS is free again)
+}
+
+// PERSIST = false: one tile per workgroup (grid = the static tile count; with GemmArgs::dyn the workgroups beyond the
+// dynamic extent exit at once).  PERSIST = true (dyn launches sized by a host-side ESTIMATE of the extent, e.g. the AuxK
+// GEMMs while few latents are dead: thousands of workgroups that start only to exit cost ~0.3 ms per launch, each needs a
+// CU's whole LDS before it can do so): a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... -- correct for
+// any grid size (gridDim.x a multiple of 8 keeps a workgroup's tiles on its XCD under xcd_remap).  Kept a separate
+// instantiation: the tile loop costs the K loop ~10 % (register allocation across the back edge).
+template <int AMODE, int BMODE, class Epi, bool PERSIST = false>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int nbm, nbn, ktiles0, ktiles;
+  if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles)) return;
+  if constexpr (PERSIST) {
+    const int nblk = nbm * nbn * g.splits;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles);
+  } else {
+    gemm256_tile<AMODE, BMODE>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles);
+  }
 }

@@ -340,8 +340,29 @@ __device__ __forceinline__ void topk_pad_segment(unsigned int* seg, int wcount, 
   if (lane < 8 && wcount + lane < SEGSZ) seg[wcount + lane] = 0u;
 }
 
+// block-wide number of 16-bit keys >= T (T in 1..0x8000) among the threads' packed key vectors
+template <int MAXV>
+__device__ __forceinline__ int topk_count_ge(const u32x4 (&keys)[MAXV], unsigned T, int t, int* red) {
+  const unsigned tp = T * 0x00010001u;
+  unsigned c2 = 0;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c2 += (((keys[v][q] | 0x80008000u) - tp) >> 15) & 0x00010001u;
+  int c = (int)((c2 & 0xFFFFu) + (c2 >> 16));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  __syncthreads();
+  if ((t & 63) == 0) red[t >> 6] = c;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+#ifndef SEL_OCC
+#define SEL_OCC 4        // waves per SIMD the compact AuxK select is compiled for
+#endif
 template <int MAXV, bool COMPACT = false>
-__global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
+__global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,
@@ -349,7 +370,8 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
                                                                int write_dense, const unsigned char* __restrict__ only_flagged = nullptr,
                                                                const int* __restrict__ vec_rank = nullptr,
                                                                const unsigned char* __restrict__ vec_bits = nullptr,
-                                                               const int* __restrict__ tkd = nullptr) {
+                                                               const int* __restrict__ tkd = nullptr,
+                                                               const int* __restrict__ dead_cols = nullptr) {
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
@@ -374,6 +396,16 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
     return;
   }
   unsigned short* crow = reinterpret_cast<unsigned short*>(dense + row * n_p);
+  if (COMPACT && k_req >= tkd[0]) {
+    // no more dead latents than k_aux = d/2 (the usual state of a healthy run): the AuxK selection takes EVERY dead latent,
+    // so the compact row is just the row's values at the dead columns (zeros stay zeros) -- no selection, no barrier
+    const unsigned short* prow = reinterpret_cast<const unsigned short*>(pre + row * n_p);
+    for (int r = t; r < 8 * cvec; r += 256) {
+      const int j = dead_cols[r];
+      crow[r] = j >= 0 ? prow[j] : (unsigned short)0;
+    }
+    return;
+  }
   if (COMPACT) {                        // (__syncthreads = s_waitcnt vmcnt(0) + barrier: these stores have landed before any emission)
     for (int g = t; g < cvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
   }
@@ -419,21 +451,6 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
     keys[v] = w;
     cand[v] = cb;
   }
-  auto count_ge = [&](unsigned T) -> int {         // block-wide number of keys >= T (T in 1..0x8000)
-    const unsigned tp = T * 0x00010001u;
-    unsigned c2 = 0;
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c2 += (((keys[v][q] | 0x80008000u) - tp) >> 15) & 0x00010001u;
-    int c = (int)((c2 & 0xFFFFu) + (c2 >> 16));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    __syncthreads();
-    if ((t & 63) == 0) red[t >> 6] = c;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-  };
   int ncand_l = 0;
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) ncand_l += __popc(cand[v]);
@@ -625,18 +642,35 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? 4 : 1) void topk_sel
   __syncthreads();
 
   // ---- largest T in [1, 0x8000] with count(key >= T) >= k; T = 0 if fewer than k positive keys
-  const int npos = count_ge(1u);
+  const int npos = topk_count_ge<MAXV>(keys, 1u, t, red);
+  if (COMPACT && npos <= k) {
+    // no more positive dead latents than k_aux in this row: all of them are selected (and the zeros that fill the selection up
+    // carry nothing) -- each thread stores its own positive candidates at their compact positions, nothing to rank or scan
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int g = v * 256 + t;
+      if (g < nvec && cand[v] != 0u) {
+        const int base = vec_rank[g];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned short key = (unsigned short)((keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+          if (((cand[v] >> e) & 1u) && key != 0) crow[base + __popc(cand[v] & ((1u << e) - 1u))] = key;
+        }
+      }
+    }
+    return;
+  }
   unsigned T = 0;
   if (npos >= k) {
-    unsigned lo = 1, hi = 0x8000u;                 // invariant: count_ge(lo) >= k, count_ge(hi + 1) < k
+    unsigned lo = 1, hi = 0x8000u;                 // invariant: count(>= lo) >= k, count(>= hi + 1) < k
     while (lo < hi) {
       const unsigned mid = (lo + hi + 1) >> 1;
-      if (count_ge(mid) >= k) lo = mid;
+      if (topk_count_ge<MAXV>(keys, mid, t, red) >= k) lo = mid;
       else hi = mid - 1;
     }
     T = lo;
   }
-  const int n_gt = T >= 0x8000u ? 0 : (T == 0 ? npos : count_ge(T + 1));
+  const int n_gt = T >= 0x8000u ? 0 : (T == 0 ? npos : topk_count_ge<MAXV>(keys, T + 1, t, red));
   const int need_ties = k - n_gt;                  // elements equal to T to take (for T == 0: candidate zeros)
   // ---- ties at T in INCREASING COLUMN order (the rule of all three select kernels: what a stable descending sort
   // takes).  Column = 8 (256 v + t) + e, i.e. vector-row v first, then thread, then element.  Most rows take every
