@@ -1333,24 +1333,21 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           GemmArgs g{};
           g.A0 = which == 0 ? c->aux_dense : c->dpre; g.B0 = which == 0 ? c->dh_b : c->xs; g.lda = n_p; g.ldb = d_p;
           g.nbm = n_p / 128; g.nbn = d_p / 128; g.ktiles0 = g.ktiles = (int)(Mp / 64);
-          // split-K from the ESTIMATED extent: a few hundred dead latents are a handful of output tiles, and K = M is long --
-          // aim at two workgroups per CU, at least 8 K tiles per split, at most what the slab buffer holds
-          {
-            const int64_t tiles_est = (int64_t)(ndp_hint / 256 > 0 ? ndp_hint / 256 : 1) * ((d_p + 255) / 256);
-            int sp = (int)((512 + tiles_est - 1) / tiles_est);
-            if (sp < c->dw_splits) sp = c->dw_splits;
-            if (sp > c->slab_splits) sp = c->slab_splits;
-            if (sp > g.ktiles / 8) sp = g.ktiles / 8 > 0 ? g.ktiles / 8 : 1;
-            g.splits = sp;
-          }
+          // split-K on the DEVICE from the real dead count (gemm_dyn_splits): a few hundred dead latents are a handful of
+          // output tiles and K = M is long; between dw_splits and what the slab buffer holds
+          g.splits = c->slab_splits > g.ktiles / 8 ? (g.ktiles / 8 > 0 ? g.ktiles / 8 : 1) : c->slab_splits;
+          g.dyn_splits_min = c->dw_splits < g.splits ? c->dw_splits : g.splits;
           g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_M;
-          g.grid_hint = (ndp_hint / 128) * (d_p / 128) * g.splits;
+          const bool big = !g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0;       // launch_gemm's kernel choice
+          const int tile = big ? 256 : 128;
+          g.grid_hint = (ndp_hint / 128) * (d_p / 128) *
+                        gemm_dyn_splits((ndp_hint / tile) * (d_p / tile), g.dyn_splits_min, g.splits, g.ktiles);   // (sizing only)
           EpiSlab e{};
           e.slab = c->slab; e.slab_stride = c->nW; e.ld = d_p;
           rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
           if (rc) return rc;
-          hipLaunchKernelGGL(aux_scatter_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->slab, c->nW, g.splits, c->dead_cols, c->tkd,
-                             which == 0 ? gWd : gWe, d_p);
+          hipLaunchKernelGGL(aux_scatter_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->slab, c->nW, g.dyn_splits_min, g.splits,
+                             g.ktiles, tile, c->dead_cols, c->tkd, which == 0 ? gWd : gWe, d_p);
         }
         hipLaunchKernelGGL(aux_scatter_dbe_kernel, dim3((n_p + 63) / 64), dim3(1024), 0, s, c->aux_dbe_part, (int)(Mp / 128), n_p,
                            c->dead_cols, c->tkd, c->db_part, gbe);

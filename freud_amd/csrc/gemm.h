@@ -37,15 +37,30 @@ struct GemmArgs {
   // segment).  The launch covers the static maximum; workgroups beyond the dynamic extent exit at once (count 0: all).
   const int* dyn;
   int dyn_dim;
+  int dyn_splits_min;    // GEMM_DYN_M only, > 0: the split-K factor is chosen ON THE DEVICE from the dynamic extent --
+                         // gemm_dyn_splits(tiles, dyn_splits_min, splits, ktiles) with `splits` the maximum the launch and
+                         // the slab buffer provide -- so that a small extent (a few output tiles, K = M long) still fills
+                         // the chip and the result never depends on a host-side estimate (run-to-run bitwise equal)
   int grid_hint;         // dyn launches of the 256x256 kernel: an ESTIMATE of the 128x128 tiles of the dynamic extent (0 = none).
                          // Well below the static maximum it selects the PERSIST instantiation with a grid of that size.
 };
 enum { GEMM_DYN_NONE = 0, GEMM_DYN_M = 1, GEMM_DYN_N = 2, GEMM_DYN_K = 3 };
 
+// split-K factor for `tiles` output tiles: about two workgroups per CU, between smin and smax, at least 8 K tiles per split
+__host__ __device__ __forceinline__ int gemm_dyn_splits(int tiles, int smin, int smax, int ktiles) {
+  int sp = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  if (sp < smin) sp = smin;
+  if (sp > smax) sp = smax;
+  if (sp > ktiles / 8) sp = ktiles / 8 > 0 ? ktiles / 8 : 1;
+  return sp;
+}
+
 // Resolves the device-side dimension; TILE128 = 1 for the 128x128 kernel, 2 for the 256x256 kernels.  False = nothing to do.
-__device__ __forceinline__ bool gemm_dyn_dims(const GemmArgs& g, int tile_idx, int& nbm, int& nbn, int& ktiles0, int& ktiles) {
+__device__ __forceinline__ bool gemm_dyn_dims(const GemmArgs& g, int tile_idx, int& nbm, int& nbn, int& ktiles0, int& ktiles,
+                                              int& splits) {
   nbm = g.nbm;
   nbn = g.nbn;
+  splits = g.splits;
   ktiles0 = g.ktiles0;
   ktiles = (g.seg1_gate != nullptr && *g.seg1_gate == 0) ? g.ktiles0 : g.ktiles;
   if (g.dyn != nullptr) {
@@ -53,8 +68,9 @@ __device__ __forceinline__ bool gemm_dyn_dims(const GemmArgs& g, int tile_idx, i
     if (g.dyn_dim == GEMM_DYN_M) nbm = g.dyn[tile_idx];
     else if (g.dyn_dim == GEMM_DYN_N) nbn = g.dyn[tile_idx];
     else ktiles0 = ktiles = g.dyn[3];
+    if (g.dyn_dim == GEMM_DYN_M && g.dyn_splits_min > 0) splits = gemm_dyn_splits(nbm * nbn, g.dyn_splits_min, g.splits, ktiles);
   }
-  return (int)blockIdx.x < nbm * nbn * g.splits;
+  return true;
 }
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
@@ -163,16 +179,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
 
-  int nbm, nbn, ktiles0, ktiles;
-  if (!gemm_dyn_dims(g, 1, nbm, nbn, ktiles0, ktiles)) return;
-  const int nblk = nbm * nbn * g.splits;
+  int nbm, nbn, ktiles0, ktiles, splits;
+  if (!gemm_dyn_dims(g, 1, nbm, nbn, ktiles0, ktiles, splits)) return;
+  const int nblk = nbm * nbn * splits;
+  if ((int)blockIdx.x >= nblk) return;
   int id = xcd_remap(blockIdx.x, nblk);
   const int split = id / (nbm * nbn);
   id -= split * (nbm * nbn);
   int bm, bn;
   tile_coords(id, nbm, nbn, bm, bn);
-  const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
-  const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
+  const int kt_begin = (int)((int64_t)ktiles * split / splits);
+  const int kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
 
   f32x16 acc[2][2];
 #pragma unroll

@@ -153,16 +153,16 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
 // One 256x256 output tile (workgroup-level id `blk` of nblk).  g.nbm / g.nbn count 256-wide tiles here.
 template <int AMODE, int BMODE, class Epi>
 __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* smem, int blk, int nbm, int nbn, int ktiles0,
-                                             int ktiles) {
+                                             int ktiles, int splits) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
-  const int nblk = nbm * nbn * g.splits;
+  const int nblk = nbm * nbn * splits;
   int id = xcd_remap(blk, nblk);
   const int split = id / (nbm * nbn);
   id -= split * (nbm * nbn);
   int bm, bn;
   tile_coords(id, nbm, nbn, bm, bn);
-  const int kt_begin = (int)((int64_t)ktiles * split / g.splits);
-  const int kt_end = (int)((int64_t)ktiles * (split + 1) / g.splits);
+  const int kt_begin = (int)((int64_t)ktiles * split / splits);
+  const int kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -291,12 +291,12 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 template <int AMODE, int BMODE, class Epi, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int nbm, nbn, ktiles0, ktiles;
-  if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles)) return;
+  int nbm, nbn, ktiles0, ktiles, splits;
+  if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles, splits)) return;
+  const int nblk = nbm * nbn * splits;
   if constexpr (PERSIST) {
-    const int nblk = nbm * nbn * g.splits;
-    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles);
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles, splits);
   } else {
-    gemm256_tile<AMODE, BMODE>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles);
+    if ((int)blockIdx.x < nblk) gemm256_tile<AMODE, BMODE>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles, splits);
   }
 }

@@ -128,12 +128,14 @@ struct EpiAuxDecode {
   }
 };
 
-// g[dead_cols[r]][:] += sum_s slab[s][r][:]  (r < ND; one wave per row, 4 rows per block; grid covers n_p)
-__global__ __launch_bounds__(256) void aux_scatter_rows_kernel(const float* __restrict__ slab, int64_t slab_stride, int splits,
-                                                                const int* __restrict__ dead_cols, const int* __restrict__ tkd,
-                                                                float* __restrict__ g, int d_p) {
+// g[dead_cols[r]][:] += sum_s slab[s][r][:]  (r < ND; one wave per row, 4 rows per block; grid covers n_p).  The split-K
+// factor is the one the GEMM chose on the device from the same dead count (gemm_dyn_splits; tile = 128 or 256 rows / columns).
+__global__ __launch_bounds__(256) void aux_scatter_rows_kernel(const float* __restrict__ slab, int64_t slab_stride, int smin, int smax,
+                                                                int ktiles, int tile, const int* __restrict__ dead_cols,
+                                                                const int* __restrict__ tkd, float* __restrict__ g, int d_p) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= tkd[TKD_ND]) return;
+  const int splits = gemm_dyn_splits((tkd[TKD_NDP] / tile) * (d_p / tile), smin, smax, ktiles);
   const int j = dead_cols[r];
   f32x4* dst = reinterpret_cast<f32x4*>(g + (int64_t)j * d_p);
   for (int i = lane; i < d_p / 4; i += 64) {

@@ -462,3 +462,35 @@ def test_topk_c3_full_size_properties():
     assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
     assert np.isfinite(runs[0][0]).all() and runs[0][0][-1] < runs[0][0][0]
 
+
+
+def test_topk_auxk_runs_are_bitwise_reproducible():
+    """Two identical runs with a dead set that appears, changes size and crosses k_aux (AuxK through its copy path, the
+    full selection and the dynamic-width GEMMs, whose launch sizes follow a stale host-side estimate): every quantity that
+    enters the arithmetic is decided on the device, so parameters and metrics are bitwise equal (tools/longrun_topk.py is
+    the long form)."""
+    from freud_amd.engine import SaeEngine
+    M, d, n, k, T = 4096, 768, 4096, 16, 512
+    g = torch.Generator().manual_seed(0)
+    We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
+    Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
+    xs = [((torch.relu(torch.randn(M, 48, generator=g)) * 0.1) @ torch.randn(48, d, generator=g)).to(torch.bfloat16)
+          .reshape(M // T, T, d).cuda() for _ in range(3)]
+    runs = []
+    for _ in range(2):
+        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.03125)
+        eng.set_topk_options(2.0 * M, T)
+        eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
+                        "b_dec": np.zeros(d, np.float32)})
+        hist = []
+        for i in range(40):
+            eng.step(xs[i % 3], 3e-4)
+            if i % 5 == 4:
+                hist.append(eng.metrics().copy())
+        runs.append((np.stack(hist), eng.get_params()))
+        eng.close()
+    (h0, p0), (h1, p1) = runs
+    assert h0[:, 5].max() > 0 and h0[:, 1].max() > 0            # latents died and AuxK ran
+    assert np.array_equal(h0, h1)
+    for key in p0:
+        assert np.array_equal(p0[key], p1[key]), key
