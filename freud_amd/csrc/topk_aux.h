@@ -62,7 +62,10 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const long long* __r
       }
     vec_bits[i >> 3] = (unsigned char)bits;
   }
-  const int nd_p = (total + 255) & ~255;
+  // ND_p: a multiple of 256 where the dictionary's padded size is one (the 256x256 GEMM kernel then applies), else of 128 --
+  // never beyond n_p, the width of every compact buffer
+  const int gran = (n_p & 255) ? 128 : 256;
+  const int nd_p = ((total + gran - 1) / gran) * gran;
   for (int r = total + t; r < nd_p; r += 1024) dead_cols[r] = -1;
   if (t == 0) {
     const int k_aux_full = d / 2;

@@ -267,7 +267,8 @@ def test_sparse_dacts_matches_dense_ddense():
     eng.close()
 
 
-@pytest.mark.parametrize("d,n,n_dead", [(768, 2048, 100), (768, 2048, 700), (384, 1024, 1024), (1280, 1536, 900)])
+@pytest.mark.parametrize("d,n,n_dead", [(768, 2048, 100), (768, 2048, 700), (384, 1024, 1024), (1280, 1536, 900),
+                                         (384, 1152, 1152)])      # n_p = 9 x 128: the compact width must not pass n_p
 def test_auxk_compact_dead_set_matches_gather_path_and_oracle(d, n, n_dead):
     """AuxK as dense GEMMs over the compacted dead latents (topk_aux.h, the default) against the gather kernels it replaces
     (debug_flags 76 switches the compaction off) and against the oracle under the engine's tie rule: fewer dead latents
