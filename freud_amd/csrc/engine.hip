@@ -342,7 +342,9 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   c->topk_csc = c->topk_sparse_da && c->n_p <= CSC_MAX_NP && c->cfg.topk_dense_backward == 0;
   if (c->topk_csc) {
     const int64_t nb = (Mp + CSC_ROWS - 1) / CSC_ROWS;
-    const int64_t emax = Mp * (int64_t)(c->k + c->k_aux_cap + (c->multi ? c->k4 : 0));
+    // (the AuxK entries enter the CSC lists only where the compact dead-set path does not apply)
+    const bool auxc_will = c->cfg.auxk_alpha != 0.0 && c->n_p <= 2048 * 44 && c->cfg.debug_flags != 76;
+    const int64_t emax = Mp * (int64_t)(c->k + (auxc_will ? 0 : c->k_aux_cap) + (c->multi ? c->k4 : 0));
     c->csc_max_items = c->n_p + emax / CSC_CHUNK + 1;
     TALLOC(c->csc_counts, nb * c->n_p * 2);
     TALLOC(c->csc_block_off, nb * c->n_p * 4);
@@ -1294,10 +1296,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       ev_end(c, KID_TK_DDENSE, s);
       ev_begin(c, KID_TK_DWD, s);
       {
-        const unsigned blocks = (unsigned)((c->csc_max_items + 3) / 4);
+        const unsigned blocks = (unsigned)((c->csc_max_items + SB_WAVES - 1) / SB_WAVES);
         auto launch_sb = [&](auto np_tag) {
           constexpr int NP = decltype(np_tag)::value;
-          hipLaunchKernelGGL(sparse_bwd_kernel<NP>, dim3(blocks), dim3(256), 0, s, ps, c->xs, c->Wd_b, c->csc_entries, c->csc_start,
+          hipLaunchKernelGGL(sparse_bwd_kernel<NP>, dim3(blocks), dim3(64 * SB_WAVES), 0, s, ps, c->xs, c->Wd_b, c->csc_entries, c->csc_start,
                              c->csc_item_start, c->csc_item_latent, n_p, c->csc_part, c->csc_pbe, gWd, gWe, gbe, c->db_part);
         };
         if (d_p == 384) launch_sb(std::integral_constant<int, 3>{});

@@ -184,8 +184,11 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
 #endif
 // ---- 5. gradient work items -----------------------------------------------------------------------------------------------
 // item -> (latent j = item_latent[item], chunk item - item_start[j]); partial sums to part[item][2][d_p] and pbe[item].
+#ifndef SB_WAVES
+#define SB_WAVES 4      // waves (work items) per workgroup of sparse_bwd_kernel
+#endif
 template <int NPAIR>
-__global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const bf16_t* __restrict__ xs, const bf16_t* __restrict__ Wd,
+__global__ __launch_bounds__(64 * SB_WAVES) void sparse_bwd_kernel(SparsePasses ps, const bf16_t* __restrict__ xs, const bf16_t* __restrict__ Wd,
                                                          const CscEntry* __restrict__ entries, const unsigned int* __restrict__ start,
                                                          const unsigned int* __restrict__ item_start,
                                                          const unsigned int* __restrict__ item_latent, int n_p,
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(SparsePasses ps, const 
   constexpr int d_p = 128 * NPAIR, CPL = 2 * NPAIR;           // columns per lane
   const int lane = threadIdx.x & 63;
   const unsigned int nitems = item_start[n_p];
-  const unsigned int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned int item = blockIdx.x * SB_WAVES + (threadIdx.x >> 6);
   if (item >= nitems) return;                                 // wave-uniform
   const int j = (int)item_latent[item];
   const unsigned int e0 = start[j] + (item - item_start[j]) * CSC_CHUNK;
