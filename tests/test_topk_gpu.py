@@ -495,3 +495,41 @@ def test_topk_auxk_runs_are_bitwise_reproducible():
     assert np.array_equal(h0, h1)
     for key in p0:
         assert np.array_equal(p0[key], p1[key]), key
+
+
+@pytest.mark.parametrize("n_dead", [100, 400])
+def test_topk_multi_topk_with_auxk_matches_oracle(n_dead):
+    """cfg.multi_topk AND dead latents in one step: the 4k pass and the main pass through the CSC backward, the AuxK pass over
+    the compacted dead set (copy path at 100 dead <= d/2, full selection at 400), did_fire from the 4k set -- against the
+    oracle under the engine's tie rule."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, B, T, aux = 384, 1024, 8, 2, 96, 0.03125
+    P, x = _make_case(d, n, k, B, T, 21)
+    M = B * T
+    thr = 100.0
+    g = torch.Generator().manual_seed(5)
+    nfsf = torch.zeros(n, dtype=torch.long)
+    nfsf[torch.randperm(n, generator=g)[:n_dead]] = 1000
+    dead = nfsf > thr
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=aux, multi_topk=True)
+    eng.set_topk_options(thr, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.set_topk_state(nfsf.numpy())
+    eng.forward_backward(x.cuda())
+    graw = _split(eng.debug_read(2, 2 * n * d + n + d), n, d)
+    eng.optimizer_step(1e-4)
+    m = eng.metrics()
+    ref = O.topk_train_step(x, P, O.OptState(), k=k, lr=1e-4, clip_thresh=1.0, dead_mask=dead, auxk_alpha=aux, optimizer="adam",
+                            multi_topk=True, stable_ties=True)
+    assert m[1] > 0 and m[6] > 0
+    assert m[0] == pytest.approx(ref["fvu"].item(), rel=5e-3)
+    assert m[1] == pytest.approx(ref["auxk_loss"].item(), rel=2e-2)
+    assert m[6] == pytest.approx(ref["multi_topk_fvu"].item(), rel=5e-3)
+    assert m[3] == pytest.approx(ref["grad_norm"].item(), rel=2e-2)
+    for kk in KEYS:
+        assert _rel(graw[kk], ref["grads"][kk].numpy()) < 2e-2, kk
+    fired = np.zeros(n, bool)
+    fired[ref["fire_indices"].numpy().ravel()] = True
+    got = eng.get_topk_state()
+    assert np.mean((got == 0) != fired) < 0.01           # boundary ties in the 4k selection move a few latents
+    eng.close()
