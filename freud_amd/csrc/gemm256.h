@@ -51,17 +51,17 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if ((wn >> 1) == pass) {
-      float* dst = tile + wm * G2_SUB_FLOATS;
-      const int h = lane >> 5, c = lane & 31;
+      // (the K loops feed the MFMA with the operands swapped -- D^T = B A^T -- so a lane holds output row 32 i + lane % 32 and,
+      // per group of four accumulator registers, FOUR CONSECUTIVE COLUMNS 32 j + 8 g + 4 (lane / 32): 16-byte LDS writes)
+      float* dst = tile + wm * G2_SUB_FLOATS + (lane & 31) * GEMM_EPI_PITCH + 64 * (wn & 1) + 4 * (lane >> 5);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-            dst[row * GEMM_EPI_PITCH + 64 * (wn & 1) + 32 * j + c] = acc[i][j][r];
-          }
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<f32x4*>(dst + 32 * i * GEMM_EPI_PITCH + 32 * j + 8 * gq) =
+                f32x4{acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
     }
     __syncthreads();
     const float* src = tile + half * G2_SUB_FLOATS;
@@ -91,12 +91,12 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
 
 // Epilogue for functors whose first act on an accumulator is its rounding to bf16 (static constexpr bool
 // ROUNDS_BF16_FIRST: the bf16-autocast GEMM outputs -- c, x_hat, dc, d acts): the WHOLE 256x256 tile goes to LDS as bf16
-// (pitch 264 elements: 135 168 bytes) in one step, so no wave sits on its 128 accumulator registers while others are
+// (pitch 260 elements: 133 120 bytes) in one step, so no wave sits on its 128 accumulator registers while others are
 // served (that cost the functors with global loads 30-70 spilled registers or a shallower prefetch), the fp32 round trip
 // through LDS is halved, and a tile needs 3 barriers less.  The functor still receives fp32 values (exactly the rounded
 // ones) and works on 128x128 sub-tiles: half h of the workgroup takes rows 128 h.., first the columns 0..127, then 128..255.
-constexpr int G2_BF16_PITCH = 264;
-constexpr int G2_BF16_TILE_BYTES = 256 * G2_BF16_PITCH * 2;            // 135 168
+constexpr int G2_BF16_PITCH = 260;     // 520-byte rows: the 8-byte writes of 16 lanes (16 rows) fall on 32 different banks
+constexpr int G2_BF16_TILE_BYTES = 256 * G2_BF16_PITCH * 2;            // 133 120
 constexpr int G2_BF16_SCRATCH_FLOATS = 1024;                           // per 256-thread half, for tile_end()
 constexpr int G2_BF16_LDS_BYTES = G2_BF16_TILE_BYTES + 2 * G2_BF16_SCRATCH_FLOATS * 4;
 
@@ -110,15 +110,15 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
   {
-    const int h = lane >> 5, c = lane & 31;
-    bf16_t* dst = tile + (128 * wm + 4 * h) * G2_BF16_PITCH + 64 * wn + c;
+    bf16_t* dst = tile + (128 * wm + (lane & 31)) * G2_BF16_PITCH + 64 * wn + 4 * (lane >> 5);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          dst[(32 * i + (r & 3) + 8 * (r >> 2)) * G2_BF16_PITCH + 32 * j] = (bf16_t)acc[i][j][r];
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<bf16x4*>(dst + 32 * i * G2_BF16_PITCH + 32 * j + 8 * gq) =
+              bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
   }
   __syncthreads();
   const int half = t >> 8, tl = t & 255;
@@ -243,7 +243,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][m >> 1], fb[kk & 1][m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+        acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], acc[m >> 1][m & 1], 0, 0, 0);   // D^T = B A^T
         __builtin_amdgcn_sched_barrier(0);
         if (kk == 0) {            // second half of tile kt+1's pieces + the fragments of K step 1
           if (m == 0) issue(clampk(kt + 1), cur ^ 1, 2);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[s][j], acc[i][j], 0, 0, 0, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);   // D^T = B A^T (g2_epilogue)
         fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);     // its registers are free: next step's fragment i
         __builtin_amdgcn_sched_barrier(0);
       }
