@@ -219,7 +219,13 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #pragma unroll
     for (int q = 0; q < 4; ++q) issue(clampk(kt_begin + 1), 1, q);
   }
+#ifdef G2X_PROLOGUE_WAIT_ALL
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  // only tile 0 has to be there (this wave's 8 older DMA instructions); tile 1 keeps landing under tile 0's MFMAs and is
+  // waited for at the first hand-over barrier, like every later tile
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
   __syncthreads();
   if (kt_begin < kt_end) {
 #pragma unroll

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
   for (int q = 0; q < 4; ++q) issue(0, 0, q);
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue(clampk(1), 1, q);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 only (8 older DMA instructions); tile 1 is waited for at the first hand-over
   __syncthreads();
 
   i32x8 fa[4], fb[2][2];
