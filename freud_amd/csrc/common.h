@@ -41,6 +41,19 @@ __device__ __forceinline__ float half_wave_max_hi(float v) {
   return __int_as_float(x);
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access of the wave
+// (s_waitcnt vmcnt(0)), and in a GEMM epilogue that is a drain of the tile's non-temporal stores (~1-2 us) at each of its
+// barriers.  Use where the threads exchange data through LDS and nothing through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// block_sum_256 with LDS-only barriers (GEMM epilogue functors)
+__device__ __forceinline__ float block_sum_256_lds(float v, float* red /* >= 4 floats of LDS */);
+
 // Sum over a group of 256 consecutive threads (4 waves); result valid in the group's first thread.  blockDim.x is 256
 // (one group) or 512 (two groups, each with its own `red`); every thread of the block must call it.
 __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
@@ -49,6 +62,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 float
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_sum_256_lds(float v, float* red) {
+  v = wave_sum(v);
+  const int w = (threadIdx.x >> 6) & 3;
+  lds_barrier();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  lds_barrier();
   return red[0] + red[1] + red[2] + red[3];
 }
 

@@ -14,6 +14,9 @@
 #pragma once
 #include "gemm.h"
 
+#ifdef G2X_STAMP
+__device__ unsigned long long* g2x_stamps = nullptr;      // tools/kbench: [tile][4] = prologue, K loop, epilogue cycles, start
+#endif
 constexpr int G2_BM = 256, G2_BN = 256;
 constexpr int G2_OPER_BYTES = 256 * GEMM_BK * 2;                      // 32 KiB per operand tile
 constexpr int G2_STAGE_BYTES = 2 * G2_OPER_BYTES;                     // 64 KiB
@@ -63,7 +66,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
             *reinterpret_cast<f32x4*>(dst + 32 * i * GEMM_EPI_PITCH + 32 * j + 8 * gq) =
                 f32x4{acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
     }
-    __syncthreads();
+    lds_barrier();
     const float* src = tile + half * G2_SUB_FLOATS;
     const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
     epi.tile_begin(row0, col0, split);
@@ -83,9 +86,10 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     epi.tile_end(tile + half * G2_SUB_FLOATS);
-    __syncthreads();
+    lds_barrier();
+
   }
 }
 
@@ -98,14 +102,14 @@ __device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int
 constexpr int G2_BF16_PITCH = 260;     // 520-byte rows: the 8-byte writes of 16 lanes (16 rows) fall on 32 different banks
 constexpr int G2_BF16_TILE_BYTES = 256 * G2_BF16_PITCH * 2;            // 133 120
 constexpr int G2_BF16_SCRATCH_FLOATS = 1024;                           // per 256-thread half, for tile_end()
-constexpr int G2_BF16_LDS_BYTES = G2_BF16_TILE_BYTES + 2 * G2_BF16_SCRATCH_FLOATS * 4;
+constexpr int G2_BF16_LDS_BYTES = G2_BF16_TILE_BYTES + 4 * G2_BF16_SCRATCH_FLOATS * 4;   // scratch per (half, pass): no barrier between the passes
 
 template <class E, class = void>
 struct epi_rounds_first { static constexpr bool value = false; };
 template <class E>
 struct epi_rounds_first<E, std::void_t<decltype(E::ROUNDS_BF16_FIRST)>> { static constexpr bool value = E::ROUNDS_BF16_FIRST; };
 
-template <class Epi>
+template <bool FINAL_BARRIER, class Epi>
 __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
@@ -120,11 +124,11 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
           *reinterpret_cast<bf16x4*>(dst + 32 * i * G2_BF16_PITCH + 32 * j + 8 * gq) =
               bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
   }
-  __syncthreads();
+  lds_barrier();
   const int half = t >> 8, tl = t & 255;
-  float* scratch = reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + half * G2_BF16_SCRATCH_FLOATS;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
+    float* scratch = reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + (2 * pass + half) * G2_BF16_SCRATCH_FLOATS;
     const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
     const bf16_t* src = tile + (128 * half) * G2_BF16_PITCH + 128 * pass;
     epi.tile_begin(row0, col0, split);
@@ -146,12 +150,12 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
       }
     }
     epi.tile_end(scratch);
-    __syncthreads();        // scratch is free again (and, after the second pass, the tile)
   }
+  if (FINAL_BARRIER) lds_barrier();        // the tile and the scratch areas are free again (persistent instantiation only)
 }
 
 // One 256x256 output tile (workgroup-level id `blk` of nblk).  g.nbm / g.nbn count 256-wide tiles here.
-template <int AMODE, int BMODE, class Epi>
+template <int AMODE, int BMODE, bool PERSIST, class Epi>
 __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* smem, int blk, int nbm, int nbn, int ktiles0,
                                              int ktiles, int splits) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
@@ -164,6 +168,17 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   const int kt_begin = (int)((int64_t)ktiles * split / splits);
   const int kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
 
+#ifdef G2X_PHASE
+  // experiment: half of the FIRST round's workgroups start late by G2X_PHASE x 8128 cycles, so that the CUs' epilogue bursts
+  // (all of them otherwise write their 128 KiB tiles at the same moment) fall under the other half's K loops
+  if ((int)blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+#pragma unroll 1
+    for (int i = 0; i < G2X_PHASE; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+#ifdef G2X_STAMP
+  unsigned long long st0 = __builtin_readcyclecounter(), st1 = 0, st2 = 0;
+#endif
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -234,6 +249,9 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
   }
 
+#ifdef G2X_STAMP
+  st1 = __builtin_readcyclecounter();
+#endif
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const char* sa = smem + cur * G2_STAGE_BYTES;
@@ -284,8 +302,18 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
   __syncthreads();
 
-  if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16(acc, smem, bm, bn, split, epi);
+#ifdef G2X_STAMP
+  st2 = __builtin_readcyclecounter();
+#endif
+  if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc, smem, bm, bn, split, epi);
   else g2_epilogue(acc, smem, bm, bn, split, epi);      // (both end with a barrier: LDS is free again)
+#ifdef G2X_STAMP
+  if (threadIdx.x == 0 && g2x_stamps) {
+    unsigned long long st3 = __builtin_readcyclecounter();
+    unsigned long long* o = g2x_stamps + 4 * (size_t)blk;
+    o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st3 - st2; o[3] = st0;
+  }
+#endif
 }
 
 // PERSIST = false: one tile per workgroup (grid = the static tile count; with GemmArgs::dyn the workgroups beyond the
@@ -301,8 +329,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   if (!gemm_dyn_dims(g, 2, nbm, nbn, ktiles0, ktiles, splits)) return;
   const int nblk = nbm * nbn * splits;
   if constexpr (PERSIST) {
-    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles, splits);
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE, true>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles, splits);
   } else {
-    if ((int)blockIdx.x < nblk) gemm256_tile<AMODE, BMODE>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles, splits);
+    if ((int)blockIdx.x < nblk) gemm256_tile<AMODE, BMODE, false>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles, splits);
   }
 }

@@ -182,7 +182,7 @@ struct EpiEnc8 {
     EPI_STORE(reinterpret_cast<unsigned*>(c8 + (int64_t)row * n_p + col), pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc));
   }
   __device__ void tile_end(float* scratch) {
-    const float s = block_sum_256(l1, scratch);
+    const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
   }
 };

@@ -180,7 +180,7 @@ struct EpiEnc {
     if (!skip_store) EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float* scratch) {
-    const float s = block_sum_256(l1, scratch);
+    const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
   }
 };
@@ -232,8 +232,8 @@ struct EpiDec {
     *reinterpret_cast<bf16x4*>(dxh + (int64_t)row * d_p + col) = o;
   }
   __device__ void tile_end(float* scratch) {
-    const float a = block_sum_256(sq, scratch);
-    const float b = block_sum_256(plain, scratch + 8);
+    const float a = block_sum_256_lds(sq, scratch);
+    const float b = block_sum_256_lds(plain, scratch + 8);
     if ((threadIdx.x & 255) == 0) {
       sq_part[2 * tile_id] = a;
       sq_part[2 * tile_id + 1] = b;
@@ -277,7 +277,7 @@ struct EpiDpre {
     const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
-    __syncthreads();
+    lds_barrier();
     if (t < 128) {
       float s = 0.f;
 #pragma unroll

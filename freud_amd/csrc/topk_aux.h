@@ -126,7 +126,7 @@ struct EpiAuxDecode {
     *reinterpret_cast<f32x4*>(dh + (int64_t)row * d_p + col) = o;
   }
   __device__ void tile_end(float* scratch) {
-    const float s = block_sum_256(sq, scratch);
+    const float s = block_sum_256_lds(sq, scratch);
     if ((threadIdx.x & 255) == 0) part[tile_id] = s;
   }
 };

@@ -143,7 +143,7 @@ struct EpiTopkEnc {
     const int t = threadIdx.x & 255;
 #pragma unroll
     for (int it = 0; it < 16; ++it) sc[((t >> 5) + 8 * it) * PITCH + (t & 31)] = rmax[it];
-    __syncthreads();
+    lds_barrier();
     if (t < 128) {
       const u32x4* r = reinterpret_cast<const u32x4*>(sc + t * PITCH);
       unsigned int m = 0;
@@ -1211,7 +1211,7 @@ struct EpiTopkDpre {
     const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
-    __syncthreads();
+    lds_barrier();
     if (t < 128) {
       float s = 0.f;
 #pragma unroll
@@ -1242,7 +1242,7 @@ struct EpiTopkDsaeIn {
     const int t = threadIdx.x & 255;
     f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
     *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
-    __syncthreads();
+    lds_barrier();
     if (t < 128) {
       float s = 0.f;
 #pragma unroll

@@ -118,6 +118,23 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     reps += 5;
   } while (reps < 40);
+#ifdef G2X_STAMP
+  {
+    const size_t ntile = (size_t)g.nbm * g.nbn * g.splits;
+    unsigned long long* dbuf;
+    CK(hipMalloc(&dbuf, ntile * 32));
+    CK(hipMemset(dbuf, 0, ntile * 32));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g2x_stamps), &dbuf, sizeof(dbuf)));
+    run();
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hs(ntile * 4);
+    CK(hipMemcpy(hs.data(), dbuf, ntile * 32, hipMemcpyDeviceToHost));
+    double a = 0, b = 0, c = 0;
+    for (size_t i = 0; i < ntile; ++i) { a += hs[4 * i]; b += hs[4 * i + 1]; c += hs[4 * i + 2]; }
+    printf("per tile (s_memtime cycles, 100 MHz-independent counter units): prologue %.0f  K loop %.0f  epilogue %.0f  -> shares %.1f %% / %.1f %% / %.1f %%\n",
+           a / ntile, b / ntile, c / ntile, 100 * a / (a + b + c), 100 * b / (a + b + c), 100 * c / (a + b + c));
+  }
+#endif
   const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
   printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
          (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
