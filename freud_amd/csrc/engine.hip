@@ -839,9 +839,11 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     GemmArgs g2 = g;
     g2.nbm = g.nbm / 2;
     g2.nbn = g.nbn / 2;
-    const int grid_max = g2.nbm * g2.nbn * g2.splits;
+    const int grid_max = (g.dyn && g.grid_cover > 0) ? g.grid_cover : g2.nbm * g2.nbn * g2.splits;
     const int grid_est = (((g.grid_hint + 3) / 4 + 7) / 8) * 8;          // 256x256 tiles, a multiple of 8
-    if (g.dyn && g.grid_hint > 0 && grid_est * 2 < grid_max) {
+    // (the caller sets grid_hint only for a SMALL estimated extent: the persistent instantiation's tile loop costs the K loop
+    // ~10 %, while the workgroups that start only to exit are cheap until they are the great majority)
+    if (g.dyn && g.grid_hint > 0 && grid_est < grid_max) {
       auto kernp = gemm256_bf16_kernel<AM, BM_, Epi, true>;
       LDS_ATTR(kernp, lds256, g_device);
       hipLaunchKernelGGL(kernp, dim3(grid_est < 256 ? 256 : grid_est), dim3(512), lds256, s, g2, epi);
@@ -853,7 +855,7 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   }
   auto kern = gemm_bf16_kernel<AM, BM_, Epi>;
   LDS_ATTR(kern, GEMM_LDS_BYTES, g_device);
-  const int grid = g.nbm * g.nbn * g.splits;
+  const int grid = (g.dyn && g.grid_cover > 0) ? g.grid_cover : g.nbm * g.nbn * g.splits;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, g, epi);
   HIP_TRY(hipGetLastError());
   return SAE_OK;
@@ -1320,12 +1322,14 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         const int nd_hint = c->dead_hint[0];
         int ndp_hint = (nd_hint + nd_hint / 4 + 511) & ~255;
         if (ndp_hint > n_p) ndp_hint = n_p;
+        const bool small_dead = (int64_t)ndp_hint * 8 <= n_p;      // estimated grids (persistent instantiation) only then
         {   // d A = [selected, > 0] bf16(d e_hat W_dec[dead]^T), column sums
           GemmArgs g{};
           g.A0 = c->dh_b; g.B0 = c->Wdd_b; g.lda = d_p; g.ldb = d_p;
           g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
           g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_N;
-          g.grid_hint = (int)((Mp / 128) * (ndp_hint / 128));
+          g.grid_hint = (int64_t)ndp_hint * 2 <= n_p ? (int)((Mp / 128) * (ndp_hint / 128)) : 0;   // (one exiting workgroup per
+                                                            // missing tile costs more than the persistent loop up to about there)
           EpiTopkDpre e{};
           e.sel = c->aux_dense; e.dpre = c->dpre; e.dbe_part = c->aux_dbe_part; e.n_p = n_p; e.accumulate = 0; e.last = 1;
           rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
@@ -1338,12 +1342,26 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           // split-K on the DEVICE from the real dead count (gemm_dyn_splits): a few hundred dead latents are a handful of
           // output tiles and K = M is long; between dw_splits and what the slab buffer holds
           g.splits = c->slab_splits > g.ktiles / 8 ? (g.ktiles / 8 > 0 ? g.ktiles / 8 : 1) : c->slab_splits;
-          g.dyn_splits_min = c->dw_splits < g.splits ? c->dw_splits : g.splits;
+          g.dyn_splits_min = 1;
+          // the launch only has to cover tiles x factor for the factor the device will choose: its maximum over every possible
+          // extent, not the static tile count times the largest factor (a workgroup that starts only to exit costs ~3 us of a
+          // CU: 8 700 of them were a quarter of these GEMMs' time)
+          {
+            const bool big_ = !g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0;
+            const int tl = big_ ? 256 : 128, tn = d_p / tl, tm_max = n_p / tl;
+            int cover = 1;
+            for (int tmm = 1; tmm <= tm_max; ++tmm) {
+              const int need = tmm * tn * gemm_dyn_splits(tmm * tn, 1, g.splits, g.ktiles);
+              if (need > cover) cover = need;
+            }
+            g.grid_cover = cover;
+          }
           g.dyn = c->tkd; g.dyn_dim = GEMM_DYN_M;
           const bool big = !g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0;       // launch_gemm's kernel choice
           const int tile = big ? 256 : 128;
-          g.grid_hint = (ndp_hint / 128) * (d_p / 128) *
-                        gemm_dyn_splits((ndp_hint / tile) * (d_p / tile), g.dyn_splits_min, g.splits, g.ktiles);   // (sizing only)
+          g.grid_hint = small_dead ? (ndp_hint / 128) * (d_p / 128) *
+                                         gemm_dyn_splits((ndp_hint / tile) * (d_p / tile), g.dyn_splits_min, g.splits, g.ktiles)
+                                   : 0;                                                                              // (sizing only)
           EpiSlab e{};
           e.slab = c->slab; e.slab_stride = c->nW; e.ld = d_p;
           rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);

@@ -41,18 +41,31 @@ struct GemmArgs {
                          // gemm_dyn_splits(tiles, dyn_splits_min, splits, ktiles) with `splits` the maximum the launch and
                          // the slab buffer provide -- so that a small extent (a few output tiles, K = M long) still fills
                          // the chip and the result never depends on a host-side estimate (run-to-run bitwise equal)
+  int grid_cover;        // dyn launches, > 0: workgroups that cover every possible extent (host-computed; default = the static
+                         // tile count times `splits`)
   int grid_hint;         // dyn launches of the 256x256 kernel: an ESTIMATE of the 128x128 tiles of the dynamic extent (0 = none).
                          // Well below the static maximum it selects the PERSIST instantiation with a grid of that size.
 };
 enum { GEMM_DYN_NONE = 0, GEMM_DYN_M = 1, GEMM_DYN_N = 2, GEMM_DYN_K = 3 };
 
-// split-K factor for `tiles` output tiles: about two workgroups per CU, between smin and smax, at least 8 K tiles per split
+// split-K factor for `tiles` output tiles (256 CUs, one workgroup each at a time): the factor in [1, smax] with at least 8 K
+// tiles per split that minimises  rounds(tiles * sp) / sp  +  a reduction price proportional to sp * tiles  -- the cost
+// model of the host's choose_splits(), evaluated on the device (same inputs -> same factor in the GEMM and in the kernel
+// that adds its slabs up).  smin is a floor for callers that want one.
 __host__ __device__ __forceinline__ int gemm_dyn_splits(int tiles, int smin, int smax, int ktiles) {
-  int sp = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
-  if (sp < smin) sp = smin;
-  if (sp > smax) sp = smax;
-  if (sp > ktiles / 8) sp = ktiles / 8 > 0 ? ktiles / 8 : 1;
-  return sp;
+  if (tiles < 1) tiles = 1;
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int sp = 1; sp <= smax; ++sp) {
+    if (sp > 1 && ktiles / sp < 8) break;
+    const int rounds = (tiles * sp + 255) / 256;
+    const float cost = (float)rounds / (float)sp + 0.04f * (float)sp * (float)tiles * (1.0f / 288.0f);
+    if (cost < best_cost - 1e-6f) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  return best < smin ? smin : best;
 }
 
 // Resolves the device-side dimension; TILE128 = 1 for the 128x128 kernel, 2 for the 256x256 kernels.  False = nothing to do.

@@ -113,6 +113,20 @@ template <bool FINAL_BARRIER, class Epi>
 __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+  const int half = t >> 8, tl = t & 255, c4 = (tl & 31) * 4;
+  const int row0 = bm * G2_BM + 128 * half;
+  // A thread's 32 elements (2 passes x 16 rows) go in batches of NB; the global loads of batch q + 1 (Epi::prefetch) are
+  // issued before batch q is applied, and those of batch 0 before the accumulators go to LDS: every memory round trip of
+  // the epilogue runs under the previous phase (with the loads issued at the head of each batch a functor that reads a
+  // [M x n] operand -- the latent in dpre, x in the decoder -- paid four exposed latencies per tile).
+  constexpr int NB = epi_prefetch_batch<Epi>::value, BPP = 16 / NB, NQ = 2 * BPP;
+  typename Epi::Pre pre[2][NB];
+  auto prefetch_batch = [&](int q, typename Epi::Pre (&dst)[NB]) {
+    const int pass = q / BPP, b0 = (q % BPP) * NB;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) dst[it] = epi.prefetch(row0 + (tl >> 5) + 8 * (b0 + it), bn * G2_BN + 128 * pass + c4);
+  };
+  prefetch_batch(0, pre[0]);
   {
     bf16_t* dst = tile + (128 * wm + (lane & 31)) * G2_BF16_PITCH + 64 * wn + 4 * (lane >> 5);
 #pragma unroll
@@ -125,31 +139,22 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
               bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
   }
   lds_barrier();
-  const int half = t >> 8, tl = t & 255;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    float* scratch = reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + (2 * pass + half) * G2_BF16_SCRATCH_FLOATS;
-    const int row0 = bm * G2_BM + 128 * half, col0 = bn * G2_BN + 128 * pass;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int pass = q / BPP, b0 = (q % BPP) * NB;
+    const int col0 = bn * G2_BN + 128 * pass;
     const bf16_t* src = tile + (128 * half) * G2_BF16_PITCH + 128 * pass;
-    epi.tile_begin(row0, col0, split);
-    {
-      const int c4 = (tl & 31) * 4;
-      constexpr int NB = epi_prefetch_batch<Epi>::value;
+    if (q + 1 < NQ) prefetch_batch(q + 1, pre[(q + 1) & 1]);
+    if (b0 == 0) epi.tile_begin(row0, col0, split);
 #pragma unroll
-      for (int b0 = 0; b0 < 16; b0 += NB) {
-        typename Epi::Pre pre[NB];
-#pragma unroll
-        for (int it = 0; it < NB; ++it) pre[it] = epi.prefetch(row0 + (tl >> 5) + 8 * (b0 + it), col0 + c4);
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-          const int row = (tl >> 5) + 8 * (b0 + it);
-          const bf16x4 q = *reinterpret_cast<const bf16x4*>(&src[row * G2_BF16_PITCH + c4]);
-          const f32x4 v = {(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
-          epi_apply(epi, b0 + it, row0 + row, col0 + c4, v, pre[it], 0);
-        }
-      }
+    for (int it = 0; it < NB; ++it) {
+      const int row = (tl >> 5) + 8 * (b0 + it);
+      const bf16x4 qv = *reinterpret_cast<const bf16x4*>(&src[row * G2_BF16_PITCH + c4]);
+      const f32x4 v = {(float)qv[0], (float)qv[1], (float)qv[2], (float)qv[3]};
+      epi_apply(epi, b0 + it, row0 + row, col0 + c4, v, pre[q & 1][it], 0);
     }
-    epi.tile_end(scratch);
+    if (b0 + NB == 16)       // scratch per (half, pass): no barrier between the passes
+      epi.tile_end(reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + (2 * pass + half) * G2_BF16_SCRATCH_FLOATS);
   }
   if (FINAL_BARRIER) lds_barrier();        // the tile and the scratch areas are free again (persistent instantiation only)
 }
