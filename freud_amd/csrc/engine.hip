@@ -26,6 +26,10 @@ static thread_local int g_device = 0;  // device of the context the current call
 #include "topk_sparse.h"
 #include "topk_aux.h"
 
+#ifndef G2_PERSIST_STATIC
+#define G2_PERSIST_STATIC 512      // resident workgroups of the big static 256x256 GEMM launches (0: one workgroup per tile)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------
@@ -843,7 +847,13 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     const int grid_est = (((g.grid_hint + 3) / 4 + 7) / 8) * 8;          // 256x256 tiles, a multiple of 8
     // (the caller sets grid_hint only for a SMALL estimated extent: the persistent instantiation's tile loop costs the K loop
     // ~10 %, while the workgroups that start only to exit are cheap until they are the great majority)
-    if (g.dyn && g.grid_hint > 0 && grid_est < grid_max) {
+    if (G2_PERSIST_STATIC > 0 && !g.dyn && g2.splits == 1 && grid_max >= 4 * G2_PERSIST_STATIC) {
+      // big static launches (the K = d GEMMs: tens of thousands of tiles) as G2_PERSIST_STATIC resident workgroups that walk
+      // the tiles: encoder / dpre -2 %, TopK encoder -2.5 % against one workgroup per tile (same box; 256 / 512 / 1024 measure alike)
+      auto kernp = gemm256_bf16_kernel<AM, BM_, Epi, true>;
+      LDS_ATTR(kernp, lds256, g_device);
+      hipLaunchKernelGGL(kernp, dim3(G2_PERSIST_STATIC), dim3(512), lds256, s, g2, epi);
+    } else if (g.dyn && g.grid_hint > 0 && grid_est < grid_max) {
       auto kernp = gemm256_bf16_kernel<AM, BM_, Epi, true>;
       LDS_ATTR(kernp, lds256, g_device);
       hipLaunchKernelGGL(kernp, dim3(grid_est < 256 ? 256 : grid_est), dim3(512), lds256, s, g2, epi);

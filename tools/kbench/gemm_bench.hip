@@ -69,9 +69,15 @@ int main(int argc, char** argv) {
       run_w4(C);
     } else if (!kmajor) {
       EpiBf16 e{C, N};
+#ifdef KB_PERSIST
+      auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16, true>;       // the tile-loop instantiation on KB_PERSIST workgroups
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
+      hipLaunchKernelGGL(kern, dim3(KB_PERSIST), dim3(512), G2_LDS_BYTES, 0, g, e);
+#else
       auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16>;
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
       hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
+#endif
     } else {
       EpiSlab e{};
       e.slab = slab; e.slab_stride = M * N; e.ld = (int)N;
