@@ -177,7 +177,11 @@ def run_l1_case(name, d, n, B, T, steps, optimizer, scheduler, lr, recon_alpha, 
     print(f"[{name}] l1={rec['l1']} recon={rec['recon']} gnorm={rec['gnorm']}")
 
 
-def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_threshold, warmup, multi_topk=False):
+def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_threshold, warmup, multi_topk=False,
+                  tie_free_margin=None):
+    """tie_free_margin: give up (return False, write nothing) as soon as a row of any step has its k-th and (k+1)-th
+    largest pre-activation closer than this RELATIVE gap -- torch.topk has no rule for ties (topkautoencoder.py:79-81), so
+    only a batch sequence without near-ties pins the selection itself (main() searches seeds for one)."""
     from src.models.config import TopKAutoEncoderConfig
     from src.models.topkautoencoder import TopKAutoEncoder
     from torch.amp import autocast
@@ -199,6 +203,14 @@ def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_thresho
         did_fire = torch.zeros(n, dtype=torch.bool)
         opt.zero_grad()
         rec["lr_used"].append(opt.param_groups[0]["lr"])
+        if tie_free_margin is not None:
+            # (its own autocast region: the weight casts a no_grad call leaves in the autocast cache would cut the real
+            # forward below off from the parameters' gradients)
+            with autocast("cpu"), torch.no_grad():
+                srt = model.pre_acts(x).float().reshape(-1, n).sort(dim=1, descending=True).values
+            hi, lo = srt[:, k - 1], srt[:, k]
+            if bool(((hi - lo) <= tie_free_margin * hi.abs()).any()):
+                return False
         with autocast("cpu"):
             dead_mask = nfsf > dead_threshold
             out, mse = model(x, dead_mask=dead_mask, return_mse=True)
@@ -241,6 +253,19 @@ def run_topk_case(name, d, n, k, B, T, steps, lr, seed, auxk_alpha, dead_thresho
         gnorm=np.array(rec["gnorm"]), lr_used=np.array(rec["lr_used"]), num_dead=np.array(rec["num_dead"]),
         nfsf_final=nfsf.numpy(), **arrays)
     print(f"[{name}] fvu={rec['fvu']} auxk={rec['auxk']} dead={rec['num_dead']}")
+    return True
+
+
+def run_tie_free_topk_case():
+    """Seed search (deterministic: first hit from seed 100 up) for a TopK trajectory on which every row of every step has
+    a relative gap of > 2^-6 (two bf16 ulps at least) between its k-th and (k+1)-th pre-activation: the reference's selection is then unambiguous
+    (and stays so under the engine's summation order), and the engine can be held to the reference's OWN gradients."""
+    for seed in range(100, 20000):
+        if run_topk_case("topk_tiefree_d64", d=64, n=128, k=4, B=2, T=4, steps=3, lr=1e-3, seed=seed, auxk_alpha=0.0,
+                         dead_threshold=1e6, warmup=1, tie_free_margin=2.0 ** -6):
+            print(f"[topk_tiefree_d64] seed {seed}")
+            return
+    raise SystemExit("no tie-free trajectory found")
 
 
 def write_shards(folder, layer, n_files, T, d, seed, dtype=np.float32):
@@ -339,27 +364,36 @@ def main():
     SummaryWriter = install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "multi":      # only the fixture added in round 2 (the others are unchanged)
-        run_topk_case("topk_multi_d32", d=32, n=256, k=8, B=2, T=16, steps=5, lr=1e-3, seed=6,
-                      auxk_alpha=0.03125, dead_threshold=40.0, warmup=2, multi_topk=True)
-        return
-    run_l1_case("l1_radam_cosine_d16", d=16, n=64, B=4, T=8, steps=5, optimizer="radam", scheduler="cosine",
-                lr=4e-4, recon_alpha=1e4, seed=0, total_steps=100)
-    run_l1_case("l1_adam_linear_d48", d=48, n=200, B=3, T=20, steps=6, optimizer="adam", scheduler="linear",
-                lr=1e-3, recon_alpha=1.0, seed=1, sched_params={"num_warmup_steps": 3}, total_steps=20)
-    run_l1_case("l1_radam_wd_d32", d=32, n=96, B=2, T=16, steps=8, optimizer="radam", scheduler="cosine",
-                lr=1e-3, recon_alpha=1e2, seed=2, weight_decay=0.01, total_steps=8)
-    run_l1_case("l1_radam_cosine_d384", d=384, n=256, B=2, T=64, steps=3, optimizer="radam", scheduler="cosine",
-                lr=4e-4, recon_alpha=1e4, seed=3, total_steps=100)
-    run_topk_case("topk_adam_linear_d16", d=16, n=64, k=4, B=3, T=8, steps=6, lr=1e-3, seed=4,
-                  auxk_alpha=0.03125, dead_threshold=40.0, warmup=2)
-    run_topk_case("topk_adam_linear_d64", d=64, n=512, k=16, B=2, T=32, steps=4, lr=1e-4, seed=5,
-                  auxk_alpha=0.0, dead_threshold=1e6, warmup=2)
-    run_topk_case("topk_multi_d32", d=32, n=256, k=8, B=2, T=16, steps=5, lr=1e-3, seed=6,
-                  auxk_alpha=0.03125, dead_threshold=40.0, warmup=2, multi_topk=True)
-    run_train_loop_case(SummaryWriter, "trainloop_l1", "l1")
-    run_train_loop_case(SummaryWriter, "trainloop_topk", "topk")
-    run_sampler_case()
+    only = set(sys.argv[1:])          # fixture names to (re)generate; none = all
+    cases = {
+        "l1_radam_cosine_d16": lambda: run_l1_case("l1_radam_cosine_d16", d=16, n=64, B=4, T=8, steps=5, optimizer="radam",
+                                                   scheduler="cosine", lr=4e-4, recon_alpha=1e4, seed=0, total_steps=100),
+        "l1_adam_linear_d48": lambda: run_l1_case("l1_adam_linear_d48", d=48, n=200, B=3, T=20, steps=6, optimizer="adam",
+                                                  scheduler="linear", lr=1e-3, recon_alpha=1.0, seed=1,
+                                                  sched_params={"num_warmup_steps": 3}, total_steps=20),
+        "l1_radam_wd_d32": lambda: run_l1_case("l1_radam_wd_d32", d=32, n=96, B=2, T=16, steps=8, optimizer="radam",
+                                               scheduler="cosine", lr=1e-3, recon_alpha=1e2, seed=2, weight_decay=0.01,
+                                               total_steps=8),
+        "l1_radam_cosine_d384": lambda: run_l1_case("l1_radam_cosine_d384", d=384, n=256, B=2, T=64, steps=3,
+                                                    optimizer="radam", scheduler="cosine", lr=4e-4, recon_alpha=1e4, seed=3,
+                                                    total_steps=100),
+        "topk_adam_linear_d16": lambda: run_topk_case("topk_adam_linear_d16", d=16, n=64, k=4, B=3, T=8, steps=6, lr=1e-3,
+                                                      seed=4, auxk_alpha=0.03125, dead_threshold=40.0, warmup=2),
+        "topk_adam_linear_d64": lambda: run_topk_case("topk_adam_linear_d64", d=64, n=512, k=16, B=2, T=32, steps=4, lr=1e-4,
+                                                      seed=5, auxk_alpha=0.0, dead_threshold=1e6, warmup=2),
+        "topk_multi_d32": lambda: run_topk_case("topk_multi_d32", d=32, n=256, k=8, B=2, T=16, steps=5, lr=1e-3, seed=6,
+                                                auxk_alpha=0.03125, dead_threshold=40.0, warmup=2, multi_topk=True),
+        "topk_tiefree_d64": run_tie_free_topk_case,
+        "trainloop_l1": lambda: run_train_loop_case(SummaryWriter, "trainloop_l1", "l1"),
+        "trainloop_topk": lambda: run_train_loop_case(SummaryWriter, "trainloop_topk", "topk"),
+        "sampler_order": run_sampler_case,
+    }
+    unknown = only - set(cases)
+    if unknown:
+        raise SystemExit(f"unknown fixture(s) {sorted(unknown)}; known: {sorted(cases)}")
+    for name, fn in cases.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":
