@@ -99,9 +99,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the data-parallel code path even with one rank (test hook)")
     ap.add_argument("--dp-payload", default="float32", choices=["float32", "bfloat16"],
                     help="gradient payload of the in-engine all-reduce (bfloat16: fused d=384 path only, half the bytes)")
-    ap.add_argument("--dp-host", action="store_true",
-                    help="data parallel through torch.distributed from Python (statistics + gradient-range all-reduces) instead "
-                         "of the engine's own RCCL communicator")
+    ap.add_argument("--dp", default=None, choices=["auto", "p2p", "rccl", "host"],
+                    help="data-parallel exchange (freud_amd/dp.py): p2p = the engine's own kernels over hipIpc peer mappings, rccl = "
+                         "the engine's own RCCL communicator, host = torch.distributed from Python; default FREUD_DP or auto")
+    ap.add_argument("--dp-host", action="store_true", help="same as --dp host")
+    ap.add_argument("--dp-overlap", type=int, default=1,
+                    help="fused d=384 backward in this many column-tile ranges, each exchanged under the next one's backward (p2p)")
     ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
@@ -161,24 +164,16 @@ def main():
     # Data parallel: the engine's own RCCL communicator (sae_dist_init) runs the whole protocol -- batch statistics and
     # gradient ranges all-reduced on a communication stream under the forward / backward kernels -- inside step(); --dp-host
     # drives the same protocol from Python through torch.distributed (the host-side variant train() keeps for CPU tests).
-    grads, works = None, []
-    if use_dist and not args.dp_host:
-        ids = [SaeEngine.dist_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ok = 1
-        try:
-            eng.dist_init(ids[0], rank, world)
-            if args.dp_payload == "bfloat16":
-                eng.dist_set_payload("bfloat16")
-        except Exception as e:              # the engine's communicator could not be created here: say so and keep going
-            print(f"[rank {rank}] in-engine RCCL unavailable ({e}); falling back to the host-driven protocol", file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
-        if int(flag.item()) == 0:
-            args.dp_host = True
+    grads, works, dp_mode = None, [], "none"
+    if use_dist:
+        from freud_amd import dp
+        mode = "host" if args.dp_host else (args.dp or dp.requested_mode())
+        dp_mode = dp.setup(eng, dist, rank, world, torch.device("cuda", local_rank), mode=mode, payload=args.dp_payload,
+                           overlap=args.dp_overlap)
+        args.dp_host = dp_mode == "host"
+    elif args.dp_overlap > 1:
+        eng.dist_set_overlap(args.dp_overlap)          # timing the range-split backward by itself
     if use_dist and args.dp_host:
-        eng.set_dp_world(world)
         grads = eng.grad_tensor()
         eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     total_steps, base_lr = 100000, 4e-4
@@ -212,7 +207,9 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    eng.profile(1)
+    # the dominant kernel is bracketed with HIP events on a SAMPLE of the timed steps (an event pair costs ~6 us of idle GPU
+    # between dependent kernels): every 8th step of a long run, every 2nd of a short one (the driver's 20-step run: 10 samples)
+    eng.profile(1, period=8 if args.steps > 64 else 2)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -228,6 +225,8 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if dp_mode in ("p2p", "rccl"):
+        eng.dist_check()                                 # a timed-out exchange must not produce a number
     times = eng.kernel_times()
     metrics = eng.metrics()
     eng.profile(0)
@@ -275,15 +274,24 @@ def main():
     except Exception:
         traffic, traffic_source = None, None
 
+    # what the exchange really carries: the bf16 payload and the column ranges exist on the fused d=384 L1 path only
+    fused = args.variant == "l1" and args.precision == "bf16" and (d + 127) // 128 * 128 == 384
+    eff_payload = args.dp_payload if (fused and dp_mode in ("p2p", "rccl")) else "float32"
+    dp_desc = {"none": "none", "host": "host-driven (torch.distributed)",
+               "p2p": f"in-engine peer exchange over hipIpc mappings, {eff_payload} gradients"
+                      + (f", backward in {args.dp_overlap} column ranges" if fused and args.dp_overlap > 1 else ""),
+               "rccl": f"in-engine RCCL, {eff_payload} gradients"}[dp_mode]
+    model_name = {384: "tiny", 512: "base", 768: "small", 1024: "medium", 1280: "large"}.get(d, f"d={d}")
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_s": args.spinup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
-        "config": {"workload": f"tiny d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
-                               f"RAdam+cosine, x {args.x_dtype} resident in HBM (BASELINE configs[1])",
+        "config": {"workload": f"Whisper-{model_name} d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
+                               f"RAdam+cosine, x {args.x_dtype} resident in HBM"
+                               + (" (BASELINE configs[1])" if (d, n, M) == (384, 3072, 65536) else ""),
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}",
-                   "dp": (("host-driven (torch.distributed)" if args.dp_host else f"in-engine RCCL, {args.dp_payload} gradients") if use_dist else "none")},
+                   "dp": dp_desc},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,

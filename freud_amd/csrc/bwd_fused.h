@@ -47,7 +47,8 @@ struct BwdFusedArgs {
   float* slab;         // [splits][384][n_p]
   float* db_part;      // [splits][n_p]
   int n_p;
-  int ntiles;          // n_p / 128
+  int ntiles;          // column tiles of this launch (n_p / 128, or one column range of them)
+  int tile0;           // first column tile of the launch (column-range launches; 0 otherwise)
   int splits;
   int steps_total;     // M_p / 32
   unsigned long long* clk;   // diagnostic (bench.py --dbg 66), normally null: [wg][4] = s_memtime / s_memrealtime around the loop
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int nblk = a.ntiles * a.splits;
   const int id = xcd_remap(blockIdx.x, nblk);
-  const int split = id / a.ntiles, ntile = id - split * a.ntiles;
+  const int split = id / a.ntiles, ntile = a.tile0 + id - split * a.ntiles;
   const int step_begin = (int)((int64_t)a.steps_total * split / a.splits);
   const int step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
   unsigned long long clk_k0 = 0;

@@ -16,7 +16,10 @@
 #include "gemm256_fp8.h"
 #include "l1_fp8.h"
 #include "dp_kernels.h"
+#include "p2p_exchange.h"
 #include <rccl/rccl.h>
+#include <mutex>
+#include <unistd.h>
 
 static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
@@ -57,6 +60,8 @@ static int fail(int code, const char* fmt, ...) {
 // dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: remember (function, device) pairs
 static int ensure_lds_attr(const void* fn, int bytes, int device) {
   static std::vector<std::pair<const void*, int>> done;
+  static std::mutex mu;                     // contexts of several host threads share the cache
+  std::lock_guard<std::mutex> lock(mu);
   for (const auto& e : done)
     if (e.first == fn && e.second == device) return SAE_OK;
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -138,6 +143,7 @@ struct sae_ctx {
   unsigned int* masked = nullptr;
   int dw_splits = 1;
   int bwd_splits = 1;       // row ranges of the fused backward
+  int bwd_range_splits = 1; // ... when it is launched in column-tile ranges (bwd_ranges > 1)
   bool use_fused_bwd = false;
   // ---- TopK variant (topkautoencoder.py): flat params [We (n_p*d_p) | be (n_p) | Wd (n_p*d_p) | bd (d_p)]
   bool topk = false;
@@ -195,11 +201,30 @@ struct sae_ctx {
   int payload = SAE_DTYPE_F32;  // SAE_DTYPE_BF16: the fused d = 384 path all-reduces a bf16 copy of the gradient (sae_dist_set_payload)
   bf16_t* Gb = nullptr;         // that copy
   bool grads_in_bf16 = false;   // the current step's summed gradient lives in Gb (the optimizer step converts it back)
+  int dist_error = 0;           // a collective of the current call failed to enqueue (message in dist_errmsg)
+  char dist_errmsg[256] = "";
+  // peer exchange over hipIpc mappings (p2p_exchange.h): the exchange of the in-engine protocol when sae_p2p_init was called
+  bool p2p = false;
+  int p2p_rank = 0;
+  float* p2p_G[P2P_MAX_WORLD] = {};
+  bf16_t* p2p_Gb[P2P_MAX_WORLD] = {};
+  double* p2p_stats[P2P_MAX_WORLD] = {};
+  unsigned long long* p2p_sig[P2P_MAX_WORLD] = {};
+  void* p2p_opened[4 * P2P_MAX_WORLD] = {};      // peer mappings to close
+  int p2p_nopened = 0;
+  unsigned long long* sig = nullptr;             // this rank's flag block (uncached device memory)
+  unsigned int* p2p_status = nullptr;            // device word the exchange kernels set on a barrier timeout
+  unsigned long long p2p_epoch[P2P_CHANNELS] = {};
+  unsigned long long p2p_timeout_ticks = 200000000ull;     // 2 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS)
+  bool gn_from_exchange = false;                 // gn_part holds the sum of squares of the EXCHANGED gradient
+  int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
+                                // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
   int profile = 0;
-  int64_t prof_tick = 0;        // forward/backward calls since sae_profile (level 1 samples every PROF_PERIOD-th)
+  int64_t prof_tick = 0;        // forward/backward calls since sae_profile (level 1 samples every prof_period-th)
+  int prof_period = 8;
   EvRing ev[KID_COUNT];
   bool ev_init = false;
 };
@@ -218,11 +243,10 @@ static int use_device(const sae_ctx* c) {
 static int dominant_kid(const sae_ctx* c) { return c->topk ? KID_TK_ENC : (c->use_fused_bwd ? KID_BWD_FUSED : KID_DW); }
 // Level 1 brackets the dominant kernel and the whole step on every PROF_PERIOD-th step only: an event record is a packet of
 // its own in the queue and costs ~6 us of idle GPU between two dependent kernels (kernel trace of the C2 step: 3 records
-// per step were 3 % of it), so the timed region of bench.py samples instead of instrumenting every step.
-constexpr int PROF_PERIOD = 8;
+// per step were 3 % of it), so the timed region of bench.py samples instead of instrumenting every step (sae_profile_period).
 static bool ev_on(const sae_ctx* c, int kid) {
   if (c->profile >= 2) return true;
-  return c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL) && (c->prof_tick % PROF_PERIOD) == 0;
+  return c->profile == 1 && (kid == dominant_kid(c) || kid == KID_STEP_TOTAL) && (c->prof_tick % c->prof_period) == 0;
 }
 static void ev_begin(sae_ctx* c, int kid, hipStream_t s) {
   if (ev_on(c, kid)) {
@@ -258,6 +282,26 @@ static int choose_splits(int r128, int c128, int64_t ktiles) {
     if (sp > 1 && ktiles / sp < 8) break;
     const int rounds = (tiles * sp + slots - 1) / slots;
     const double cost = (double)rounds / sp + 0.04 * sp;
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  return best;
+}
+
+// Row ranges ("splits") of the fused d = 384 backward for `ntiles` column tiles of 128 and `steps` 32-row steps: the launch has
+// ntiles x splits workgroups, one per CU at a time (each wave owns its SIMD's register file), so it runs in
+// ceil(ntiles x splits / 256) rounds of steps / splits steps each, plus a prologue + epilogue worth ~5 steps per workgroup,
+// plus one more [384 x cols] fp32 slab written and read back per split.  256 / ntiles, the old rule, left CUs idle whenever
+// ntiles does not divide 256 (n = 12 288: 96 x 2 = 192 workgroups on 256 CUs, a quarter of the backward).
+static int fused_bwd_splits(int ntiles, int steps, int cols) {
+  const double slab_steps = (double)cols * BF_D * 8.0 / 4.0e12 / 1.43e-6;      // slab write + read at ~4 TB/s, in 1.43 us steps
+  int best = 1;
+  double best_cost = 1e300;
+  for (int sp = 1; sp <= 64 && sp <= steps; ++sp) {
+    const int rounds = (ntiles * sp + 255) / 256;
+    const double cost = rounds * ((double)((steps + sp - 1) / sp) + 5.0) + sp * slab_steps;
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best = sp;
@@ -403,6 +447,9 @@ extern "C" void sae_destroy(sae_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
+  for (int i = 0; i < c->p2p_nopened; ++i) (void)hipIpcCloseMemHandle(c->p2p_opened[i]);
+  if (c->sig) (void)hipFree(c->sig);
+  if (c->p2p_status) (void)hipFree(c->p2p_status);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
@@ -479,15 +526,15 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1 && !c->fp8;
   c->use_fused_fwd = (c->d_p == FF_D) && cfg->force_generic != 1 && !c->fp8;
-  {
-    const int ntiles = c->n_p / BF_BN, steps = (int)(Mp / BF_BM);
-    int sp = 256 / ntiles;
-    if (sp < 1) sp = 1;
-    if (sp > 64) sp = 64;
-    if (sp > steps) sp = steps;
-    c->bwd_splits = sp;
-  }
-  int slab_splits = c->use_fused_bwd ? (c->bwd_splits > c->dw_splits ? c->bwd_splits : c->dw_splits) : c->dw_splits;
+  c->bwd_splits = fused_bwd_splits(c->n_p / BF_BN, (int)(Mp / BF_BM), c->n_p);
+  // column-tile ranges (sae_dist_set_overlap, up to 4): a range of ntiles / r tiles is split into more row ranges
+  c->bwd_range_splits = c->bwd_splits;
+  for (int r = 2; r <= 4; ++r)
+    if ((c->n_p / BF_BN) % r == 0) {
+      const int sp = fused_bwd_splits(c->n_p / BF_BN / r, (int)(Mp / BF_BM), c->n_p / r);
+      if (sp > c->bwd_range_splits) c->bwd_range_splits = sp;
+    }
+  int slab_splits = c->use_fused_bwd ? (c->bwd_range_splits > c->dw_splits ? c->bwd_range_splits : c->dw_splits) : c->dw_splits;
   {   // a chunk launch writes splits x (chunk rows x n_p) floats at the chunk's row offset of each slab
     const int64_t need = (int64_t)c->dw_chunk_splits;
     if (need > slab_splits) slab_splits = (int)need;
@@ -680,35 +727,120 @@ extern "C" int sae_set_grad_ready_callback(sae_ctx* c, sae_grad_ready_fn fn, voi
   return SAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// the exchange of the in-engine data-parallel protocol: peer exchange (p2p_exchange.h) or RCCL
+// ------------------------------------------------------------------------------------------
+static void dist_fail(sae_ctx* c, const char* what, const char* detail) {
+  if (!c->dist_error) snprintf(c->dist_errmsg, sizeof(c->dist_errmsg), "%s: %s", what, detail ? detail : "");
+  c->dist_error = 1;
+}
+
+static int p2p_grid(int64_t vectors) {
+  int64_t g = vectors / 1024;
+  if (g < 1) g = 1;
+  if (g > 48) g = 48;
+  return (int)g;
+}
+
+// enqueue one peer exchange of `nseg` segments on stream s (channel 0: statistics, doubles; channel 1: gradient buffer)
+static void p2p_launch(sae_ctx* c, int channel, const P2PSeg* segs, int nseg, int grid, double* gn_part, hipStream_t s) {
+  P2PArgs a{};
+  for (int r = 0; r < c->dp_world; ++r) {
+    a.buf[r] = channel == 0 ? (void*)c->p2p_stats[r] : (void*)c->p2p_G[r];
+    a.bbuf[r] = c->p2p_Gb[r];
+    a.sig[r] = c->p2p_sig[r];
+  }
+  for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+  a.nseg = nseg; a.rank = c->p2p_rank; a.world = c->dp_world; a.channel = channel;
+  a.epoch = ++c->p2p_epoch[channel];
+  a.timeout_ticks = c->p2p_timeout_ticks;
+  a.status = c->p2p_status;
+  a.gn_part = gn_part;
+  if (channel == 0) hipLaunchKernelGGL(p2p_allreduce_kernel<2>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(p2p_allreduce_kernel<4>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
+  if (hipGetLastError() != hipSuccess) dist_fail(c, "peer exchange launch", "hipLaunchKernel failed");
+}
+
+// all-reduce (sum) of the contiguous range [offset, offset + count) of the gradient buffer on stream s
+static void exchange_range(sae_ctx* c, int64_t offset, int64_t count, hipStream_t s) {
+  if (c->p2p) {
+    P2PSeg g{};
+    g.off = offset; g.pitch = count; g.rows = 1; g.cols = (int)count; g.kind = P2P_F32; g.in_norm = 0;
+    if (count > 0x7ffffff0ll) {      // (cols is an int: cut very long ranges into rows of 2^20 elements + a tail segment)
+      const int64_t rows = count >> 20;
+      P2PSeg t = g;
+      g.rows = (int)rows; g.cols = 1 << 20; g.pitch = 1 << 20;
+      t.off = offset + (rows << 20); t.cols = (int)(count - (rows << 20)); t.pitch = t.cols;
+      P2PSeg two[2] = {g, t};
+      p2p_launch(c, 1, two, t.cols > 0 ? 2 : 1, p2p_grid(count / 4), nullptr, s);
+      return;
+    }
+    p2p_launch(c, 1, &g, 1, p2p_grid(count / 4), nullptr, s);
+    return;
+  }
+  const ncclResult_t r = ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, s);
+  if (r != ncclSuccess) dist_fail(c, "ncclAllReduce of a gradient range", ncclGetErrorString(r));
+}
+
 // A contiguous range of the gradient buffer is final in stream order: tell the host (its own all-reduce), or -- with the
-// engine's own communicator -- all-reduce it now on the communication stream, under the backward kernels still to come.
-static int dist_error = 0;
+// engine's own communicator / peer mappings -- all-reduce it now on the communication stream, under the backward kernels still
+// to come.  (The fused d = 384 backward announces its column ranges itself: fused_exchange.)
 static inline void notify_grads(sae_ctx* c, int64_t offset, int64_t count, hipStream_t s) {
   if (count <= 0) return;
   if (c->dist && c->dp_world > 0) {
-    if (c->use_fused_bwd && !c->topk) {
-      // fused d = 384 backward: the whole gradient becomes final at once, nothing is left to overlap with -- the
-      // all-reduce goes on the COMPUTE stream (no cross-stream hand-over: two event hops cost ~20 us of a 600 us step)
-      if (c->payload == SAE_DTYPE_BF16) {     // bf16 copy of the parameters' gradient + the fp32 scalars, one RCCL group
-        const bool ok = ncclGroupStart() == ncclSuccess &&
-                        ncclAllReduce(c->Gb, c->Gb, (size_t)c->nparams, ncclBfloat16, ncclSum, c->comm, s) == ncclSuccess &&
-                        ncclAllReduce(c->G + c->nparams, c->G + c->nparams, (size_t)(count - c->nparams), ncclFloat, ncclSum,
-                                      c->comm, s) == ncclSuccess &&
-                        ncclGroupEnd() == ncclSuccess;
-        if (!ok) dist_error = 1;
-        c->grads_in_bf16 = true;
-      } else if (ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) {
-        dist_error = 1;
-      }
+    hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess) {
+      dist_fail(c, "gradient range hand-over", "event record / wait failed");
       return;
     }
-    hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
-    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess ||
-        ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess)
-      dist_error = 1;
+    exchange_range(c, offset, count, c->comm_stream);
     return;
   }
   if (c->grad_ready) c->grad_ready(c->grad_ready_user, offset, count, (void*)s);
+}
+
+// Fused d = 384 backward, data parallel: column range [c0, c0 + cols) of dW and of db is final on stream s (`last`: with it
+// the loss scalars).  One range = the whole gradient: exchanged in line on the COMPUTE stream (nothing is left to overlap
+// with, and two event hops cost ~20 us of a 600 us step).  Several ranges: each goes to the communication stream and runs
+// under the backward of the next range; the caller joins the streams after the last one.
+static void fused_exchange(sae_ctx* c, int range, int nranges, int c0, int cols, bool last, hipStream_t s) {
+  hipStream_t xs = s;
+  if (nranges > 1) {
+    hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess) {
+      dist_fail(c, "gradient range hand-over", "event record / wait failed");
+      return;
+    }
+    xs = c->comm_stream;
+  }
+  const int64_t tail = SAE_NUM_METRICS;
+  if (c->p2p) {
+    const int kind = c->payload == SAE_DTYPE_BF16 ? P2P_BF16 : P2P_F32;
+    P2PSeg seg[3]{};
+    int ns = 0;
+    if (nranges == 1) { seg[ns].off = 0; seg[ns].pitch = c->nW; seg[ns].rows = 1; seg[ns].cols = (int)c->nW; }
+    else { seg[ns].off = c0; seg[ns].pitch = c->n_p; seg[ns].rows = c->d_p; seg[ns].cols = cols; }
+    seg[ns].kind = kind; seg[ns].in_norm = 1; ++ns;
+    seg[ns].off = c->nW + c0; seg[ns].pitch = cols; seg[ns].rows = 1; seg[ns].cols = cols; seg[ns].kind = kind; seg[ns].in_norm = 1; ++ns;
+    if (last) { seg[ns].off = c->nparams; seg[ns].pitch = tail; seg[ns].rows = 1; seg[ns].cols = (int)tail; seg[ns].kind = P2P_F32; seg[ns].in_norm = 0; ++ns; }
+    const int grid = p2p_grid((int64_t)(c->d_p + 1) * (cols / 4));
+    p2p_launch(c, 1, seg, ns, grid, c->gn_part + (int64_t)range * grid, xs);
+    c->gn_blocks = nranges * grid;
+    c->gn_from_exchange = true;
+    return;
+  }
+  // RCCL: contiguous buffers only -- the whole gradient in one piece (sae_dist_set_overlap refuses ranges without peer mappings)
+  if (c->payload == SAE_DTYPE_BF16) {     // bf16 copy of the parameters' gradient + the fp32 scalars, one RCCL group
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclAllReduce(c->Gb, c->Gb, (size_t)c->nparams, ncclBfloat16, ncclSum, c->comm, xs);
+    if (r == ncclSuccess) r = ncclAllReduce(c->G + c->nparams, c->G + c->nparams, (size_t)tail, ncclFloat, ncclSum, c->comm, xs);
+    const ncclResult_t e = ncclGroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) dist_fail(c, "ncclAllReduce of the bf16 gradient", ncclGetErrorString(r));
+    c->grads_in_bf16 = true;
+  } else {
+    exchange_range(c, 0, c->nparams + tail, xs);
+  }
 }
 
 extern "C" int sae_get_topk_state(sae_ctx* c, int64_t* out, int64_t n) {
@@ -793,6 +925,16 @@ extern "C" int sae_set_dp_world(sae_ctx* c, int world) {
   return SAE_OK;
 }
 
+static int dist_streams_create(sae_ctx* c) {
+  if (c->comm_stream) return SAE_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  for (auto& e : c->ev_range) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return SAE_OK;
+}
+
 extern "C" int sae_dist_unique_id(void* out, int64_t capacity) {
   if (!out || capacity < (int64_t)sizeof(ncclUniqueId)) return fail(SAE_ERR_INVALID, "need %d bytes", (int)sizeof(ncclUniqueId));
   ncclUniqueId id;
@@ -810,11 +952,10 @@ extern "C" int sae_dist_init(sae_ctx* c, const void* unique_id, int64_t id_bytes
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
   NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
-  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  for (auto& e : c->ev_range) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  {
+    int rc_s = dist_streams_create(c);
+    if (rc_s) return rc_s;
+  }
   c->dist = true;
   c->dp_world = world;
   return SAE_OK;
@@ -828,6 +969,157 @@ extern "C" int sae_dist_set_payload(sae_ctx* c, int dtype) {
   USE_DEVICE(c);
   if (dtype == SAE_DTYPE_BF16 && !c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
   c->payload = dtype;
+  return SAE_OK;
+}
+
+// ---- peer exchange over hipIpc mappings (p2p_exchange.h) ----
+struct P2PBlob {                      // what one rank publishes (sae_p2p_export) -- plain bytes, travels by any host channel
+  hipIpcMemHandle_t G, Gb, stats, sig;
+  int64_t n_grad, n_stats;            // floats in G, doubles in stats: must agree between the ranks
+  int32_t pid, device;
+  int32_t magic, pad_;
+};
+constexpr int32_t P2P_MAGIC = 0x50325031;
+
+extern "C" int sae_p2p_blob_bytes(void) { return (int)sizeof(P2PBlob); }
+
+extern "C" int sae_p2p_export(sae_ctx* c, void* out, int64_t capacity) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  if (capacity < (int64_t)sizeof(P2PBlob)) return fail(SAE_ERR_INVALID, "need %d bytes", (int)sizeof(P2PBlob));
+  if (c->dist) return fail(SAE_ERR_STATE, "the context already runs a data-parallel protocol");
+  USE_DEVICE(c);
+  if (!c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
+  if (!c->sig) {
+    // flags the PEERS write and this rank polls: uncached device memory, so that a poll always reaches memory
+    HIP_TRY(hipExtMallocWithFlags((void**)&c->sig, (size_t)P2P_SIG_WORDS * 8, hipDeviceMallocUncached));
+    HIP_TRY(hipMemset(c->sig, 0, (size_t)P2P_SIG_WORDS * 8));
+    HIP_TRY(hipMalloc((void**)&c->p2p_status, 64));
+    HIP_TRY(hipMemset(c->p2p_status, 0, 64));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  P2PBlob b{};
+  HIP_TRY(hipIpcGetMemHandle(&b.G, c->G));
+  HIP_TRY(hipIpcGetMemHandle(&b.Gb, c->Gb));
+  HIP_TRY(hipIpcGetMemHandle(&b.stats, c->stats));
+  HIP_TRY(hipIpcGetMemHandle(&b.sig, c->sig));
+  b.n_grad = c->nparams + SAE_NUM_METRICS + (c->topk ? c->n_p : 0);
+  b.n_stats = c->stats_cap;
+  b.pid = (int32_t)getpid();
+  b.device = c->cfg.device_id;
+  b.magic = P2P_MAGIC;
+  memcpy(out, &b, sizeof(b));
+  return SAE_OK;
+}
+
+static int p2p_selftest(sae_ctx* c);
+
+extern "C" int sae_p2p_init(sae_ctx* c, const void* blobs, int64_t bytes_per_rank, int rank, int world) {
+  if (!c || !blobs) return fail(SAE_ERR_INVALID, "null argument");
+  if (bytes_per_rank != (int64_t)sizeof(P2PBlob)) return fail(SAE_ERR_INVALID, "blob must be %d bytes per rank", (int)sizeof(P2PBlob));
+  if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(SAE_ERR_INVALID, "rank %d / world %d (the peer exchange serves up to %d ranks of one node)", rank, world, P2P_MAX_WORLD);
+  if (c->dist) return fail(SAE_ERR_STATE, "the context already runs a data-parallel protocol");
+  if (!c->sig) return fail(SAE_ERR_STATE, "sae_p2p_export must be called first");
+  USE_DEVICE(c);
+  const P2PBlob* all = reinterpret_cast<const P2PBlob*>(blobs);
+  const int64_t n_grad = c->nparams + SAE_NUM_METRICS + (c->topk ? c->n_p : 0);
+  for (int r = 0; r < world; ++r) {
+    if (all[r].magic != P2P_MAGIC) return fail(SAE_ERR_INVALID, "rank %d: not a sae_p2p_export blob", r);
+    if (all[r].n_grad != n_grad || all[r].n_stats != c->stats_cap)
+      return fail(SAE_ERR_INVALID, "rank %d runs a different model (gradient buffer %lld floats, here %lld)", r,
+                  (long long)all[r].n_grad, (long long)n_grad);
+  }
+  int rc = dist_streams_create(c);
+  if (rc) return rc;
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) {
+      c->p2p_G[r] = c->G; c->p2p_Gb[r] = c->Gb; c->p2p_stats[r] = c->stats; c->p2p_sig[r] = c->sig;
+      continue;
+    }
+    if (all[r].pid == (int32_t)getpid()) return fail(SAE_ERR_INVALID, "rank %d lives in this process: one process per rank", r);
+    void* m[4] = {};
+    const hipIpcMemHandle_t* h[4] = {&all[r].G, &all[r].Gb, &all[r].stats, &all[r].sig};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipIpcOpenMemHandle(&m[i], *h[i], hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return fail(SAE_ERR_HIP, "hipIpcOpenMemHandle (rank %d, buffer %d) failed: %s", r, i, hipGetErrorString(e));
+      c->p2p_opened[c->p2p_nopened++] = m[i];
+    }
+    c->p2p_G[r] = (float*)m[0]; c->p2p_Gb[r] = (bf16_t*)m[1]; c->p2p_stats[r] = (double*)m[2]; c->p2p_sig[r] = (unsigned long long*)m[3];
+  }
+  if (const char* t = getenv("FREUD_P2P_TIMEOUT_MS")) {
+    const long ms = atol(t);
+    if (ms > 0) c->p2p_timeout_ticks = (unsigned long long)ms * 100000ull;
+  }
+  c->p2p = true;
+  c->p2p_rank = rank;
+  c->dist = true;
+  c->dp_world = world;
+  rc = p2p_selftest(c);
+  if (rc) {          // leave the protocol again: the caller may fall back to a host-driven exchange with this context
+    c->p2p = false;
+    c->dist = false;
+    c->dp_world = 0;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < c->p2p_nopened; ++i) (void)hipIpcCloseMemHandle(c->p2p_opened[i]);
+    c->p2p_nopened = 0;
+    (void)hipMemset(c->p2p_status, 0, 64);
+  }
+  return rc;
+}
+
+// every rank fills its gradient buffer (and the bf16 copy) with a rank-dependent pattern, exchanges, and checks the sums:
+// proves mappings, flags and both payloads before the first training step; a rank that cannot reach its peers times out here
+// (status word) instead of corrupting a run.  Collective: every rank runs it inside sae_p2p_init.
+static int p2p_selftest(sae_ctx* c) {
+  hipStream_t s = c->comm_stream;
+  const int64_t n = c->nparams;
+  std::vector<float> keep((size_t)n);
+  HIP_TRY(hipMemcpy(keep.data(), c->G, (size_t)n * 4, hipMemcpyDeviceToHost));
+  unsigned int bad_total = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    hipLaunchKernelGGL(p2p_selftest_fill_kernel, dim3(256), dim3(256), 0, s, c->G, c->Gb, n, c->p2p_rank);
+    P2PSeg g{};
+    g.off = 0; g.pitch = n; g.rows = 1; g.cols = (int)n; g.kind = pass == 0 ? P2P_F32 : P2P_BF16; g.in_norm = 1;
+    p2p_launch(c, 1, &g, 1, p2p_grid(n / 4), c->gn_part, s);
+    HIP_TRY(hipMemsetAsync(c->p2p_status + 1, 0, 4, s));
+    hipLaunchKernelGGL(p2p_selftest_check_kernel, dim3(256), dim3(256), 0, s, c->G, n, c->dp_world, c->p2p_status + 1);
+    unsigned int st[2] = {};
+    HIP_TRY(hipMemcpyAsync(st, c->p2p_status, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st[0] & 1u) return fail(SAE_ERR_HIP, "peer exchange self-test: a peer did not arrive within %.1f s", c->p2p_timeout_ticks / 1e8);
+    bad_total += st[1];
+  }
+  HIP_TRY(hipMemcpy(c->G, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  if (c->dist_error) return fail(SAE_ERR_HIP, "peer exchange self-test: %s", c->dist_errmsg);
+  if (bad_total) return fail(SAE_ERR_HIP, "peer exchange self-test: %u wrong sums", bad_total);
+  return SAE_OK;
+}
+
+extern "C" int sae_dist_set_overlap(sae_ctx* c, int nranges) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (nranges < 1 || nranges > 4) return fail(SAE_ERR_INVALID, "1 to 4 column ranges");
+  if (nranges > 1 && c->dist && !c->p2p) return fail(SAE_ERR_STATE, "column ranges need the peer exchange (RCCL sums contiguous buffers)");
+  if (nranges > 1 && !(c->use_fused_bwd && !c->topk)) return fail(SAE_ERR_INVALID, "column ranges belong to the fused d = 384 backward");
+  if ((c->n_p / BF_BN) % nranges != 0) return fail(SAE_ERR_INVALID, "%d column tiles do not divide into %d ranges", c->n_p / BF_BN, nranges);
+  c->bwd_ranges = nranges;
+  if (nranges > 1)     // (the slab buffer was sized for the largest of these at creation)
+    c->bwd_range_splits = fused_bwd_splits(c->n_p / BF_BN / nranges, (int)(c->max_rows_p / BF_BM), c->n_p / nranges);
+  return SAE_OK;
+}
+
+// Synchronises the context's streams and reports a failure of the in-engine exchange (a peer that never arrived: the
+// exchange kernels give up after the timeout instead of hanging the GPU).
+extern "C" int sae_dist_check(sae_ctx* c) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->dist) return SAE_OK;
+  USE_DEVICE(c);
+  HIP_TRY(hipDeviceSynchronize());
+  if (c->p2p) {
+    unsigned int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->p2p_status, 4, hipMemcpyDeviceToHost));
+    if (st & 1u) return fail(SAE_ERR_HIP, "peer exchange: a peer did not arrive within %.1f s (results of this run are invalid)", c->p2p_timeout_ticks / 1e8);
+  }
+  if (c->dist_error) return fail(SAE_ERR_HIP, "%s", c->dist_errmsg);
   return SAE_OK;
 }
 
@@ -1033,16 +1325,31 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       BwdFusedArgs a{};
       a.dxh = c->dxh; a.xb = c->xb_cur; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
       a.unscaled = c->use_fused_fwd ? 1 : 0;
-      a.n_p = n_p; a.ntiles = n_p / BF_BN; a.steps_total = (int)(Mp / BF_BM);
+      a.n_p = n_p; a.steps_total = (int)(Mp / BF_BM);
       // diagnostic clock stamps go to the second half of the (unused on this path) dpre buffer
       a.clk = c->cfg.debug_flags == 66 ? reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16) : nullptr;
-      splits = c->bwd_splits;
+      // Column-tile ranges (sae_dist_set_overlap; one range otherwise): each range is a launch of its own over ALL rows, split
+      // into enough row ranges to fill the chip; its slabs are reduced and the range's gradient exchanged on the communication
+      // stream while the next range's backward runs.
+      const int nranges = c->bwd_ranges, rtiles = (n_p / BF_BN) / nranges;
+      splits = nranges == 1 ? c->bwd_splits : c->bwd_range_splits;
       if (splits > a.steps_total) splits = a.steps_total;
-      a.splits = splits;
+      a.ntiles = rtiles; a.splits = splits;
       db_rows = splits;
+      const bool dp_now = c->dist && c->dp_world > 0;
+      bf16_t* gb = (dp_now && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr;
       ev_begin(c, KID_BWD_FUSED, s);
       LDS_ATTR(bwd_fused_d384_kernel, BF_LDS_BYTES, g_device);
-      hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+      for (int r = 0; r < nranges; ++r) {
+        a.tile0 = r * rtiles;
+        hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+        if (nranges > 1) {
+          const int c0 = a.tile0 * BF_BN, cols = rtiles * BF_BN;
+          hipLaunchKernelGGL(reduce_grads_range_kernel, dim3(256), dim3(256), 0, s, c->slab, c->nW, splits, c->db_part, db_rows, n_p,
+                             d_p, c0, cols, c->G, c->gn_part + 256 * r, gb);
+          if (dp_now && r + 1 < nranges) fused_exchange(c, r, nranges, c0, cols, false, s);
+        }
+      }
       ev_end(c, KID_BWD_FUSED, s);
       HIP_TRY(hipGetLastError());
     } else {
@@ -1060,7 +1367,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs).  With a gradient-ready hook the GEMM is issued in
       // row chunks of dW (contiguous ranges of the gradient buffer): each chunk is reduced and announced as soon as it
       // is enqueued, so its all-reduce runs under the GEMM of the next chunk.
-      const bool chunked = c->grad_ready != nullptr && c->dw_chunk_rows < d_p;
+      const bool chunked = (c->grad_ready != nullptr || (c->dist && c->dp_world > 0)) && c->dw_chunk_rows < d_p;
       const int chunk_rows = chunked ? c->dw_chunk_rows : d_p;
       if (chunked) splits = c->dw_chunk_splits;
       ev_begin(c, KID_DW, s);
@@ -1086,7 +1393,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       dw_chunked = dw_chunked_any = chunked;
     }
     ev_begin(c, KID_REDUCE, s);
-    if (c->use_fused_bwd) {   // one pass: slabs + db partials -> grads, plus the local gradient sum of squares
+    if (c->use_fused_bwd && c->bwd_ranges > 1) {   // (every range was reduced right behind its launch)
+      c->gn_blocks = 256 * c->bwd_ranges;
+      c->gn_valid = true;
+    } else if (c->use_fused_bwd) {   // one pass: slabs + db partials -> grads, plus the local gradient sum of squares
       const int64_t nW4 = c->nW / 4, n4 = c->nparams / 4;
       int blocks = (int)((n4 + 255) / 256);
       if (blocks > 1024) blocks = 1024;
@@ -1111,7 +1421,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
                        (const float*)nullptr, 0, gs);
   if (backward) {   // everything that was not announced chunk by chunk: [dW] | db | loss scalars
     const int64_t total = c->nparams + SAE_NUM_METRICS;
-    if (dw_chunked_any) notify_grads(c, c->nW, total - c->nW, s);
+    if (c->use_fused_bwd && c->dist && c->dp_world > 0) {      // the last (or only) column range, with the loss scalars
+      const int nr = c->bwd_ranges, cols = n_p / nr;
+      fused_exchange(c, nr - 1, nr, (nr - 1) * cols, cols, true, s);
+    } else if (dw_chunked_any) notify_grads(c, c->nW, total - c->nW, s);
     else notify_grads(c, 0, total, s);
   }
   ev_end(c, KID_STEP_TOTAL, s);
@@ -1516,20 +1829,27 @@ static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, v
   USE_DEVICE(c);
   hipStream_t s = (hipStream_t)stream;
   const bool dp = c->dist && backward;
+  c->gn_from_exchange = false;
   if (dp) {
-    dist_error = 0;
+    c->dist_error = 0;
     HIP_TRY(hipEventRecord(c->ev_x, s));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
     int rc = batch_stats_dispatch(c, x, M, x_dtype, c->comm_stream);
     if (rc) return rc;
-    NCCL_TRY(ncclAllReduce(c->stats, c->stats, (size_t)c->stats_n, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    if (c->p2p) {
+      P2PSeg g{};
+      g.off = 0; g.pitch = c->stats_n; g.rows = 1; g.cols = (int)c->stats_n; g.kind = P2P_F64;
+      p2p_launch(c, 0, &g, 1, p2p_grid(c->stats_n / 2), nullptr, c->comm_stream);
+    } else {
+      NCCL_TRY(ncclAllReduce(c->stats, c->stats, (size_t)c->stats_n, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    }
     HIP_TRY(hipEventRecord(c->ev_stats, c->comm_stream));
   }
   int rc = dispatch_fwd_bwd_inner(c, x, M, x_dtype, s, backward);
   if (rc) return rc;
   if (dp) {
-    if (dist_error) return fail(SAE_ERR_HIP, "RCCL all-reduce of a gradient range failed");
-    if (!(c->use_fused_bwd && !c->topk)) {      // (the fused path all-reduced on the compute stream itself)
+    if (c->dist_error) return fail(SAE_ERR_HIP, "%s", c->dist_errmsg);
+    if (!(c->use_fused_bwd && !c->topk && c->bwd_ranges == 1)) {      // (a single-range fused backward exchanged on the compute stream itself)
       HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
       HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
     }
@@ -1631,7 +1951,9 @@ extern "C" int sae_step(sae_ctx* c, const void* x, int64_t M, int x_dtype, doubl
   int rc = sae_forward_backward(c, x, M, x_dtype, stream);
   if (rc) return rc;
   // (data parallel with global statistics: the all-reduced gradient already is the whole batch's -- grad_scale stays 1)
-  c->step_fused_call = c->dp_world == 0;     // the local sum of squares is only the clip norm without an all-reduce
+  // the sum of squares the backward left is the clip norm when nothing summed the gradient over ranks afterwards -- or when
+  // the peer exchange itself took it from the summed values
+  c->step_fused_call = c->dp_world == 0 || c->gn_from_exchange;
   rc = sae_optimizer_step(c, lr, 1.0, stream);
   c->step_fused_call = false;
   return rc;
@@ -1851,6 +2173,12 @@ extern "C" int sae_profile(sae_ctx* c, int level) {
   c->profile = level;
   c->prof_tick = 0;
   for (auto& r : c->ev) r.n = 0;
+  return SAE_OK;
+}
+
+extern "C" int sae_profile_period(sae_ctx* c, int period) {
+  if (!c || period < 1) return fail(SAE_ERR_INVALID, "bad argument");
+  c->prof_period = period;
   return SAE_OK;
 }
 

@@ -91,6 +91,11 @@ def load() -> C.CDLL:
         "sae_dist_init": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
         "sae_dist_world": (C.c_int, [vp]),
         "sae_dist_set_payload": (C.c_int, [vp, C.c_int]),
+        "sae_p2p_blob_bytes": (C.c_int, []),
+        "sae_p2p_export": (C.c_int, [vp, vp, i64]),
+        "sae_p2p_init": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
+        "sae_dist_set_overlap": (C.c_int, [vp, C.c_int]),
+        "sae_dist_check": (C.c_int, [vp]),
         "sae_set_grad_ready_callback": (C.c_int, [vp, GRAD_READY_FN, vp]),
         "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
@@ -105,6 +110,7 @@ def load() -> C.CDLL:
         "sae_latent_colmax": (C.c_int, [vp, fptr, i64, vp]),
         "sae_debug_read": (C.c_int, [vp, C.c_int, fptr, i64]),
         "sae_profile": (C.c_int, [vp, C.c_int]),
+        "sae_profile_period": (C.c_int, [vp, C.c_int]),
         "sae_kernel_times": (C.c_int, [vp, fptr, C.POINTER(i32), C.c_int]),
         "sae_kernel_name": (C.c_char_p, [C.c_int]),
         "sae_dominant_kernel": (C.c_int, [vp]),
@@ -121,9 +127,10 @@ EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
     "sae_set_grad_ready_callback", "sae_batch_stats", "sae_stats_buffer", "sae_set_dp_world", "sae_dist_unique_id",
-    "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_p2p_blob_bytes", "sae_p2p_export", "sae_p2p_init",
+    "sae_dist_set_overlap", "sae_dist_check", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
-    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_kernel_times",
+    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
 
@@ -321,6 +328,29 @@ class SaeEngine:
         """"float32" (default, exact) or "bfloat16" (fused d=384 path: half the all-reduce bytes)."""
         _check(self._lib.sae_dist_set_payload(self._ctx, DTYPE[dtype]))
 
+    def p2p_export(self) -> bytes:
+        """This rank's blob for the peer exchange (hipIpc handles of the gradient / statistics / flag buffers)."""
+        nbytes = int(self._lib.sae_p2p_blob_bytes())
+        buf = C.create_string_buffer(nbytes)
+        _check(self._lib.sae_p2p_export(self._ctx, buf, nbytes))
+        return buf.raw
+
+    def p2p_init(self, blobs: Sequence[bytes], rank: int, world: int) -> None:
+        """Map the peers from the blobs of ALL ranks (rank order) and run the self-test exchange.  Collective.  Afterwards
+        forward_backward() / step() run the data-parallel protocol with the engine's own exchange kernels."""
+        assert len(blobs) == world and all(len(b) == len(blobs[0]) for b in blobs)
+        joined = b"".join(blobs)
+        buf = C.create_string_buffer(joined, len(joined))
+        _check(self._lib.sae_p2p_init(self._ctx, buf, len(blobs[0]), int(rank), int(world)))
+
+    def dist_set_overlap(self, nranges: int) -> None:
+        """Fused d=384 backward in `nranges` column-tile ranges, each exchanged under the next one's backward."""
+        _check(self._lib.sae_dist_set_overlap(self._ctx, int(nranges)))
+
+    def dist_check(self) -> None:
+        """Synchronise and raise if an in-engine exchange failed (a peer never arrived)."""
+        _check(self._lib.sae_dist_check(self._ctx))
+
     def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))
 
@@ -428,7 +458,10 @@ class SaeEngine:
         _check(self._lib.sae_debug_read(self._ctx, which, out.ctypes.data_as(C.POINTER(C.c_float)), count))
         return out
 
-    def profile(self, level: int) -> None:
+    def profile(self, level: int, period: Optional[int] = None) -> None:
+        """level 1 brackets the dominant kernel with HIP events on every `period`-th step (default 8)."""
+        if period is not None:
+            _check(self._lib.sae_profile_period(self._ctx, int(period)))
         _check(self._lib.sae_profile(self._ctx, level))
 
     def kernel_times(self) -> Dict[str, tuple]:

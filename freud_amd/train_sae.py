@@ -10,9 +10,10 @@ perm[r::R] of every epoch permutation with the per-GPU batch_size of the config.
 the batch statistics the losses normalise by (unmasked-entry count and rows; for TopK the column sums
 behind total_variance) are summed over the ranks first, every rank's backward normalises by the
 global values, and the summed gradients are the whole batch's (include/freud_sae.h).  On GPUs the
-engine does all of it itself on its own RCCL communicator (sae_dist_init: no Python in the step); a
-host-driven variant of the same protocol over torch.distributed serves CPU tests (gloo) and
-FREUD_DP_HOST=1.
+engine does all of it itself (no Python in the step): by default with its own exchange kernels over hipIpc
+peer mappings (freud_amd/dp.py, csrc/p2p_exchange.h), optionally on its own RCCL communicator
+(FREUD_DP=rccl); a host-driven variant of the same protocol over torch.distributed serves CPU tests
+(gloo), FREUD_DP=host and every case where the peers cannot be mapped.
 """
 from __future__ import annotations
 
@@ -376,21 +377,14 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
     # the engine announces them when it can), optimizer.
     grads, works, overlap, in_engine = None, [], False, False
     if use_dist:
-        in_engine = (hasattr(eng, "dist_init") and dist.get_backend() == "nccl" and os.environ.get("FREUD_DP_HOST") != "1")
-        if in_engine:
-            ids = [eng.dist_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ok = 1
-            try:
-                eng.dist_init(ids[0], rank, world)
-            except Exception as e:          # no communicator here: every rank falls back to the host-driven protocol together
-                print(f"[rank {rank}] in-engine RCCL unavailable ({e}); using torch.distributed for the exchange")
-                ok = 0
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            in_engine = int(flag.item()) == 1
+        from freud_amd import dp
+        dp_mode = dp.setup(eng, dist, rank, world, device, mode=dp.requested_mode(),
+                           payload=os.environ.get("FREUD_DP_PAYLOAD", "float32"),
+                           overlap=int(os.environ.get("FREUD_DP_OVERLAP", "1")))
+        in_engine = dp_mode in ("p2p", "rccl")
+        if is_main:
+            print(f"data parallel: {world} ranks, exchange = {dp_mode}")
         if not in_engine:
-            eng.set_dp_world(world)
             grads = eng.grad_tensor()
             overlap = hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
             if overlap:
@@ -426,6 +420,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             rows_done += activations.shape[0] * activations.shape[1] * world
 
             if state["step"] % log_tb_every == 0:           # the only device->host sync of the loop
+                if in_engine:
+                    eng.dist_check()                        # a peer that never arrived: stop, the replicas are out of step
                 m = eng.metrics()
                 if autoencoder_variant == "l1":
                     logger.add_scalar("train/loss", float(m[0]) + float(m[1]), state["step"])
@@ -490,6 +486,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
     logger.close()
     if use_dist:
+        if in_engine:
+            eng.dist_check()
         dist.barrier()
     return state
 

@@ -174,6 +174,30 @@ int sae_dist_world(sae_ctx* ctx);                                      /* 0 with
  * other than the fused one keep fp32. */
 int sae_dist_set_payload(sae_ctx* ctx, int dtype);
 
+/* ---- peer exchange: the same in-engine protocol with the all-reduces done by the engine's own kernels over hipIpc peer
+ * mappings instead of RCCL (on the full xGMI mesh a direct reduce-scatter + all-gather pulls 1/R of
+ * the payload over EVERY link at once and needs three flag round trips, where a ring moves the payload over one link per hop
+ * -- the 4.7 MB gradient of the d = 384 model is latency-bound).  Up to 8 ranks of one node, one process per GPU.  Like the
+ * RCCL form it stands where a DDP wrapper would stand around loss.backward() (train_sae.py:448); results are bit-identical on
+ * every rank (each range is summed once, in rank order, by its owner).
+ *   sae_p2p_blob_bytes  size of the blob one rank publishes;
+ *   sae_p2p_export      allocates the exchange state and writes this rank's blob (hipIpc handles of the gradient buffer, its
+ *                       bf16 copy, the statistics buffer and the flag block) to host memory;
+ *   sae_p2p_init        takes the blobs of ALL ranks (rank order, gathered over any host channel), maps the peers and runs a
+ *                       self-test exchange (collective: every rank must call it; a peer that cannot be reached makes it FAIL
+ *                       after FREUD_P2P_TIMEOUT_MS, default 2000, instead of hanging).  Afterwards sae_forward_backward /
+ *                       sae_step run the data-parallel protocol through the peer exchange; sae_dist_world() == world.
+ *   sae_dist_set_overlap  fused d = 384 path: launch the backward in `nranges` column-tile ranges; each range's gradient is
+ *                       exchanged on the communication stream under the next range's backward (needs the peer exchange:
+ *                       RCCL sums contiguous buffers only).  1 (default) = one launch, exchanged in line.
+ *   sae_dist_check      synchronises and reports a failed exchange (a peer that never arrived: the exchange kernels give up
+ *                       after the timeout -- the replicas are then out of step and the run must stop). */
+int sae_p2p_blob_bytes(void);
+int sae_p2p_export(sae_ctx* ctx, void* blob_out_host, int64_t capacity_bytes);
+int sae_p2p_init(sae_ctx* ctx, const void* all_blobs_host, int64_t bytes_per_rank, int rank, int world);
+int sae_dist_set_overlap(sae_ctx* ctx, int nranges);
+int sae_dist_check(sae_ctx* ctx);
+
 /* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */
 int sae_optimizer_step(sae_ctx* ctx, double lr, double grad_scale, void* stream);
@@ -237,6 +261,7 @@ int sae_debug_read(sae_ctx* ctx, int which, float* out_host, int64_t capacity_fl
  * kernel ids 0..n-1 (ids: sae_kernel_name).  Level 1 samples every 8th step: an event record costs ~6 us of idle GPU
  * between two dependent kernels, which at three records per 0.6 ms step was 3 % of the thing being measured. */
 int sae_profile(sae_ctx* ctx, int level);
+int sae_profile_period(sae_ctx* ctx, int period);   /* level 1 samples every `period`-th step (default 8; short runs use less) */
 int sae_kernel_times(sae_ctx* ctx, float* ms_sum, int32_t* launches, int n);
 const char* sae_kernel_name(int id);        /* NULL past the last id */
 int sae_dominant_kernel(sae_ctx* ctx);      /* id bracketed at level 1 */

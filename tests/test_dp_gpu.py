@@ -181,3 +181,119 @@ def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["rel"] < 1e-6, res
     np.testing.assert_allclose(res["m1"][:4], res["m0"][:4], rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Two REAL processes on one GPU: the in-engine protocol with the peer exchange (csrc/p2p_exchange.h) end to end
+# ------------------------------------------------------------------------------------------------------------------
+_TRAIN_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["FREUD_ROOT"])
+from freud_amd.train_sae import train
+cfg = json.load(open(sys.argv[1]))
+world = int(os.environ.get("WORLD_SIZE", "1"))
+state = train(**cfg, dist_backend="gloo" if world > 1 else None)     # gloo: host channel only (two NCCL ranks cannot share a GPU)
+if world > 1:
+    import torch.distributed as dist
+    dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_children(script, cfg_path, world, extra_env, timeout=900):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, FREUD_ROOT=root, **extra_env)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        if world > 1:      # both ranks on GPU 0: the exchange runs between two processes that share the device
+            env.update(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script, cfg_path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=timeout))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()           # the exact children this test started
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, (so[-2000:], se[-4000:])
+    return outs
+
+
+@pytest.mark.parametrize("case,payload,overlap", [
+    ("l1_fused", "float32", 1),        # d = 384: fused forward / backward, whole gradient exchanged in line
+    ("l1_fused", "bfloat16", 1),       # ... as a bf16 copy (rounded once by the owner of each shard)
+    ("l1_fused", "float32", 2),        # ... backward in two column-tile ranges, range 0 exchanged under range 1's backward
+    ("l1_generic", "float32", 1),      # d = 1280: three-GEMM backward, dW row chunks exchanged under the remaining chunks
+    ("topk", "float32", 1),            # TopK with AuxK: statistics (column sums), did_fire OR, dW_dec before dW_enc
+])
+def test_two_processes_one_gpu_train_like_one_process(tmp_path, case, payload, overlap):
+    """R x B == 1 x RB on REAL kernels with the REAL exchange: two freshly spawned processes (ranks 0 and 1, both on GPU 0)
+    run train() with the in-engine protocol over hipIpc peer mappings -- handles through a gloo group, batch statistics
+    summed before the backward, every gradient range summed by the engine's exchange kernels, self-test at start-up -- and
+    must reproduce a single process that trains on twice the batch: weights / optimizer moments to fp32 summation order
+    (bf16 payload: to the bf16 rounding of the summed gradient), logged losses alike.  Files carry very different numbers of
+    masked (-1) entries, so per-rank means would NOT average to the whole batch's (l1autoencoder.py:29-36)."""
+    import copy
+    import json
+    import os
+    from freud_amd.loader import write_shards
+    d, n, T = {"l1_fused": (384, 1024, 64), "l1_generic": (1280, 512, 32), "topk": (384, 1024, 32)}[case]
+    n_files, B, steps = 16, 2, 4
+    g = torch.Generator().manual_seed(11)
+    rows = ((torch.relu(torch.randn(n_files * T, 16, generator=g)) * 0.2) @ torch.randn(16, d, generator=g)).reshape(n_files, T * d)
+    for f, frac in ((0, 0.5), (3, 0.3), (5, 0.6), (10, 0.2)):
+        idx = torch.randperm(T * d, generator=g)[: int(frac * T * d)]
+        rows[f, idx] = -1.0
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, "enc", rows.numpy(), [T, d])
+    base = {
+        "whisper_config": {"model": "tiny", "layer_name": "enc"}, "seed": 0, "train_folder": folder, "val_folder": folder,
+        "device": "cuda", "lr": 1e-3, "weight_decay": 0.0, "steps": steps, "clip_thresh": 1.0, "dl_max_workers": 0,
+        "log_tb_every": 1, "save_every": 2, "val_every": 1000, "scheduler_params": {}, "start_checkpoint": None, "from_disk": True,
+    }
+    if case == "topk":
+        base.update(autoencoder_variant="topk", optimizer="adam", scheduler="cosine",
+                    autoencoder_config={"n_dict_components": n, "k": 8, "auxk_alpha": 0.03125, "normalize_decoder": True,
+                                        "multi_topk": False, "dead_feature_threshold": 100.0})
+    else:
+        base.update(autoencoder_variant="l1", optimizer="radam", scheduler="cosine",
+                    autoencoder_config={"n_dict_components": n, "recon_alpha": 100.0})
+    script = os.path.join(str(tmp_path), "child.py")
+    open(script, "w").write(_TRAIN_CHILD)
+    cfg2 = dict(copy.deepcopy(base), batch_size=B, run_dir=os.path.join(str(tmp_path), "dp2"))
+    cfg1 = dict(copy.deepcopy(base), batch_size=2 * B, run_dir=os.path.join(str(tmp_path), "dp1"))
+    for name, cfg in (("cfg2.json", cfg2), ("cfg1.json", cfg1)):
+        json.dump(cfg, open(os.path.join(str(tmp_path), name), "w"))
+    env = {"FREUD_DP": "p2p", "FREUD_DP_PAYLOAD": payload, "FREUD_DP_OVERLAP": str(overlap), "FREUD_P2P_TIMEOUT_MS": "20000"}
+    outs = _run_children(script, os.path.join(str(tmp_path), "cfg2.json"), 2, env)
+    assert "exchange = p2p" in outs[0][0], outs[0][0][-1000:]
+    _run_children(script, os.path.join(str(tmp_path), "cfg1.json"), 1, {})
+    a = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", f"step{steps}.pth"), map_location="cpu")
+    b = torch.load(os.path.join(cfg1["run_dir"], "checkpoints", f"step{steps}.pth"), map_location="cpu")
+    sc = lambda run: {(json.loads(l)["tag"], json.loads(l)["step"]): json.loads(l)["value"]
+                      for l in open(os.path.join(run, "metrics.jsonl"))}
+    s2, s1 = sc(cfg2["run_dir"]), sc(cfg1["run_dir"])
+    wtol, ltol = (5e-3, 1e-2) if payload == "bfloat16" else (1e-4, 1e-4)
+    for k in a["model"]:
+        assert _rel(a["model"][k].numpy(), b["model"][k].numpy()) < wtol, k
+    tags = ("train/fvu", "train/auxk_loss", "train/grad_norm") if case == "topk" else ("train/loss_recon", "train/loss_l1", "train/grad_norm")
+    for step in range(1, steps + 1):
+        for tag in tags:
+            assert s2[(tag, step)] == pytest.approx(s1[(tag, step)], rel=ltol, abs=1e-7), (tag, step)
