@@ -215,6 +215,7 @@ struct sae_ctx {
   unsigned long long* sig = nullptr;             // this rank's flag block (uncached device memory)
   unsigned int* p2p_status = nullptr;            // device word the exchange kernels set on a barrier timeout
   unsigned long long p2p_epoch[P2P_CHANNELS] = {};
+  unsigned long long p2p_epoch_push = 0;         // epoch of the statistics push inside finalize_losses_kernel
   unsigned long long p2p_timeout_ticks = 200000000ull;     // 2 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS)
   bool gn_from_exchange = false;                 // gn_part holds the sum of squares of the EXCHANGED gradient
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
@@ -228,6 +229,9 @@ struct sae_ctx {
   EvRing ev[KID_COUNT];
   bool ev_init = false;
 };
+
+// fused d = 384 L1 path with the peer exchange: the batch statistics are exchanged inside finalize_losses_kernel (StatsPush)
+static bool inline_stats(const sae_ctx* c) { return c->p2p && c->use_fused_fwd && !c->topk; }
 
 static int use_device(const sae_ctx* c) {
   HIP_TRY(hipSetDevice(c->cfg.device_id));
@@ -991,8 +995,9 @@ extern "C" int sae_p2p_export(sae_ctx* c, void* out, int64_t capacity) {
   if (!c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
   if (!c->sig) {
     // flags the PEERS write and this rank polls: uncached device memory, so that a poll always reaches memory
-    HIP_TRY(hipExtMallocWithFlags((void**)&c->sig, (size_t)P2P_SIG_WORDS * 8, hipDeviceMallocUncached));
-    HIP_TRY(hipMemset(c->sig, 0, (size_t)P2P_SIG_WORDS * 8));
+    // [barrier flags of the exchange kernels | inbox of the statistics push: 2 parities x 8 sources x 4 words]
+    HIP_TRY(hipExtMallocWithFlags((void**)&c->sig, (size_t)(P2P_SIG_WORDS + 64) * 8, hipDeviceMallocUncached));
+    HIP_TRY(hipMemset(c->sig, 0, (size_t)(P2P_SIG_WORDS + 64) * 8));
     HIP_TRY(hipMalloc((void**)&c->p2p_status, 64));
     HIP_TRY(hipMemset(c->p2p_status, 0, 64));
     HIP_TRY(hipDeviceSynchronize());
@@ -1312,9 +1317,17 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
   if (rc) return rc;
   if (c->use_fused_fwd) {  // the fused forward counted the masked entries itself: scal[] and the losses are due now
-    if (gs && c->dist) HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));      // the summed statistics have arrived
+    StatsPush push{};
+    if (gs && inline_stats(c)) {       // peer exchange: the statistics travel inside this kernel (no pass over x, no second stream)
+      for (int r = 0; r < c->dp_world; ++r) push.inbox[r] = c->p2p_sig[r] + P2P_SIG_WORDS;
+      push.rank = c->p2p_rank; push.world = c->dp_world; push.epoch = ++c->p2p_epoch_push;
+      push.timeout_ticks = c->p2p_timeout_ticks; push.status = c->p2p_status; push.gstats_out = c->stats;
+    } else if (gs && c->dist) {
+      HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));      // the summed statistics have arrived
+    }
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)(Mp / 128), c->sq_part,
-                       (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128), gs);
+                       (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128),
+                       push.world > 0 ? (const double*)nullptr : gs, push);
   }
   bool dw_chunked_any = false;
   if (backward) {
@@ -1418,7 +1431,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   if (!c->use_fused_fwd)
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)((Mp / 128) * (n_p / 128)),
                        c->sq_part, (int)((Mp / 128) * (d_p / 128)), c->scal, c->G + c->nparams, M, d, alpha,
-                       (const float*)nullptr, 0, gs);
+                       (const float*)nullptr, 0, gs, StatsPush{});
   if (backward) {   // everything that was not announced chunk by chunk: [dW] | db | loss scalars
     const int64_t total = c->nparams + SAE_NUM_METRICS;
     if (c->use_fused_bwd && c->dist && c->dp_world > 0) {      // the last (or only) column range, with the loss scalars
@@ -1830,8 +1843,8 @@ static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, v
   hipStream_t s = (hipStream_t)stream;
   const bool dp = c->dist && backward;
   c->gn_from_exchange = false;
-  if (dp) {
-    c->dist_error = 0;
+  if (dp) c->dist_error = 0;
+  if (dp && !inline_stats(c)) {
     HIP_TRY(hipEventRecord(c->ev_x, s));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
     int rc = batch_stats_dispatch(c, x, M, x_dtype, c->comm_stream);

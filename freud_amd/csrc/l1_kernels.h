@@ -394,12 +394,30 @@ __global__ __launch_bounds__(256) void reduce_db_kernel(const float* __restrict_
 // scalars scal[0..2] = {count, alpha/count, 1/M} are produced here instead of by finalize_count_kernel.
 // gstats != null (data parallel): every scalar is normalised by the GLOBAL count / rows so that the SUM over the ranks of
 // metrics[0..2] is the loss of the whole batch; metrics[4] stays this rank's own count (it sums to the global one).
+// push.world > 0 (data parallel with the peer exchange, fused forward): the batch statistics are exchanged RIGHT HERE.  The
+// fused forward has just counted this rank's unmasked entries, so instead of a separate pass over x plus an all-reduce on a
+// second stream, thread r of this one-block kernel writes (count, rows, epoch) into rank r's inbox (uncached device memory
+// of the peer, mapped by sae_p2p_init; the epoch last, as a system-scope release) and then polls this rank's own inbox for
+// rank r's triple: one one-way flag latency, no extra kernel, nothing on another stream.  The global values are also left in
+// gstats_out for the kernels that read them later.  Inbox slots alternate with the epoch's parity; a peer's next write to
+// the same slot lies behind two gradient exchanges, i.e. after this read.
+struct StatsPush {
+  unsigned long long* inbox[8];     // inbox[r]: rank r's inbox, [2 parities][8 sources][4 words]
+  int rank, world;
+  unsigned long long epoch;
+  unsigned long long timeout_ticks; // of s_memrealtime (100 MHz)
+  unsigned int* status;             // bit 0 set when a peer's triple did not arrive in time
+  double* gstats_out;               // [2]: global unmasked count, global rows
+};
+
 __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
                                                                 int n_sq, float* scal, float* metrics, int64_t M,
                                                                 int d, float alpha, const float* cnt_part, int n_cnt,
-                                                                const double* gstats) {
+                                                                const double* gstats, StatsPush push) {
   __shared__ double red[3][16];
   __shared__ double redc[16];
+  __shared__ double peer_stats[8][2];
+  __shared__ double glob[2];
   double a = 0, b = 0, c = 0;
   if (cnt_part) {
     double m = 0;
@@ -407,18 +425,54 @@ __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_p
     m = wave_sum_d(m);
     if ((threadIdx.x & 63) == 0) redc[threadIdx.x >> 6] = m;
     __syncthreads();
+    double tot = 0;
+    for (int k = 0; k < 16; ++k) tot += redc[k];
+    const double local = (double)M * d - tot;
+    if (push.world > 0) {
+      if ((int)threadIdx.x < push.world) {
+        const int r = threadIdx.x;
+        const int slot = (int)(push.epoch & 1) * 32;
+        unsigned long long* dst = push.inbox[r] + slot + push.rank * 4;
+        __hip_atomic_store(dst + 0, (unsigned long long)__double_as_longlong(local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong((double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 2, push.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* src = push.inbox[push.rank] + slot + r * 4;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(src + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != push.epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > push.timeout_ticks) {
+            atomicOr(push.status, 1u);
+            break;
+          }
+        }
+        peer_stats[r][0] = __longlong_as_double((long long)__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        peer_stats[r][1] = __longlong_as_double((long long)__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double gc = 0, gr = 0;
+        for (int r = 0; r < push.world; ++r) {       // rank order: the same bits on every rank
+          gc += peer_stats[r][0];
+          gr += peer_stats[r][1];
+        }
+        glob[0] = gc;
+        glob[1] = gr;
+        push.gstats_out[0] = gc;
+        push.gstats_out[1] = gr;
+      }
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
-      double tot = 0;
-      for (int k = 0; k < 16; ++k) tot += redc[k];
-      const double local = (double)M * d - tot;
-      const double count = gstats ? gstats[0] : local;
+      const double count = push.world > 0 ? glob[0] : (gstats ? gstats[0] : local);
       scal[0] = (float)count;
       scal[1] = alpha / (float)count;
-      scal[2] = 1.0f / (float)(gstats ? gstats[1] : (double)M);
+      scal[2] = 1.0f / (float)(push.world > 0 ? glob[1] : (gstats ? gstats[1] : (double)M));
       scal[3] = (float)local;
     }
     __syncthreads();
   }
+  const bool global_norm = gstats != nullptr || push.world > 0;
+  const double rows_norm = push.world > 0 ? glob[1] : (gstats ? gstats[1] : (double)M);
   for (int i = threadIdx.x; i < n_l1; i += 1024) a += (double)l1_part[i];
   for (int i = threadIdx.x; i < n_sq; i += 1024) {
     b += (double)sq_part[2 * i];
@@ -440,12 +494,12 @@ __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_p
       sq += red[1][k];
       pl += red[2][k];
     }
-    const double count = (double)scal[0], rows = gstats ? gstats[1] : (double)M;
+    const double count = (double)scal[0], rows = rows_norm;
     metrics[0] = (float)((double)alpha * (sq / count));
     metrics[1] = (float)(l1 / rows);
     metrics[2] = (float)(pl / (rows * d));
     metrics[3] = 0.f;
-    metrics[4] = gstats ? scal[3] : scal[0];
+    metrics[4] = global_norm ? scal[3] : scal[0];
     metrics[5] = metrics[6] = metrics[7] = 0.f;
   }
 }

@@ -16,6 +16,7 @@
 //   barrier 1
 //   phase 2    all-gather: every rank copies slice (p, b) from its owner p -- the replicas end up bit-identical;
 //   barrier 2  nobody overwrites its buffer (next step's reduce_grads) while a peer still reads it.
+// (A world of one rank -- the single-GPU test hook -- has nothing to fetch and nobody to wait for after phase 1.)
 // Flags live in device memory allocated uncached (hipDeviceMallocUncached) on every rank; a rank writes its arrival into the
 // PEERS' flag blocks with a system-scope release store and polls its OWN block with system-scope acquire loads.  Flag values
 // are the call's epoch (monotonic, 64 bit): no resets, no ABA.  A poll that outlasts `timeout_ticks` of the 100 MHz
@@ -75,113 +76,105 @@ __device__ __forceinline__ void p2p_barrier(const P2PArgs& a, int slot) {
   __syncthreads();
 }
 
-// element (vector) address helpers: flattened 16-byte-vector index v of the call -> segment, row, column
-struct P2PLoc {
-  int seg;
-  int64_t elem;          // element offset in the segment's buffer
-};
-template <int EPV /* elements per 16-byte vector: 4 (fp32 / bf16 payload) or 2 (fp64) */>
-__device__ __forceinline__ P2PLoc p2p_locate(const P2PArgs& a, int64_t v) {
-  P2PLoc l;
-  l.seg = 0;
-#pragma unroll
-  for (int s = 0; s < P2P_MAX_SEGS - 1; ++s) {       // (walks the segments in order; stops at the one that holds v)
-    const int64_t nv = (int64_t)a.seg[s].rows * (a.seg[s].cols / EPV);
-    const bool next = l.seg == s && s + 1 < a.nseg && v >= nv;
-    v -= next ? nv : 0;
-    l.seg += next ? 1 : 0;
-  }
-  const P2PSeg& g = a.seg[l.seg];
-  const int vpr = g.cols / EPV;
-  const int64_t row = v / vpr;
-  l.elem = g.off + row * g.pitch + (v - row * vpr) * EPV;
-  return l;
-}
-
 __device__ __forceinline__ double p2p_sq(const f32x4& o) {
   return (double)(o[0] * o[0]) + (double)(o[1] * o[1]) + (double)(o[2] * o[2]) + (double)(o[3] * o[3]);
 }
 
-// The exchange kernel.  EPV = 4: fp32 and bf16-payload segments (mixed per segment); EPV = 2: fp64 segments only.
+// The exchange kernel.  EPV = elements per 16-byte vector: 4 = fp32 and bf16-payload segments (mixed per segment),
+// 2 = fp64 segments.  Every SEGMENT is cut into `world` shards of `gridDim.x` slices on its own (a 16-byte vector never
+// straddles two segments, and the address of a vector needs no search for its segment); vector indices are 32 bit.
 template <int EPV>
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
-  int64_t total = 0;
-  for (int s = 0; s < a.nseg; ++s) total += (int64_t)a.seg[s].rows * (a.seg[s].cols / EPV);
-  const int64_t shard = (total + a.world - 1) / a.world;
-  const int64_t slice = (shard + gridDim.x - 1) / gridDim.x;
   // sums of squares of the reduced values, kept PER SHARD: they are added in shard order at the end, not in the order the
   // phases ran (own shard first -- different on every rank), so every replica gets the same clip coefficient bit for bit
   double ss_own = 0, ss[P2P_MAX_WORLD];
 #pragma unroll
   for (int q = 0; q < P2P_MAX_WORLD; ++q) ss[q] = 0;
 
+  // vectors [v0, v1) of slice (q, blockIdx.x) of segment g; address of vector v of segment g
+  auto slice_of = [&](const P2PSeg& g, int q, unsigned& v0, unsigned& v1) {
+    const unsigned total = (unsigned)g.rows * (unsigned)(g.cols / EPV);
+    const unsigned shard = (total + a.world - 1) / a.world, slice = (shard + gridDim.x - 1) / gridDim.x;
+    v0 = q * shard + blockIdx.x * slice;
+    v1 = v0 + slice;
+    if (v1 > (q + 1) * shard) v1 = (q + 1) * shard;
+    if (v1 > total) v1 = total;
+  };
+  auto elem_of = [&](const P2PSeg& g, unsigned v) -> int64_t {
+    if (g.rows == 1) return g.off + (int64_t)v * EPV;
+    const unsigned vpr = (unsigned)(g.cols / EPV), row = v / vpr;
+    return g.off + (int64_t)row * g.pitch + (int64_t)(v - row * vpr) * EPV;
+  };
+
   p2p_barrier(a, 0);
 
   // ---- phase 1: the owner's sum of slice (rank, b) over every rank's copy, in rank order
-  {
-    const int64_t s0 = a.rank * shard + (int64_t)blockIdx.x * slice;
-    int64_t s1 = s0 + slice;
-    if (s1 > (a.rank + 1) * shard) s1 = (a.rank + 1) * shard;
-    if (s1 > total) s1 = total;
-    for (int64_t v = s0 + threadIdx.x; v < s1; v += P2P_THREADS) {
-      const P2PLoc l = p2p_locate<EPV>(a, v);
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const P2PSeg g = a.seg[sgi];
+    unsigned v0, v1;
+    slice_of(g, a.rank, v0, v1);
+    for (unsigned v = v0 + threadIdx.x; v < v1; v += P2P_THREADS) {
+      const int64_t e = elem_of(g, v);
       if constexpr (EPV == 2) {
         typedef __attribute__((ext_vector_type(2))) double f64x2;
-        f64x2 acc = *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[0]) + l.elem);
-        for (int p = 1; p < a.world; ++p) acc += *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[p]) + l.elem);
-        *reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.buf[a.rank]) + l.elem) = acc;
+        f64x2 acc = *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[0]) + e);
+        for (int p = 1; p < a.world; ++p) acc += *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[p]) + e);
+        *reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.buf[a.rank]) + e) = acc;
       } else {
         f32x4 o;
-        if (a.seg[l.seg].kind == P2P_BF16) {
+        if (g.kind == P2P_BF16) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           for (int p = 0; p < a.world; ++p) {
-            const bf16x4 t = *reinterpret_cast<const bf16x4*>(a.bbuf[p] + l.elem);
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(a.bbuf[p] + e);
             acc += f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
           }
           const bf16x4 r = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
-          *reinterpret_cast<bf16x4*>(a.bbuf[a.rank] + l.elem) = r;
+          *reinterpret_cast<bf16x4*>(a.bbuf[a.rank] + e) = r;
           o = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
         } else {
-          o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[0]) + l.elem);
-          for (int p = 1; p < a.world; ++p) o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[p]) + l.elem);
+          o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[0]) + e);
+          for (int p = 1; p < a.world; ++p) o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[p]) + e);
         }
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.buf[a.rank]) + l.elem) = o;
-        if (a.seg[l.seg].in_norm) ss_own += p2p_sq(o);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.buf[a.rank]) + e) = o;
+        if (g.in_norm) ss_own += p2p_sq(o);
       }
     }
   }
 
-  p2p_barrier(a, 1);
+  if (a.world > 1) {
+    p2p_barrier(a, 1);
 
-  // ---- phase 2: fetch every other shard's slice b from its owner
+    // ---- phase 2: fetch every other shard's slice b from its owner
 #pragma unroll
-  for (int q = 0; q < P2P_MAX_WORLD; ++q) {
-    if (q >= a.world || q == a.rank) continue;
-    const int64_t s0 = q * shard + (int64_t)blockIdx.x * slice;
-    int64_t s1 = s0 + slice;
-    if (s1 > (q + 1) * shard) s1 = (q + 1) * shard;
-    if (s1 > total) s1 = total;
-    for (int64_t v = s0 + threadIdx.x; v < s1; v += P2P_THREADS) {
-      const P2PLoc l = p2p_locate<EPV>(a, v);
-      if constexpr (EPV == 2) {
-        typedef __attribute__((ext_vector_type(2))) double f64x2;
-        *reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.buf[a.rank]) + l.elem) =
-            *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[q]) + l.elem);
-      } else {
-        f32x4 o;
-        if (a.seg[l.seg].kind == P2P_BF16) {
-          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.bbuf[q] + l.elem);
-          o = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-        } else {
-          o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[q]) + l.elem);
+    for (int q = 0; q < P2P_MAX_WORLD; ++q) {
+      if (q >= a.world || q == a.rank) continue;
+      for (int sgi = 0; sgi < a.nseg; ++sgi) {
+        const P2PSeg g = a.seg[sgi];
+        unsigned v0, v1;
+        slice_of(g, q, v0, v1);
+        for (unsigned v = v0 + threadIdx.x; v < v1; v += P2P_THREADS) {
+          const int64_t e = elem_of(g, v);
+          if constexpr (EPV == 2) {
+            typedef __attribute__((ext_vector_type(2))) double f64x2;
+            *reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.buf[a.rank]) + e) =
+                *reinterpret_cast<const f64x2*>(reinterpret_cast<const double*>(a.buf[q]) + e);
+          } else {
+            f32x4 o;
+            if (g.kind == P2P_BF16) {
+              const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.bbuf[q] + e);
+              o = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            } else {
+              o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.buf[q]) + e);
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.buf[a.rank]) + e) = o;
+            if (g.in_norm) ss[q] += p2p_sq(o);
+          }
         }
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.buf[a.rank]) + l.elem) = o;
-        if (a.seg[l.seg].in_norm) ss[q] += p2p_sq(o);
       }
     }
-  }
 
-  p2p_barrier(a, 2);
+    p2p_barrier(a, 2);
+  }
 
   if (EPV == 4 && a.gn_part) {
     __shared__ double red[P2P_THREADS / 64];
