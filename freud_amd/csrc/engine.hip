@@ -158,6 +158,7 @@ struct sae_ctx {
   unsigned short* tile_max = nullptr;   // [M_p][n_p / 128] maxima of the pre-activation tiles (tile-driven select)
   unsigned char* sel_flag = nullptr;    // [M_p] rows the tile-driven select left to the general kernel
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
+  bool multi_dense_valid = false;   // the same for the multi-TopK (4k) rows
   // AuxK on the compacted dead set (topk_aux.h)
   float* be_r = nullptr;            // encoder bias rounded to bf16 (as float), refreshed every step
   int slab_splits = 1;              // slabs allocated in c->slab (TopK)
@@ -1495,6 +1496,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   // the masked DENSE rows [M x n] are only written for those who read them: the dense fallbacks and validation / inference
   const bool write_dense = !use_csc;
   c->dense_valid = write_dense;
+  c->multi_dense_valid = write_dense;
   // tile-driven main select (topk_select_tiles_kernel): when no dense row is wanted, every column is a candidate and k fits
   // (rows it cannot take -- too many qualifying tiles or candidates -- fall to the register kernel: n_p <= 2048 * 44)
   const bool tile_select = !write_dense && n == n_p && k <= n_p / 128 && n_p / 128 <= TSEL_MAX_TILES && n_p <= 2048 * 44 &&
@@ -2099,6 +2101,15 @@ extern "C" int sae_multi_topk_buffers(sae_ctx* c, void** dense_dev, int64_t* row
   if (!c || !dense_dev || !row_stride || !idx_dev || !k4) return fail(SAE_ERR_INVALID, "null argument");
   if (!c->topk || !c->multi) return fail(SAE_ERR_INVALID, "sae_multi_topk_buffers: not a TopK context with multi_topk");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
+  if (!c->multi_dense_valid) {      // a training step on the sparse backward keeps the 4k selection compact: densify on demand
+    USE_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(topk_densify_kernel, dim3((unsigned)c->last_M_p), dim3(256), 0, (hipStream_t)0, c->multi_vals, c->multi_idx, c->k4,
+                       c->multi_dense, c->n_p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    c->multi_dense_valid = true;
+  }
   *dense_dev = c->multi_dense;
   *row_stride = c->n_p;
   *idx_dev = c->multi_idx;
@@ -2176,6 +2187,30 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   HIP_TRY(hipMemcpyAsync(tmp.data(), bits, (size_t)c->n_p * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   memcpy(out_host, tmp.data(), (size_t)c->n * 4);
+  return SAE_OK;
+}
+
+// Validation without host round trips (train_sae.py:168-190 runs one file per forward and reads .item() four times per
+// file): forward of one file, then its loss scalars and its per-feature maxima are left in CALLER-OWNED device rows; the
+// host reads all rows once at the end.  Everything is asynchronous on `stream`.
+extern "C" int sae_eval_into(sae_ctx* c, const void* x, int64_t M, int x_dtype, float* metrics_out, float* colmax_out, void* stream) {
+  if (!c || !x || !metrics_out) return fail(SAE_ERR_INVALID, "null argument");
+  int rc = dispatch_fwd_bwd(c, x, M, x_dtype, stream, false);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(metrics_out, c->G + c->nparams, SAE_NUM_METRICS * 4, hipMemcpyDeviceToDevice, s));
+  if (colmax_out) {
+    if (c->topk && !c->dense_valid) return fail(SAE_ERR_STATE, "the evaluation forward did not leave the dense latent rows");
+    HIP_TRY(hipMemsetAsync(colmax_out, 0, (size_t)c->n * 4, s));
+    const int rows_per_block = 256;
+    const int64_t Mr = c->last_M;
+    // (columns [n_dict, n_p) are padding and are not written: the kernel covers whole 256-column blocks below n_dict only
+    // when n_dict is a multiple of 256, so the tail block is guarded by the column bound)
+    dim3 grid((c->n + 255) / 256, (unsigned)((Mr + rows_per_block - 1) / rows_per_block));
+    hipLaunchKernelGGL(latent_colmax_bounded_kernel, grid, dim3(256), 0, s, c->topk ? c->dense : c->c, reinterpret_cast<int*>(colmax_out),
+                       Mr, c->n_p, c->n, rows_per_block);
+    HIP_TRY(hipGetLastError());
+  }
   return SAE_OK;
 }
 

@@ -28,6 +28,13 @@
 
 #include "bwd_fused.h"
 
+// Timing experiments (tools/build_variant.sh <name> -DFF_KO=<bits>; results become WRONG): 1 = no bias / ReLU / L1 arithmetic,
+// 2 = no latent staging / stores, 4 = no LDS-DMA inside the loop, 8 = no decoder fragment reads inside the loop,
+// 16 = latent = S cast to bf16 (no rounding-then-bias, no ReLU, no L1 sum: the price of that arithmetic with live data)
+#ifndef FF_KO
+#define FF_KO 0
+#endif
+
 constexpr int FF_D = 384;
 constexpr int FF_BM = 128;                        // rows per workgroup
 constexpr int FF_BN = 32;                         // dictionary columns per tile
@@ -248,21 +255,22 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       // ---- fragment prefetch (ring carried across iterations)
       {
         const int g = i + DIST;
-        if (g < 24) ring[g % RING] = dec_frag(SLOT_D, g);
+        if (g < 24) { if (!(FF_KO & 8)) ring[g % RING] = dec_frag(SLOT_D, g); }
         else if (g < 48) ring[g % RING] = enc_frag(SLOT_E, g - 24);
-        else ring[g % RING] = dec_frag(SLOT_DN, g - 48);
+        else { if (!(FF_KO & 8)) ring[g % RING] = dec_frag(SLOT_DN, g - 48); }
       }
       if (i < 4) bq[i] = *reinterpret_cast<const f32x4*>(bj + 8 * i + 4 * ah);    // bias of S rows 8 i + 4 h + (0..3)
       if (i == 12) {
         // everything older than the previous iteration's 2 latent stores has completed once <= 2 operations are
         // outstanding: in particular the 6 DMA pieces of tile j+1.  Raw barrier (no fence).
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (FF_KO & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == FF_DMA_G0 || i == FF_DMA_G1 || i == FF_DMA_G2) dma_pair(i == FF_DMA_G0 ? 0 : (i == FF_DMA_G1 ? 1 : 2), jt, SLOT_DMA);
-      if ((PH & 1) == 0 && i == FF_DMA_G2 + 2 && w == 0) {
+      if (!(FF_KO & 4) && (i == FF_DMA_G0 || i == FF_DMA_G1 || i == FF_DMA_G2)) dma_pair(i == FF_DMA_G0 ? 0 : (i == FF_DMA_G1 ? 1 : 2), jt, SLOT_DMA);
+      if (!(FF_KO & 4) && (PH & 1) == 0 && i == FF_DMA_G2 + 2 && w == 0) {
         // bias of tiles j+2, j+3 (64 floats) -> ring slots (j+2) % 8, (j+3) % 8; past the end the last pair is re-copied
         const int jb = j + 2 <= a.ntiles - 2 ? j + 2 : a.ntiles - 2;
         glds4(a.bias + (int64_t)jb * FF_BN, (unsigned)(lane * 4),
@@ -270,14 +278,14 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
       }
       // latent element e at gap 6 + 5 (e >> 1) + 2 (e & 1): gaps 6, 8, 11, 13, ..., 41, 43 (computed from the unrolled
       // loop index itself: a lookup table made hipcc emit all 16 elements' work in ONE gap)
-      if (i >= 6 && i < 46 && ((i - 6) % 5 == 0 || (i - 6) % 5 == 2)) {
+      if (!(FF_KO & 1) && i >= 6 && i < 46 && ((i - 6) % 5 == 0 || (i - 6) % 5 == 2)) {
         const int e = 2 * ((i - 6) / 5) + ((i - 6) % 5 == 2);   // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
         // pre-activation rounded to bf16 BEFORE the fp32 bias add, as CPU autocast does (l1autoencoder.py:74)
-        float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
+        float cv = (FF_KO & 16) ? S[e] : fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);
         if (PAD) cv = row_ok ? cv : 0.f;
-        l1_it += cv;
+        if (!(FF_KO & 16)) l1_it += cv;
         cfn[e >> 3][e & 7] = (bf16_t)cv;
-        if ((e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
+        if (!(FF_KO & 2) && (e & 3) == 3) {   // 4 consecutive columns ready: 8 bytes into the staging image
           const int k = e >> 2;
           const bf16x4 o = {cfn[e >> 3][(e & 7) - 3], cfn[e >> 3][(e & 7) - 2], cfn[e >> 3][(e & 7) - 1], cfn[e >> 3][e & 7]};
           const int chunk = 4 * (PH & 1) + k;              // 16-B chunk of the 128-B row; +8 bytes for h = 1
@@ -287,11 +295,11 @@ __global__ __launch_bounds__(256, 1) void fwd_fused_d384_kernel(FwdFusedArgs a) 
         }
       }
       // two full-line pieces of the finished pair per iteration: LDS read in one gap, global store 8 gaps later
-      if (i == 29 || i == 34) {
+      if (!(FF_KO & 2) && (i == 29 || i == 34)) {
         const int r = 8 * (2 * (PH & 1) + (i == 34)) + drow_l;
         dr[i == 34] = *reinterpret_cast<const u32x4*>(cst_r + r * 128 + ((dch ^ (r & 7)) << 4));
       }
-      if (i == 37 || i == 42) {
+      if (!(FF_KO & 2) && (i == 37 || i == 42)) {
         const int p = 2 * (PH & 1) + (i == 42);
         // written once, read once by the backward after 400 MB more of it: non-temporal, it must not evict W^T / x lines
         // odd pieces hold rows with bit 3 set: their 8-byte halves were stored swapped (see the staging write)

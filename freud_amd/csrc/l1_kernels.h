@@ -531,6 +531,18 @@ __global__ __launch_bounds__(256) void latent_colmax_kernel(const bf16_t* __rest
   atomicMax(out_bits + col, __float_as_int(m));
 }
 
+// the same into a caller-owned row of exactly n (un-padded) columns
+__global__ __launch_bounds__(256) void latent_colmax_bounded_kernel(const bf16_t* __restrict__ c, int* __restrict__ out_bits,
+                                                                     int64_t M, int n_p, int n, int rows_per_block) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float m = 0.f;
+  for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, (float)c[r * n_p + col]);
+  atomicMax(out_bits + col, __float_as_int(m));
+}
+
 struct OptArgs {
   float lr, grad_scale, clip_thresh, weight_decay;
   float beta1, beta2, eps;

@@ -102,6 +102,7 @@ def load() -> C.CDLL:
         "sae_set_topk_options": (C.c_int, [vp, dbl, i64]),
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+        "sae_eval_into": (C.c_int, [vp, vp, i64, C.c_int, vp, vp, vp]),
         "sae_latent_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_topk_indices": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
         "sae_decode": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp]),
@@ -130,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_p2p_blob_bytes", "sae_p2p_export", "sae_p2p_init",
     "sae_dist_set_overlap", "sae_dist_check", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
-    "sae_step", "sae_eval", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
+    "sae_step", "sae_eval", "sae_eval_into", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
 
@@ -363,6 +364,19 @@ class SaeEngine:
         self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_eval(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    def eval_into(self, x, metrics_row, colmax_row=None, stream=None) -> None:
+        """eval() of one file with its 8 loss scalars (and per-feature latent maxima) left in the given fp32 CUDA rows:
+        no host synchronisation (validate() reads all rows once at the end)."""
+        self._note_shape(x)
+        x, ptr, rows, dt = self._x_args(x)
+        assert metrics_row.is_cuda and metrics_row.is_contiguous() and metrics_row.numel() >= NUM_METRICS
+        cm = None
+        if colmax_row is not None:
+            assert colmax_row.is_cuda and colmax_row.is_contiguous() and colmax_row.numel() >= self.n
+            cm = C.c_void_p(colmax_row.data_ptr())
+        _check(self._lib.sae_eval_into(self._ctx, C.c_void_p(ptr), rows, dt, C.c_void_p(metrics_row.data_ptr()), cm,
+                                       self._stream(stream)))
 
     # -- inference (SURVEY section 8 row f3) ---------------------------------------------------------
     def latent_buffer(self):

@@ -123,7 +123,8 @@ class MemoryMappedActivationDataLoader:
         # direct mode: the shard mapping is host-registered (pinned in place) so that rows travel to HBM by DMA straight
         # from the page cache, without a CPU gather into staging buffers (measured on the MI355X host: the whole train()
         # loop 25.5 M fp16 activations/s against 18-22 M staged, with no gather threads).  Registration faults in and pins
-        # the whole file, so it is automatic only while the shard fits in half of the host's available memory
+        # the whole file, so it is automatic only while the shard fits in this rank's share of a quarter of the host's available
+        # memory and in 32 GiB
         # (FREUD_LOADER_DIRECT_MAX_GB overrides the limit; train-other-500 at ~342 GB stays staged on most hosts and is
         # disk-bound anyway); FREUD_LOADER_DIRECT=1 forces it, =0 disables it; any failure to register (no GPU,
         # locked-memory limit, mapping larger than RAM) silently keeps the staged path.  Converting delivery needs the
@@ -132,7 +133,13 @@ class MemoryMappedActivationDataLoader:
         self._registered = None
         mode = os.environ.get("FREUD_LOADER_DIRECT", "auto")
         limit = os.environ.get("FREUD_LOADER_DIRECT_MAX_GB")
-        limit = int(float(limit) * (1 << 30)) if limit else _mem_available_bytes() // 2
+        if limit:
+            limit = int(float(limit) * (1 << 30))
+        else:
+            # every rank of a node registers (faults in and PINS) the whole shard, and each samples MemAvailable before the
+            # others have pinned: the automatic limit is this rank's share of a quarter of the free memory, at most 32 GiB
+            local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+            limit = min(_mem_available_bytes() // 4 // local_world, 32 << 30)
         small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= limit
         if self.device.type == "cuda" and not self._convert and (mode == "1" or (mode not in ("0",) and small)):
             self._try_register()

@@ -223,14 +223,28 @@ def validate(engine, val_folder: str, device, layer_name: str, from_disk: bool, 
     (The Whisper-transcript part of the reference's validate needs Whisper weights: out of scope.)"""
     loader, _, _ = init_dataloader(from_disk, val_folder, "", None, layer_name, device, 1, 1, None, {"shuffle": False})
     recon, l1, mses, maxes, multi = [], [], [], [], []
-    for acts, _names in loader:
-        engine.eval(acts)
-        m = engine.metrics()
-        recon.append(float(m[0]))
-        l1.append(float(m[1]))
-        mses.append(float(m[2]))
-        multi.append(float(m[6]))
-        maxes.append(engine.latent_colmax())
+    if hasattr(engine, "eval_into"):
+        # every file's loss scalars and per-feature maxima stay in device rows; ONE read-back at the end (the reference
+        # synchronises four times per file with .item(), train_sae.py:173-190)
+        n_files = len(loader)
+        met = torch.zeros((max(n_files, 1), 8), dtype=torch.float32, device=device)
+        cmx = torch.zeros((max(n_files, 1), engine.n), dtype=torch.float32, device=device)
+        i = 0
+        for acts, _names in loader:
+            engine.eval_into(acts, met[i], cmx[i])
+            i += 1
+        m = met[:i].cpu().numpy()          # the one synchronisation
+        recon, l1, mses, multi = list(m[:, 0]), list(m[:, 1]), list(m[:, 2]), list(m[:, 6])
+        maxes = list(cmx[:i].cpu().numpy())
+    else:
+        for acts, _names in loader:
+            engine.eval(acts)
+            m = engine.metrics()
+            recon.append(float(m[0]))
+            l1.append(float(m[1]))
+            mses.append(float(m[2]))
+            multi.append(float(m[6]))
+            maxes.append(engine.latent_colmax())
     mag = np.stack(maxes) if maxes else np.zeros((0, engine.n), np.float32)
     losses = {"l1": float(np.mean(l1)) if variant == "l1" and l1 else None,
               "recon": float(np.mean(recon)) if variant == "l1" and recon else None,

@@ -241,6 +241,12 @@ int sae_decode(sae_ctx* ctx, const void* latent_dev, int latent_dtype, int64_t l
  * out.encoded / out.sae_out when multi_topk is set (topkautoencoder.py:134-147 re-binds the names); encode() keeps k. */
 int sae_multi_topk_buffers(sae_ctx* ctx, void** dense_dev, int64_t* row_stride, void** idx_dev, int* k4);
 
+/* validate() without per-file host round trips (train_sae.py:168-190 reads four .item()s per file): sae_eval of one file,
+ * then its SAE_NUM_METRICS loss scalars go to metrics_out_dev[8] and -- unless colmax_out_dev is NULL -- its per-feature
+ * maxima of |latent| (train_sae.py:176-178) to colmax_out_dev[n_dict]; both are CALLER-OWNED device rows (one pair per
+ * file), so a whole validation folder is enqueued without a single synchronisation and read back once.  Asynchronous. */
+int sae_eval_into(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, float* metrics_out_dev, float* colmax_out_dev, void* stream);
+
 /* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
 int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);
 

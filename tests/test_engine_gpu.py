@@ -102,6 +102,15 @@ def test_eval_and_latent_colmax_match_oracle(d, n, M, generic):
     assert cm.shape == (n,)
     np.testing.assert_allclose(cm, ref, rtol=2 ** -7, atol=1e-6)
     assert np.array_equal(cm == 0, ref == 0) or (np.abs(cm - ref)[(cm == 0) != (ref == 0)] < 1e-3).all()
+    # the synchronisation-free form validate() uses (sae_eval_into): rows on the device, the same numbers (a second forward
+    # renormalises the already normalised columns again: last-bit differences in W, hence no bitwise equality)
+    met = torch.zeros(2, 8, device="cuda")
+    cmx = torch.full((2, n), -1.0, device="cuda")
+    eng.eval_into(x.cuda(), met[1], cmx[1])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(met[1].cpu().numpy(), m, rtol=1e-4)
+    assert float(met[0].abs().sum()) == 0.0 and float(cmx[0].max()) == -1.0          # the neighbouring rows are untouched
+    np.testing.assert_allclose(cmx[1].cpu().numpy(), cm, rtol=2 ** -7, atol=1e-6)
     eng.close()
 
 

@@ -4,5 +4,5 @@
 set -e
 name=$1; shift
 mkdir -p build/ab
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value "$@" -shared -o build/ab/libfreud_sae_$name.so freud_amd/csrc/engine.hip
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value "$@" -shared -o build/ab/libfreud_sae_$name.so freud_amd/csrc/engine.hip -L/opt/rocm/lib -lrccl
 echo build/ab/libfreud_sae_$name.so
