@@ -392,7 +392,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
     TALLOC(c->m2_part, Mp * 4);
   }
   // reserved switches: topk_dense_backward = 1 dense ddense GEMM, 2 = sparse d pre-activations + dense weight-gradient GEMMs
-  c->topk_csc = c->topk_sparse_da && c->n_p <= CSC_MAX_NP && c->cfg.topk_dense_backward == 0;
+  c->topk_csc = c->topk_sparse_da && c->cfg.topk_dense_backward == 0;
   if (c->topk_csc) {
     const int64_t nb = (Mp + CSC_ROWS - 1) / CSC_ROWS;
     // (the AuxK entries enter the CSC lists only where the compact dead-set path does not apply)
@@ -1625,14 +1625,15 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (aux && !auxc) { ps.idx[1] = c->aux_idx; ps.vals[1] = c->aux_vals; ps.g[1] = c->dh_b; ps.kcap[1] = c->k_aux_cap; ps.gated[1] = 1; }
       ps.idx[2] = c->top_idx; ps.vals[2] = c->top_vals; ps.g[2] = c->de_b; ps.kcap[2] = k;
       const int nb = (int)((M + CSC_ROWS - 1) / CSC_ROWS);
-      const int lds = n_p * 2;
+      const int nseg = (n_p + CSC_MAX_NP - 1) / CSC_MAX_NP;            // dictionary segments of the counting kernels
+      const int lds = (n_p < CSC_MAX_NP ? n_p : CSC_MAX_NP) * 2;
       ev_begin(c, KID_TK_DDENSE, s);
-      hipLaunchKernelGGL(csc_count_kernel, dim3(nb), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_counts);
+      hipLaunchKernelGGL(csc_count_kernel, dim3(nb, nseg), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_counts);
       hipLaunchKernelGGL(csc_scan_blocks_kernel, dim3((n_p + 63) / 64), dim3(1024), 0, s, c->csc_counts, nb, n_p, c->csc_block_off,
                          c->csc_total);
       hipLaunchKernelGGL(csc_scan_latents_kernel, dim3(1), dim3(1024), 0, s, c->csc_total, n_p, c->csc_start, c->csc_item_start);
       hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent);
-      hipLaunchKernelGGL(csc_fill_kernel, dim3(nb), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_block_off, c->csc_start, c->csc_entries);
+      hipLaunchKernelGGL(csc_fill_kernel, dim3(nb, nseg), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_block_off, c->csc_start, c->csc_entries);
       ev_end(c, KID_TK_DDENSE, s);
       ev_begin(c, KID_TK_DWD, s);
       {

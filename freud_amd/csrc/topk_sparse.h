@@ -15,7 +15,8 @@
 // slots of a latent in order: run-to-run bitwise identical, no float atomics.
 //
 // CSC build (stable counting sort by latent):
-//   1. csc_count:  one WAVE per block of CSC_ROWS rows counts its entries per latent in LDS (u16 counters, n_p <= 32768);
+//   1. csc_count:  one WAVE per block of CSC_ROWS rows counts its entries per latent in LDS (u16 counters; the dictionary in
+//                  segments of 32 768 latents, one wave per (row block, segment): any n_p);
 //   2. csc_scan_blocks: per latent, exclusive prefix over the row blocks (+ the latent's total);
 //   3. csc_scan_latents: exclusive prefix over the latents (list starts) and over the work-item counts;
 //   4. csc_fill:   the same wave walks its rows IN ORDER; an LDS add-with-return hands every entry its rank inside
@@ -25,7 +26,7 @@
 #include "topk_kernels.h"
 
 constexpr int CSC_ROWS = 64;          // rows per counting block (one wave)
-constexpr int CSC_MAX_NP = 32768;     // u16 LDS counters: 64 KiB per wave
+constexpr int CSC_MAX_NP = 32768;     // latents per counting segment (u16 LDS counters: 64 KiB per wave)
 constexpr int CSC_CHUNK = 256;        // entries per work item of the gradient kernel
 
 struct SparsePasses {                 // autograd's execution order: multi-TopK, AuxK, main
@@ -42,12 +43,15 @@ struct CscEntry {                     // 8 bytes
 };
 
 // ---- 1. counts[b][j] (u16) --------------------------------------------------------------------------------------------
+// (grid.y = dictionary segments of CSC_MAX_NP latents: a wave counts only the entries of its segment, so any n_p fits the
+// 64 KiB of u16 counters; the rows' index lists are read once per segment -- 16 MB per pass against the gathers' 13 GB)
 __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const int* __restrict__ tk, int64_t M, int n_p,
                                                        unsigned short* __restrict__ counts) {
-  extern __shared__ unsigned int ctr32[];                     // n_p / 2 words = n_p u16 counters
+  extern __shared__ unsigned int ctr32[];                     // segment / 2 words = one u16 counter per latent of the segment
   const int lane = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
-  for (int i = lane; i < n_p / 2; i += 64) ctr32[i] = 0u;
+  const int seg0 = blockIdx.y * CSC_MAX_NP, seg1 = min(seg0 + CSC_MAX_NP, n_p), segn = seg1 - seg0;
+  for (int i = lane; i < segn / 2; i += 64) ctr32[i] = 0u;
   __syncthreads();
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
@@ -61,12 +65,13 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
       for (int r = 0; r < CSC_ROWS; ++r) v[r] = (q < kcap && r0 + r < M) ? ps.idx[pass][(r0 + r) * kcap + q] : -1;
 #pragma unroll
       for (int r = 0; r < CSC_ROWS; ++r)
-        if (v[r] >= 0) atomicAdd(&ctr32[v[r] >> 1], (v[r] & 1) ? 0x10000u : 1u);   // (a block holds < 65536 entries of a latent)
+        if (v[r] >= seg0 && v[r] < seg1)
+          atomicAdd(&ctr32[(v[r] - seg0) >> 1], (v[r] & 1) ? 0x10000u : 1u);   // (a block holds < 65536 entries of a latent)
     }
   }
   __syncthreads();
-  unsigned int* out = reinterpret_cast<unsigned int*>(counts + (int64_t)blockIdx.x * n_p);
-  for (int i = lane; i < n_p / 2; i += 64) out[i] = ctr32[i];
+  unsigned int* out = reinterpret_cast<unsigned int*>(counts + (int64_t)blockIdx.x * n_p + seg0);
+  for (int i = lane; i < segn / 2; i += 64) out[i] = ctr32[i];
 }
 
 // ---- 2. per latent: exclusive prefix over the row blocks, total -----------------------------------------------------------
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
   extern __shared__ unsigned int ctr32[];
   const int lane = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
-  for (int i = lane; i < n_p / 2; i += 64) ctr32[i] = 0u;
+  const int seg0 = blockIdx.y * CSC_MAX_NP, seg1 = min(seg0 + CSC_MAX_NP, n_p), segn = seg1 - seg0;    // as in csc_count_kernel
+  for (int i = lane; i < segn / 2; i += 64) ctr32[i] = 0u;
   __syncthreads();
   const unsigned int* boff = block_off + (int64_t)blockIdx.x * n_p;
   for (int pass = 0; pass < 3; ++pass) {
@@ -166,9 +172,9 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
 #pragma unroll
       for (int r = 0; r < CSC_ROWS; ++r) {
         const int j = v[r];
-        if (j < 0) continue;
+        if (j < seg0 || j >= seg1) continue;
         // rank inside (block, latent): LDS add with return; one wave, program order, distinct j within a (row, pass)
-        const unsigned int old = atomicAdd(&ctr32[j >> 1], (j & 1) ? 0x10000u : 1u);
+        const unsigned int old = atomicAdd(&ctr32[(j - seg0) >> 1], (j & 1) ? 0x10000u : 1u);
         const unsigned int rank = (j & 1) ? (old >> 16) : (old & 0xFFFFu);
         CscEntry e;
         e.row_pass = (unsigned int)(r0 + r) | ((unsigned int)pass << 30);

@@ -426,6 +426,8 @@ def test_topk_multi_topk_sparse_path_matches_oracle():
     (768, 24576, 64, 2, 256, "reg12"),      # BASELINE configs[2] at its real n and k (register select, 12 vectors / thread)
     (384, 32768, 32, 2, 64, "reg44"),       # n_p > 24 576: topk_select_reg_kernel<44>
     (384, 98304, 32, 1, 64, "generic"),     # n_p > 90 112: the radix-select fallback (topk_select_kernel)
+    (1280, 40960, 32, 1, 64, "csc2"),       # large-v3 with the reference's default expansion 32 (config.py:7): n_p > 32 768, the
+                                            # sparse backward's counting sort runs in two dictionary segments
 ])
 def test_topk_real_dictionary_sizes_match_oracle(d, n, k, B, T, kernel):
     """The configs[2] shape at full n / k against the oracle (M = 512 rows), and the two select kernels that only large
