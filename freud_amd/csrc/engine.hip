@@ -134,6 +134,8 @@ struct sae_ctx {
   void* grad_ready_user = nullptr;
   int dw_chunk_rows = 0;       // generic L1 path: rows (of d_p) per weight-gradient GEMM launch when a hook is set
   int dw_chunk_splits = 1;     // its split-K factor
+  int dw_col_chunks = 1;       // ... with the peer exchange: COLUMN chunks of dW instead (each reads only its own columns of the
+  int dw_col_splits = 1;       //     latent / dpre streams, where a row chunk re-reads all of them), and their split-K factor
   float* cnt_part = nullptr;   // fused forward: per-workgroup masked-entry counts
   int gn_blocks = 0;
   bool step_fused_call = false; // set by sae_step: forward_backward and optimizer_step back to back
@@ -527,6 +529,13 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // models finish their gradient in one piece); the chunk's split-K factor keeps its launch rounds full
   c->dw_chunk_rows = c->d_p >= 1024 ? 512 : c->d_p;
   c->dw_chunk_splits = choose_splits(c->dw_chunk_rows / 128, c->n_p / 128, 2 * Mp / 64);
+  if (c->d_p >= 1024 && c->n_p % 256 == 0)
+    for (int q = 4; q >= 2; --q)
+      if ((c->n_p / 256) % q == 0) {
+        c->dw_col_chunks = q;
+        break;
+      }
+  c->dw_col_splits = choose_splits(c->d_p / 128, c->n_p / 128 / c->dw_col_chunks, 2 * Mp / 64);
   // fused backward (bwd_fused.h) is specialised for a padded d_model of 384; force_generic forces the
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1 && !c->fp8;
@@ -541,7 +550,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     }
   int slab_splits = c->use_fused_bwd ? (c->bwd_range_splits > c->dw_splits ? c->bwd_range_splits : c->dw_splits) : c->dw_splits;
   {   // a chunk launch writes splits x (chunk rows x n_p) floats at the chunk's row offset of each slab
-    const int64_t need = (int64_t)c->dw_chunk_splits;
+    const int64_t need = (int64_t)(c->dw_chunk_splits > c->dw_col_splits ? c->dw_chunk_splits : c->dw_col_splits);
     if (need > slab_splits) slab_splits = (int)need;
   }
   const int64_t db_rows = (Mp / 128) > 64 ? (Mp / 128) : 64;
@@ -802,6 +811,19 @@ static inline void notify_grads(sae_ctx* c, int64_t offset, int64_t count, hipSt
     return;
   }
   if (c->grad_ready) c->grad_ready(c->grad_ready_user, offset, count, (void*)s);
+}
+
+// the same for a 2-D block of the gradient buffer (rows x cols at element offset `off`, `pitch` elements between rows):
+// peer exchange only (callers check c->p2p)
+static inline void exchange_block(sae_ctx* c, int64_t off, int rows, int cols, int64_t pitch, hipStream_t s) {
+  hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
+  if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess) {
+    dist_fail(c, "gradient block hand-over", "event record / wait failed");
+    return;
+  }
+  P2PSeg g{};
+  g.off = off; g.pitch = pitch; g.rows = rows; g.cols = cols; g.kind = P2P_F32; g.in_norm = 0;
+  p2p_launch(c, 1, &g, 1, p2p_grid((int64_t)rows * (cols / 4)), nullptr, c->comm_stream);
 }
 
 // Fused d = 384 backward, data parallel: column range [c0, c0 + cols) of dW and of db is final on stream s (`last`: with it
@@ -1381,11 +1403,35 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       // dW = dx_hat^T c + x^T dpre   (K = 2 M, split-K partial slabs).  With a gradient-ready hook the GEMM is issued in
       // row chunks of dW (contiguous ranges of the gradient buffer): each chunk is reduced and announced as soon as it
       // is enqueued, so its all-reduce runs under the GEMM of the next chunk.
-      const bool chunked = (c->grad_ready != nullptr || (c->dist && c->dp_world > 0)) && c->dw_chunk_rows < d_p;
+      // Peer exchange: COLUMN chunks of dW (a [d_p x cols] block of the gradient is a strided 2-D segment, which the exchange
+      // kernel takes as it is): every chunk reads only its own columns of the latent / dpre streams, so chunking costs no
+      // extra HBM traffic -- row chunks (the contiguous ranges RCCL and the host callback need) re-read both 5.4 GB streams
+      // once per chunk: +1.5 ms of the 30 ms C4 step on one rank.
+      const bool col_chunked = c->dist && c->dp_world > 0 && c->p2p && c->dw_col_chunks > 1;
+      if (col_chunked) {
+        const int cols = n_p / c->dw_col_chunks;
+        ev_begin(c, KID_DW, s);
+        for (int q = 0; q < c->dw_col_chunks; ++q) {
+          const int col0 = q * cols;
+          GemmArgs g{};
+          g.A0 = c->dxh; g.B0 = c->c + col0; g.A1 = c->xb_cur; g.B1 = c->dpre + col0; g.lda = d_p; g.ldb = n_p;
+          g.nbm = d_p / 128; g.nbn = cols / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
+          g.splits = c->dw_col_splits > g.ktiles ? g.ktiles : c->dw_col_splits;
+          EpiSlab e{};
+          e.slab = c->slab + col0; e.slab_stride = c->nW; e.ld = n_p;
+          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+          if (rc) return rc;
+          hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3(512), dim3(256), 0, s, c->slab, c->nW, g.splits, n_p, d_p, col0, cols, c->G);
+          exchange_block(c, col0, d_p, cols, n_p, s);
+        }
+        ev_end(c, KID_DW, s);
+        dw_chunked = dw_chunked_any = true;
+      }
+      const bool chunked = !col_chunked && (c->grad_ready != nullptr || (c->dist && c->dp_world > 0)) && c->dw_chunk_rows < d_p;
       const int chunk_rows = chunked ? c->dw_chunk_rows : d_p;
       if (chunked) splits = c->dw_chunk_splits;
-      ev_begin(c, KID_DW, s);
-      for (int r0 = 0; r0 < d_p; r0 += chunk_rows) {
+      if (!col_chunked) ev_begin(c, KID_DW, s);
+      for (int r0 = 0; r0 < d_p && !col_chunked; r0 += chunk_rows) {
         const int rows = d_p - r0 < chunk_rows ? d_p - r0 : chunk_rows;
         GemmArgs g{};
         g.A0 = c->dxh + r0; g.B0 = c->c; g.A1 = c->xb_cur + r0; g.B1 = c->dpre; g.lda = d_p; g.ldb = n_p;
@@ -1403,8 +1449,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           notify_grads(c, 4 * off4, 4 * n4, s);
         }
       }
-      ev_end(c, KID_DW, s);
-      dw_chunked = dw_chunked_any = chunked;
+      if (!col_chunked) {
+        ev_end(c, KID_DW, s);
+        dw_chunked = dw_chunked_any = chunked;
+      }
     }
     ev_begin(c, KID_REDUCE, s);
     if (c->use_fused_bwd && c->bwd_ranges > 1) {   // (every range was reduced right behind its launch)

@@ -229,6 +229,21 @@ __global__ __launch_bounds__(256) void reduce_grads_range_kernel(const float* __
   if (threadIdx.x == 0) gn_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// dW rows [0, d_p) x columns [c0, c0 + cols) of the generic weight-gradient GEMM's split-K slabs -> gradient buffer (the
+// column chunks of the d >= 1024 path under the peer exchange)
+__global__ __launch_bounds__(256) void reduce_slabs_range_kernel(const float* __restrict__ slab, int64_t slab_stride, int splits, int n_p,
+                                                                  int d_p, int c0, int cols, float* __restrict__ grad) {
+  const int vpr = cols / 4;
+  const int64_t nv = (int64_t)d_p * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / vpr;
+    const int64_t o = row * n_p + c0 + (i - row * vpr) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(slab + o);
+    for (int k = 1; k < splits; ++k) a += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * slab_stride + o);
+    *reinterpret_cast<f32x4*>(grad + o) = a;
+  }
+}
+
 // Self-test pattern of sae_p2p_init: element i of rank r = pattern(r, i); after the exchange every element must be the sum
 // over the ranks.  Small integers: exact in fp32 and in bf16 (|value| < 256).
 __global__ void p2p_selftest_fill_kernel(float* buf, bf16_t* bbuf, int64_t n, int rank) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for one round, run ON the GPU box from the repo root (gpurun -- bash tools/profile_round.sh r02):
-#   1. bench lines (un-profiled): default C2, forced data-parallel (in-engine RCCL fp32 / bf16 payload, host-driven),
+#   1. bench lines (un-profiled): default C2, forced data-parallel (peer exchange fp32 / bf16 payload, RCCL, host-driven),
 #      C3 (TopK), C4, C5 bf16 and fp8 shapes                                  -> gpurun_out/prof_<tag>/bench_*.json
 #   2. --kernel-trace --stats of the default bench (program directly after "--", a SHORT spin-up of 0.2 s and 3000 timed
 #      steps: the --stats averages cover every launch of the run, and the ~300 launches on ramping clocks of the spin-up
@@ -10,7 +10,7 @@
 #   4. PMC passes of the default bench, each in its own run (never combined with traces): FETCH_SIZE, WRITE_SIZE, SQ
 # tools/parse_pmc.py turns the counter CSVs into profiles/<tag>_hbm_traffic.json afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -21,6 +21,9 @@ $B --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_default_driver_style.js
 $B --no-cpu-baseline --force-dist > "$OUT/bench_forcedist.json" 2> "$OUT/bench_forcedist.err"
 $B --no-cpu-baseline --force-dist --dp-payload bfloat16 > "$OUT/bench_forcedist_bf16.json" 2>> "$OUT/bench_forcedist.err"
 $B --no-cpu-baseline --force-dist --dp-host > "$OUT/bench_forcedist_host.json" 2>> "$OUT/bench_forcedist.err"
+$B --no-cpu-baseline --force-dist --dp rccl > "$OUT/bench_forcedist_rccl.json" 2>> "$OUT/bench_forcedist.err"
+$B --no-cpu-baseline --force-dist --dp p2p --dp-overlap 2 > "$OUT/bench_forcedist_overlap2.json" 2>> "$OUT/bench_forcedist.err"
+$B --no-cpu-baseline --variant topk --d 1280 --n 40960 --k 32 --steps 20 --warmup 5 --dead-threshold 1e15 --breakdown > "$OUT/bench_topk_d1280_n40960.json" 2> "$OUT/bench_topk_d1280.err"
 $B --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 50 --warmup 5 --dead-threshold 1e15 --breakdown > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
 $B --no-cpu-baseline --variant topk --d 768 --n 24576 --k 64 --steps 50 --warmup 5 --dead-threshold 1e5 --breakdown > "$OUT/bench_c3_auxk.json" 2>> "$OUT/bench_c3.err"
 $B --no-cpu-baseline --d 1280 --n 40960 --steps 20 --warmup 3 --breakdown > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
