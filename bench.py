@@ -358,8 +358,9 @@ def main():
         st = eng.debug_read(5, (M // 128) * 32).reshape(-1, 8)
         st = st[st[:, 3] > 0]
         per = st[:, :3] / st[:, 3:4]
-        print("fwd stamps (cycles/iteration, median over waves): decoder gaps 0-11 %.0f | decoder gaps 12-23 (+barrier, DMA) %.0f | "
-              "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
+        if per.sum() > 0:      # (the per-phase stamps exist in fwd_fused.h only)
+            print("fwd stamps (cycles/iteration, median over waves): decoder gaps 0-11 %.0f | decoder gaps 12-23 (+barrier, DMA) %.0f | "
+                  "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
         print("fwd in-kernel clock %.0f MHz (median), loop cycles/iteration %.0f" %
               (np.median(st[:, 4] / st[:, 5]) * 100.0, np.median(st[:, 4] / st[:, 3])), file=sys.stderr)
         print("fwd per-workgroup cycles (median): prologue %.0f | loop %.0f | epilogue %.0f | whole %.0f" %

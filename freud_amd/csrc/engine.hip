@@ -25,6 +25,7 @@ static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every G
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
+#include "fwd_fused2.h"
 #include "topk_kernels.h"
 #include "topk_sparse.h"
 #include "topk_aux.h"
@@ -126,6 +127,7 @@ struct sae_ctx {
   unsigned char *x8 = nullptr, *c8 = nullptr, *W8 = nullptr, *W8t = nullptr;
   float *scal8 = nullptr, *x8_part = nullptr;
   bool use_fused_fwd = false;
+  int fwd_variant = 2;          // fused forward: 2 = fwd_fused2.h (decoder split along d), 1 = fwd_fused.h (FREUD_FWD=1: A/B, stamps)
   bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
@@ -540,6 +542,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // generic three-GEMM path (used by the tests to cover both)
   c->use_fused_bwd = (c->d_p == BF_D) && cfg->force_generic != 1 && !c->fp8;
   c->use_fused_fwd = (c->d_p == FF_D) && cfg->force_generic != 1 && !c->fp8;
+  if (const char* fv = getenv("FREUD_FWD")) c->fwd_variant = atoi(fv) == 1 ? 1 : 2;
   c->bwd_splits = fused_bwd_splits(c->n_p / BF_BN, (int)(Mp / BF_BM), c->n_p);
   // column-tile ranges (sae_dist_set_overlap, up to 4): a range of ntiles / r tiles is split into more row ranges
   c->bwd_range_splits = c->bwd_splits;
@@ -1265,9 +1268,19 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     };
     ev_begin(c, KID_FWD_FUSED, s);
     int rcl = SAE_OK;
-    if (full_wgs > 0 && c->cfg.debug_flags == 65) {   // diagnostic: stamps into the (unused here) dpre buffer
+    if (full_wgs > 0 && c->cfg.debug_flags == 65 && c->fwd_variant != 2) {   // diagnostic: stamps into the (unused here) dpre buffer
       a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
       rcl = launch(fwd_fused_d384_kernel<T, false, true>, full_wgs, 0);
+    } else if (c->fwd_variant == 2) {               // the second decomposition (fwd_fused2.h)
+      if (full_wgs > 0 && c->cfg.debug_flags == 65) {
+        a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
+        rcl = launch(fwd_fused2_d384_kernel<T, false, true>, full_wgs, 0);
+      } else if (full_wgs > 0) rcl = launch(fwd_fused2_d384_kernel<T, false>, full_wgs, 0);
+      if (!rcl && all_wgs > full_wgs) rcl = launch(fwd_fused2_d384_kernel<T, true>, all_wgs - full_wgs, full_wgs);
+      if (rcl) return rcl;
+      ev_end(c, KID_FWD_FUSED, s);
+      HIP_TRY(hipGetLastError());
+      return SAE_OK;
     } else if (full_wgs > 0) {
       rcl = launch(fwd_fused_d384_kernel<T, false, false>, full_wgs, 0);
     }

@@ -1,0 +1,422 @@
+// Fused forward of the tied-weight L1 SAE for d_model (padded) == 384 on gfx950, second decomposition.
+// Same arithmetic, same outputs and the same arguments as fwd_fused_d384_kernel (fwd_fused.h; reference
+// src/models/l1autoencoder.py:69-95, mse_loss :29-36); what changes is who multiplies what in the DECODER product.
+//
+// Why: in fwd_fused.h every MFMA takes its A operand from LDS (W^T rows for the encoder, transposed reads of the same image for
+// the decoder) -- 1 KiB per MFMA and wave, 4 waves, 32 cycles per MFMA = 128 B/clk, which IS the LDS bandwidth of a CU.  With
+// the DMA writes, bias and staging traffic on top the kernel asks for ~165 B/clk at full matrix rate and runs at ~82 % of the
+// LDS peak: 60-63 % MFMA busy, and knocking out the decoder's fragment reads alone returns 16 % (profiles/r03_fwd_knockouts.txt).
+// Register blocking is the only way to feed more than one MFMA per fragment, and the [384 x 32] fp32 x_hat^T tile per wave
+// (192 accumulator registers) leaves no room for a second row block.  So the decoder is split along d instead of along rows:
+//
+//   encoder (unchanged): wave w computes S^T[32 n x 32 rows of ITS row block] = W^T tile . x^T   (x fragments in registers)
+//   bias / ReLU / L1 (unchanged) -> c^T of the row block, written to the latent staging image in LDS -- which already exists
+//           (it feeds the full-line stores of the latent) and now doubles as the exchange buffer between the waves;
+//   decoder: wave w owns the d-SLICE [96 w, 96 w + 96) of x_hat^T for ALL 128 rows of the workgroup:
+//           x_hat^T[96 x 128] += W[96 x 32 n] . c^T[32 n x 128]  =  6 W fragments (transposed reads) x 8 c^T fragments
+//           (ds_read_b128 from the staging image) for the same 24 MFMAs: every W fragment feeds 4 MFMAs, every c^T fragment 3.
+//
+// LDS reads per iteration and wave: 24 + 12 + 8 instead of 24 + 48; bytes 38 KiB instead of 48 KiB + ...; the accumulator
+// budget is the same 192 registers ([96 x 128] = 12 tiles).  The price is one dependency across waves per tile: c^T of tile j
+// is written during iteration j, published by the iteration's single barrier (at MFMA 40, which also hands over the DMA'd
+// W^T tile as before) and multiplied in iteration j + 1.
+//
+// Staging image: two pair buffers [128 rows][128 B]; a row holds tiles 2t and 2t + 1 (64 B each) as four 16-byte chunks per
+// tile, chunk (s, h) = the eight latents n = 16 s + 8 (q >> 2) + 4 h + (q & 3), q = 0..7 -- exactly the eight values lane
+// (row, h) holds after the encoder for k-step s, and exactly the k order the transposed W reads deliver (tr_frag_perm), so
+// writer and reader move whole 16-byte chunks; the chunk index is XORed with (row & 7) (conflict-free for both).  The drain to
+// HBM reassembles natural column order from two 8-byte halves.
+#pragma once
+#include "fwd_fused.h"
+
+// STAMP: diagnostic build (bench.py --dbg 65): s_memtime / s_memrealtime around the tile loop per wave into a.stamps[wg][wave][8]
+// ([3] iterations, [4] loop cycles, [5] loop time in 10 ns ticks, [6] prologue cycles, [7] whole-kernel cycles).
+template <typename T, bool PAD, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int arow = lane & 31, ah = lane >> 5;
+  const int wg = blockIdx.x + a.block_offset;
+  const int64_t m0 = (int64_t)wg * FF_BM + 32 * w;             // first row of this wave's row block
+  const int64_t mrow = m0 + arow;
+  const bool row_ok = mrow < a.M;
+  char* cst = smem + FF_RING_BYTES;                             // two pair buffers [128 rows][128 B]
+  float* bias_s = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
+  unsigned long long clk_k0 = 0, clk_t0 = 0, clk_r0 = 0;
+  if (STAMP) clk_k0 = __builtin_amdgcn_s_memtime();
+
+  bf16x8 xfrag[24];
+  {
+    const bf16_t* xp = a.xb + mrow * FF_D + 8 * ah;
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
+  }
+  if (t < 2 * FF_BN) bias_s[t] = a.bias[t];
+  // ring slot 3 and the staging image are read (times zero / as zeros) by the first iteration's decoder phase
+  for (int i = t; i < FF_WT_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t; i < FF_CST_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(cst)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  f32x16 acc[12];                       // acc[4 dtl + mb]: rows d = 96 w + 32 dtl + ..., columns = row block mb
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ---- LDS-DMA plan of a W^T tile (as in fwd_fused.h)
+  unsigned voff_t[6], loff_t[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int inst = w + 4 * i, sub = inst >> 3, row = 4 * (inst & 7) + (lane >> 4), pc = lane & 15;
+    const int ch = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    voff_t[i] = (unsigned)(row * (FF_D * 2) + (sub * 16 + ch) * 16);
+    loff_t[i] = (unsigned)__builtin_amdgcn_readfirstlane(sub * 8192 + (inst & 7) * 1024);
+  }
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  auto dma_pair = [&](int p, int jt, int st) {
+    const bf16_t* src = a.Wt + (int64_t)jt * FF_BN * FF_D;
+    const unsigned dst = smem_base + st * FF_WT_BYTES;
+    glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p])),
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p + 1])));
+  };
+  const int last = a.ntiles - 1;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)                       // prologue: W^T tiles 0, 1, 2 into slots 0, 1, 2
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dma_pair(p, q <= last ? q : last, q);
+#pragma unroll
+  for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(xfrag[kk]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- loop-invariant per-lane LDS offsets
+  int roff[8];                       // encoder: row reads of a W^T tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i) roff[i] = dual_off(arow, 2 * i + ah);
+  // decoder: the six W fragments (k-step ks, slice tile dtl) of this wave's d-slice: two transposed 8-byte reads each
+  int aoff0[6], aoff1[6];
+  {
+    const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      const int ks = f / 3, dt = 3 * w + f % 3;
+      const int col = 32 * (dt & 3) + 16 * g + 4 * p;
+      const int r0 = 4 * ah + q, r1 = r0 + 8;
+      const int base = (dt >> 2) * 8192 + ks * 4096;
+      aoff0[f] = base + dual_off(r0, col >> 3) + (col & 7) * 2;
+      aoff1[f] = base + dual_off(r1, col >> 3) + (col & 7) * 2;
+    }
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr_pair = [&](const char* p0, const char* p1) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  // staging image: byte offset of chunk (tile half hf, k-step s, this lane's h) in row `arow` of a 32-row block
+  int boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) boff[i] = arow * 128 + (((4 * (i >> 1) + 2 * (i & 1) + ah) ^ (arow & 7)) << 4);
+  const int wrow = w * 4096;                                     // this wave's row block inside a pair buffer
+  // drain: piece p = rows 8 p .. 8 p + 7 of the row block; lane -> row 8 p + lane / 8, 16 output bytes = columns 8 o .. 8 o + 7
+  const int drow_l = lane >> 3, dch = lane & 7;
+  int doff0, doff1;
+  {
+    const int tl = dch >> 2, s = (dch & 3) >> 1, u = dch & 1;
+    doff0 = drow_l * 128 + (((4 * tl + 2 * s + 0) ^ drow_l) << 4) + 8 * u;
+    doff1 = drow_l * 128 + (((4 * tl + 2 * s + 1) ^ drow_l) << 4) + 8 * u;
+  }
+  bf16_t* cdrain = a.c + (m0 + drow_l) * a.n_p + dch * 8;
+
+  float l1_acc = 0.f;
+
+  // ---- S(0): encoder product of tile 0 (outside the pipeline)
+  f32x16 Sn;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Sn[r] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 24; ++kk) {
+    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(smem + (kk >> 3) * 8192 + roff[kk & 7]);
+    Sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xfrag[kk], Sn, 0, 0, 0);
+  }
+
+  // ---- pipeline.  Iteration j issues 48 MFMAs, decoder and encoder INTERLEAVED slot by slot:
+  //   even slots: decoder of tile j-1:  acc[4 dtl + mb] += W fragment (ks, dtl) . c^T fragment (mb, ks)      m = 12 ks + 3 mb + dtl
+  //   odd slots:  encoder of tile j+1:  S(j+1) += W^T rows (slot (j+1) % 4) . x^T
+  // with the bias / ReLU / L1 work that turns S(j) into c(j) in the even gaps 4..34 (two 16-byte staging writes, gaps 18 and
+  // 34), ONE barrier at gap 40 -- by then every wave's c(j) is in the staging image and the W^T tile j+2 (DMA'd during the
+  // previous iteration) has landed -- and after it the DMA of tile j+3 into the slot whose tile j-1 was last read at gap 17,
+  // the first c^T / W fragments of the next decoder phase, the first encoder fragments of tile j+2, the drain of the previous
+  // tile pair.
+  constexpr int RING = 8;
+  const char *rlo[8], *rhi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    rlo[i] = smem + roff[i];
+    rhi[i] = smem + 2 * FF_WT_BYTES + roff[i];
+  }
+  const char *a0lo[6], *a1lo[6], *a0hi[6], *a1hi[6];
+#pragma unroll
+  for (int f = 0; f < 6; ++f) {
+    a0lo[f] = smem + aoff0[f];
+    a1lo[f] = smem + aoff1[f];
+    a0hi[f] = smem + 2 * FF_WT_BYTES + aoff0[f];
+    a1hi[f] = smem + 2 * FF_WT_BYTES + aoff1[f];
+  }
+  const char* bptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bptr[i] = cst + boff[i];
+  auto dec_a = [&](int slot, int f) -> bf16x8 {          // W fragment f = 3 ks + dtl of ring slot `slot`
+    const int off = (slot & 1) * FF_WT_BYTES;
+    return tr_pair((slot < 2 ? a0lo : a0hi)[f] + off, (slot < 2 ? a1lo : a1hi)[f] + off);
+  };
+  auto enc_frag = [&](int slot, int kk) -> bf16x8 {
+    const int off = (slot & 1) * FF_WT_BYTES + (kk >> 3) * 8192;
+    return *reinterpret_cast<const bf16x8*>((slot < 2 ? rlo : rhi)[kk & 7] + off);
+  };
+  auto dec_b = [&](int pb, int hf, int b) -> bf16x8 {    // c^T fragment b = 4 ks + mb of pair buffer pb, tile half hf
+    const int ks = b >> 2, mb = b & 3;
+    return *reinterpret_cast<const bf16x8*>(bptr[2 * hf + ks] + pb * 16384 + mb * 4096);
+  };
+
+  bf16x8 ring[RING], Afr[6], Bq[4];
+  f32x16 SA = Sn, SB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) SB[r] = 0.f;
+  // decoder of "tile -1": zeros from pair buffer 1, half 1 (cleared above) times the cleared ring slot 3; the first three
+  // encoder fragments of tile 1
+#pragma unroll
+  for (int f = 0; f < 3; ++f) Afr[f] = dec_a(3, f);
+  Bq[0] = dec_b(1, 1, 0);
+  Bq[1] = dec_b(1, 1, 1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ring[k] = enc_frag(1, k);
+
+  u32x4 dr[2];
+  bf16_t* const dummy_line = a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
+  auto body = [&](auto ph_tag, int j) {
+    constexpr int PH = decltype(ph_tag)::value;          // == j % 4
+    constexpr int SLOT_D = (PH + 3) & 3, SLOT_DN = PH, SLOT_E = (PH + 1) & 3, SLOT_EN = (PH + 2) & 3, SLOT_DMA = (PH + 3) & 3;
+    constexpr int PB_W = (PH >> 1) & 1, HF_W = PH & 1;               // where c(j) goes
+    constexpr int PB_D = (((PH + 3) & 3) >> 1) & 1, HF_D = (PH + 3) & 1;   // where c(j-1) is read (this iteration's decoder)
+    f32x16& Scur = (PH & 1) ? SB : SA;
+    f32x16& Snxt = (PH & 1) ? SA : SB;
+    const int jt = j + 3 <= last ? j + 3 : last;                     // DMA source (clamped in the tail)
+    const float* bj = bias_s + (j & (FF_BIAS_RING_TILES - 1)) * FF_BN;
+    const char* cst_r = cst + (PB_W ^ 1) * 16384 + wrow;             // pair buffer drained (tiles 2t-2, 2t-1), this wave's rows
+    bf16_t* dst_pair = j >= 2 ? cdrain + 64 * ((j >> 1) - 1) : dummy_line;
+    const int64_t dst_rstride = j >= 2 ? (int64_t)a.n_p : 0;
+    f32x4 bq[4];
+    float l1_it = 0.f;
+    bf16x8 cw;
+    const f32x16 S = Scur;
+
+    // 48 MFMA slots: EVEN slot i = decoder MFMA i / 2 of tile j-1 (m = 12 ks + 3 mb + dtl: accumulators rotate), ODD slot i =
+    // encoder MFMA i / 2 of tile j+1 (a chain through one accumulator: interleaved with the decoder its dependent issue is
+    // never back to back).  Fragments are requested >= 6 slots ahead.
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+      // ---- fragment prefetch
+      if ((i & 1) == 0 && i <= 40) ring[(i / 2 + 3) % RING] = enc_frag(SLOT_E, i / 2 + 3);         // encoder k = i/2 + 3 (slot i + 7)
+      if (i == 42 || i == 44 || i == 46) ring[(i - 42) / 2] = enc_frag(SLOT_EN, (i - 42) / 2);      // k = 0..2 of the NEXT iteration
+      if (i == 15 || i == 16 || i == 17) Afr[i - 12] = dec_a(SLOT_D, i - 12);                       // k-step 1 (decoder MFMAs 12..23)
+      if (i == 45 || i == 46 || i == 47) Afr[i - 45] = dec_a(SLOT_DN, i - 45);                      // k-step 0 of the next phase
+      // c^T fragment b feeds decoder MFMAs 3 b .. 3 b + 2 (slots 6 b .. 6 b + 4): requested at slot 6 b - 7
+      if (i >= 5 && i <= 35 && (i - 5) % 6 == 0) Bq[((i + 7) / 6) & 3] = dec_b(PB_D, HF_D, (i + 7) / 6);
+      if (i == 41) Bq[0] = dec_b(PB_W, HF_W, 0);                                                    // next phase, after the barrier
+      if (i == 47) Bq[1] = dec_b(PB_W, HF_W, 1);
+      if (i < 4) bq[i] = *reinterpret_cast<const f32x4*>(bj + 8 * i + 4 * ah);
+      if (i == 40) {
+        // <= 1 VMEM operation outstanding (this iteration's first latent store): the six DMA pieces of tile j+2 are done;
+        // <= 2 LDS operations outstanding (four fragment reads follow the staging write of gap 34): that write is done
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 41 || i == 43 || i == 45) dma_pair((i - 41) / 2, jt, SLOT_DMA);
+      if ((PH & 1) == 0 && i == 46 && w == 0) {
+        const int jb = j + 2 <= a.ntiles - 2 ? j + 2 : a.ntiles - 2;
+        glds4(a.bias + (int64_t)jb * FF_BN, (unsigned)(lane * 4),
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + FF_FIXED_LDS + ((j + 2) & (FF_BIAS_RING_TILES - 1)) * FF_BN * 4)));
+      }
+      // latent element e at gap 4 + 2 e
+      if (i >= 4 && i <= 34 && (i & 1) == 0) {
+        const int e = (i - 4) >> 1;                      // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+        float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);    // rounded to bf16 BEFORE the fp32 bias add (CPU autocast)
+        if (PAD) cv = row_ok ? cv : 0.f;
+        l1_it += cv;
+        cw[e & 7] = (bf16_t)cv;
+        if ((e & 7) == 7)      // the eight values of k-step e >> 3: one 16-byte chunk of this lane's row
+          *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e >> 3)]) = cw;
+      }
+      // two full-line pieces of the finished pair per iteration: LDS reads in one gap, global store 8 gaps later
+      if (i == 29 || i == 33) {
+        const int p = 2 * (PH & 1) + (i == 33);
+        const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff0);
+        const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff1);
+        dr[i == 33] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      if (i == 37 || i == 42) {
+        const int p = 2 * (PH & 1) + (i == 42);
+        __builtin_nontemporal_store(dr[i == 42], reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((i & 1) == 0) {
+        const int m = i / 2, ks = m / 12, mb = (m % 12) / 3, dtl = m % 3;
+        acc[4 * dtl + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Afr[3 * ks + dtl], Bq[(4 * ks + mb) & 3], acc[4 * dtl + mb], 0, 0, 0);
+      } else if (i == 1) {
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[0], xfrag[0], zero, 0, 0, 0);
+      } else {
+        Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(i / 2) % RING], xfrag[i / 2], Snxt, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l1_acc += l1_it;
+  };
+  if (STAMP) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int j4 = 0; j4 < a.ntiles; j4 += 4) {            // ntiles is a multiple of 4 (n_p is a multiple of 128)
+    body(std::integral_constant<int, 0>{}, j4);
+    body(std::integral_constant<int, 1>{}, j4 + 1);
+    body(std::integral_constant<int, 2>{}, j4 + 2);
+    body(std::integral_constant<int, 3>{}, j4 + 3);
+  }
+  if (STAMP) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + ((int64_t)wg * 4 + w) * 8;
+      o[0] = o[1] = o[2] = 0; o[3] = (unsigned long long)a.ntiles; o[4] = t1 - clk_t0; o[5] = r1 - clk_r0; o[6] = clk_t0 - clk_k0;
+    }
+  }
+  // ---- final half iteration: decoder of the last tile (slot 3, pair buffer 1, half 1); its k-step 0 W fragments and its
+  // first two c^T fragments were requested at the end of the last iteration (after its barrier)
+  Bq[2] = dec_b(1, 1, 2);
+#pragma unroll
+  for (int m = 0; m < 24; ++m) {
+    if (m == 3 || m == 4 || m == 5) Afr[m] = dec_a(3, m);
+    if (m % 3 == 0 && m / 3 + 3 <= 7) Bq[(m / 3 + 3) & 3] = dec_b(1, 1, m / 3 + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    const int ks = m / 12, mb = (m % 12) / 3, dtl = m % 3;
+    acc[4 * dtl + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Afr[3 * ks + dtl], Bq[(4 * ks + mb) & 3], acc[4 * dtl + mb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // drain the last pair of latent tiles (this wave's rows; published by the last iteration's barrier)
+  {
+    const char* cst_r = cst + (((a.ntiles >> 1) - 1) & 1) * 16384 + wrow;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff0);
+      const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff1);
+      __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y},
+                                  reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue: x_hat^T accumulators -> residual / dx_hat / squared-error sums.
+  // acc[4 dtl + mb][r] <-> d = 96 w + 32 dtl + (r&3) + 8 (r>>2) + 4 h, row 128 wg + 32 mb + arow: every wave needs all 128 x
+  // rows (for its d-slice), so the whole [128 x 384] x block is staged in the (now idle) rings, transformed in place into
+  // dx_hat by the four waves, and leaves as coalesced 16-byte stores.
+  float sq = 0.f, plain = 0.f, nmask = 0.f;
+  typedef __attribute__((ext_vector_type(4))) T Tx4;
+  const bool vec_ok = (a.d == FF_D) && ((reinterpret_cast<uintptr_t>(a.x) & (sizeof(T) * 4 - 1)) == 0);
+  constexpr int FF_DXH_PITCH = FF_D * 2 + 16;                    // 784 B
+  static_assert(128 * FF_DXH_PITCH <= FF_FIXED_LDS, "the dx_hat staging must fit the idle LDS");
+  char* stg = smem;                                              // [128 rows][784 B]
+  constexpr bool X_VIA_LDS = !PAD && sizeof(T) == 2;
+  if (X_VIA_LDS && vec_ok) {     // the wave's 32 x rows are one contiguous 24 KiB block: 24 coalesced 16-byte loads per lane
+    const char* xblk = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.x) + m0 * FF_D);
+#pragma unroll
+    for (int p0 = 0; p0 < 24; p0 += 8) {
+      u32x4 xr[8];
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) xr[pc] = *reinterpret_cast<const u32x4*>(xblk + (p0 + pc) * 1024 + lane * 16);
+#pragma unroll
+      for (int pc = 0; pc < 8; ++pc) {
+        const int off = (p0 + pc) * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
+        *reinterpret_cast<u32x4*>(stg + (32 * w + r) * FF_DXH_PITCH + cb) = xr[pc];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int64_t grow = (int64_t)wg * FF_BM + 32 * mb + arow;   // global activation row of this lane in row block mb
+    const bool ok = !PAD || grow < a.M;
+    const float rmask = ok ? 1.f : 0.f;
+    const T* xrow = reinterpret_cast<const T*>(a.x) + (ok ? grow : a.M - 1) * a.d;
+    char* srow = stg + (32 * mb + arow) * FF_DXH_PITCH;
+#pragma unroll
+    for (int dtl = 0; dtl < 3; ++dtl) {
+      const int dbase = 96 * w + 32 * dtl + 4 * ah;
+      if (vec_ok) {
+        Tx4 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          xv[k] = X_VIA_LDS ? *reinterpret_cast<const Tx4*>(srow + (dbase + 8 * k) * 2) : *reinterpret_cast<const Tx4*>(xrow + dbase + 8 * k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float xf = (float)xv[k][q];
+            const float e = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
+            const float e2 = e * e;
+            plain += rmask * e2;
+            const float keep = (xf != -1.0f) ? rmask : 0.f;
+            nmask += rmask - keep;
+            sq += keep * e2;
+            o[q] = (bf16_t)(keep * (e * 2.0f));
+          }
+          *reinterpret_cast<bf16x4*>(srow + (dbase + 8 * k) * 2) = o;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int dd = dbase + 8 * k + q;
+            const bool valid = dd < a.d;
+            const float xf = (float)xrow[valid ? dd : a.d - 1];
+            const float e = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
+            const float e2 = valid ? e * e : 0.f;
+            plain += rmask * e2;
+            const float keep = (valid && xf != -1.0f) ? rmask : 0.f;
+            nmask += (valid ? rmask : 0.f) - keep;
+            sq += keep * e2;
+            o[q] = (bf16_t)(keep * (e * 2.0f));
+          }
+          *reinterpret_cast<bf16x4*>(srow + (dbase + 8 * k) * 2) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {   // the wave's 32 rows of dx_hat are one contiguous 24 KiB block: 24 fully coalesced 16-byte stores per lane
+    char* gblk = reinterpret_cast<char*>(a.dxh + m0 * FF_D);
+#pragma unroll
+    for (int pc = 0; pc < 24; ++pc) {
+      const int off = pc * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
+      *reinterpret_cast<u32x4*>(gblk + off) = *reinterpret_cast<const u32x4*>(stg + (32 * w + r) * FF_DXH_PITCH + cb);
+    }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  const float l1s = block_sum_256(l1_acc, red);
+  const float sqs = block_sum_256(sq, red + 8);
+  const float pls = block_sum_256(plain, red + 16);
+  const float nms = block_sum_256(nmask, red + 24);
+  if (STAMP && lane == 0) a.stamps[((int64_t)wg * 4 + w) * 8 + 7] = __builtin_amdgcn_s_memtime() - clk_k0;
+  if (t == 0) {
+    a.cnt_part[wg] = nms;
+    a.l1_part[wg] = l1s;
+    a.sq_part[2 * wg] = sqs;
+    a.sq_part[2 * wg + 1] = pls;
+  }
+}
