@@ -298,3 +298,63 @@ def test_two_processes_one_gpu_train_like_one_process(tmp_path, case, payload, o
     for step in range(1, steps + 1):
         for tag in tags:
             assert s2[(tag, step)] == pytest.approx(s1[(tag, step)], rel=ltol, abs=1e-7), (tag, step)
+
+
+_ABSENT_PEER_CHILD = r"""
+import os, sys, time
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["FREUD_ROOT"])
+from freud_amd.engine import SaeEngine, EngineError
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+d, n, M = 384, 1024, 512
+eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e2)
+W = torch.empty(d, n); torch.nn.init.orthogonal_(W, generator=torch.Generator().manual_seed(0))
+eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)})
+blobs = [None, None]
+dist.all_gather_object(blobs, eng.p2p_export())
+eng.p2p_init(blobs, rank, 2)                      # collective self-test exchange: both ranks alive here
+dist.barrier()
+if rank == 1:
+    os._exit(0)                                   # the peer disappears without a word
+x = torch.randn(M, d, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+t0 = time.time()
+eng.step(x, 1e-3)                                 # the statistics push / exchange kernel wait for a rank that never comes
+try:
+    eng.dist_check()
+    print("NO_ERROR", flush=True)
+except EngineError as e:
+    print("ERROR_AFTER %.1f s: %s" % (time.time() - t0, e), flush=True)
+os._exit(0)
+"""
+
+
+def test_absent_peer_times_out_instead_of_hanging(tmp_path):
+    """Failure detection of the in-engine exchange: rank 1 exits after the start-up self-test; rank 0's next step must NOT hang
+    the GPU -- the polling kernels give up after FREUD_P2P_TIMEOUT_MS and sae_dist_check reports the absent peer."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "absent.py")
+    open(script, "w").write(_ABSENT_PEER_CHILD)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, FREUD_ROOT=root, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FREUD_P2P_TIMEOUT_MS="400")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    try:
+        outs = [pr.communicate(timeout=180) for pr in procs]
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    assert procs[0].returncode == 0, outs[0][1][-3000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith(("ERROR_AFTER", "NO_ERROR"))][-1]
+    assert line.startswith("ERROR_AFTER") and "did not arrive" in line, line
+    assert time.time() - t0 < 120
