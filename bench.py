@@ -189,90 +189,117 @@ def main():
     dtype = getattr(torch, args.x_dtype)
     x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype, kind=args.data)
     x = x_cpu.cuda()
-    if args.variant == "topk":
-        eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
-                        clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128, debug_flags=args.dbg)
-        eng.set_topk_options(args.dead_threshold, 1024)
-        g = torch.Generator().manual_seed(0)
-        We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
-        Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
-        eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
-                        "b_dec": np.zeros(d, np.float32)})
-        if args.dead_latents > 0:
-            nf = np.zeros(n, np.int64)
-            nf[np.random.default_rng(0).permutation(n)[:args.dead_latents]] = np.int64(4e18)
-            eng.set_topk_state(nf)
-    else:
-        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
-                        clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128,
-                        precision=args.precision)
-        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
-    # Data parallel: the engine's own RCCL communicator (sae_dist_init) runs the whole protocol -- batch statistics and
-    # gradient ranges all-reduced on a communication stream under the forward / backward kernels -- inside step(); --dp-host
-    # drives the same protocol from Python through torch.distributed (the host-side variant train() keeps for CPU tests).
-    grads, works, dp_mode = None, [], "none"
-    if use_dist:
-        from freud_amd import dp
-        mode = "host" if args.dp_host else (args.dp or dp.requested_mode())
-        dp_mode = dp.setup(eng, dist, rank, world, torch.device("cuda", local_rank), mode=mode, payload=args.dp_payload,
-                           overlap=args.dp_overlap)
-        args.dp_host = dp_mode == "host"
-    elif args.dp_overlap > 1:
-        eng.dist_set_overlap(args.dp_overlap)          # timing the range-split backward by itself
-    if use_dist and args.dp_host:
-        grads = eng.grad_tensor()
-        eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
     total_steps, base_lr = 100000, 4e-4
-    lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
-    def one_step(i):
-        if use_dist and args.dp_host:
-            eng.batch_stats(x)
-            dist.all_reduce(eng.stats_tensor())
-            eng.forward_backward(x)
-            for w in works:
-                w.wait()
-            works.clear()
-            eng.optimizer_step(lr_of(i), 1.0)
+    def attempt(mode_override=None):
+        """engine + data-parallel set-up + spin-up + warm-up + the timed region.  Returns (engine, step function, seconds of the
+        timed region, exchange in force, healthy)."""
+        grads, works = None, []
+        args.dp_host = args.dp_host_flag or mode_override == "host"
+        if args.variant == "topk":
+            eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=args.k, auxk_alpha=0.03125,
+                            clip_thresh=1.0, device_id=local_rank, force_gemm128=args.gemm128, debug_flags=args.dbg)
+            eng.set_topk_options(args.dead_threshold, 1024)
+            g = torch.Generator().manual_seed(0)
+            We = (torch.rand(n, d, generator=g) * 2 - 1) / d ** 0.5
+            Wd = We / (We.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)
+            eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32), "W_dec": Wd.numpy(),
+                            "b_dec": np.zeros(d, np.float32)})
+            if args.dead_latents > 0:
+                nf = np.zeros(n, np.int64)
+                nf[np.random.default_rng(0).permutation(n)[:args.dead_latents]] = np.int64(4e18)
+                eng.set_topk_state(nf)
         else:
-            eng.step(x, lr_of(i))
+            eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4,
+                            clip_thresh=1.0, device_id=local_rank, debug_flags=args.dbg, force_gemm128=args.gemm128,
+                            precision=args.precision)
+            eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        # Data parallel: the engine's own RCCL communicator (sae_dist_init) runs the whole protocol -- batch statistics and
+        # gradient ranges all-reduced on a communication stream under the forward / backward kernels -- inside step(); --dp-host
+        # drives the same protocol from Python through torch.distributed (the host-side variant train() keeps for CPU tests).
+        dp_mode = "none"
+        if use_dist:
+            from freud_amd import dp
+            mode = mode_override or ("host" if args.dp_host else (args.dp or dp.requested_mode()))
+            dp_mode = dp.setup(eng, dist, rank, world, torch.device("cuda", local_rank), mode=mode, payload=args.dp_payload,
+                               overlap=args.dp_overlap)
+            args.dp_host = dp_mode == "host"
+        elif args.dp_overlap > 1:
+            eng.dist_set_overlap(args.dp_overlap)          # timing the range-split backward by itself
+        if use_dist and args.dp_host:
+            grads = eng.grad_tensor()
+            eng.set_grad_ready_callback(lambda off, cnt: works.append(dist.all_reduce(grads[off:off + cnt], async_op=True)))
+        lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
-    if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
-        t_spin = time.perf_counter()
-        while True:
-            for _ in range(20):
-                one_step(0)
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t_spin
-            if use_dist:                     # every rank must leave after the same number of (collective) steps
-                te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-                dist.all_reduce(te, op=dist.ReduceOp.MAX)
-                elapsed = float(te.item())
-            if elapsed >= args.spinup:
-                break
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    # the dominant kernel is bracketed with HIP events on a SAMPLE of the timed steps (an event pair costs ~6 us of idle GPU
-    # between dependent kernels): every 8th step of a long run, every 2nd of a short one (the driver's 20-step run: 10 samples)
-    eng.profile(1, period=8 if args.steps > 64 else 2)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if dp_mode in ("p2p", "rccl"):
-        eng.dist_check()                                 # a timed-out exchange must not produce a number
+        def one_step(i):
+            if use_dist and args.dp_host:
+                eng.batch_stats(x)
+                dist.all_reduce(eng.stats_tensor())
+                eng.forward_backward(x)
+                for w in works:
+                    w.wait()
+                works.clear()
+                eng.optimizer_step(lr_of(i), 1.0)
+            else:
+                eng.step(x, lr_of(i))
+
+        if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
+            t_spin = time.perf_counter()
+            while True:
+                for _ in range(20):
+                    one_step(0)
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t_spin
+                if use_dist:                     # every rank must leave after the same number of (collective) steps
+                    te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+                    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                    elapsed = float(te.item())
+                if elapsed >= args.spinup:
+                    break
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize()
+        # the dominant kernel is bracketed with HIP events on a SAMPLE of the timed steps (an event pair costs ~6 us of idle GPU
+        # between dependent kernels): every 8th step of a long run, every 2nd of a short one (the driver's 20-step run: 10 samples)
+        eng.profile(1, period=8 if args.steps > 64 else 2)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        healthy = True
+        if dp_mode in ("p2p", "rccl"):                       # a timed-out exchange must not produce a number
+            try:
+                eng.dist_check()
+            except Exception as e:          # noqa: BLE001
+                print(f"[rank {rank}] in-engine exchange failed during the run: {e}", file=sys.stderr)
+                healthy = False
+            flag = torch.tensor([1 if healthy else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same decision
+            healthy = int(flag.item()) == 1
+        return eng, one_step, dt, dp_mode, healthy
+
+    args.dp_host_flag = args.dp_host
+    eng, one_step, dt, dp_mode, healthy = attempt()
+    if not healthy:
+        # the peers could not be reached in the middle of the run (the exchange kernels time out instead of hanging): the
+        # measurement is repeated from scratch with the host-driven protocol, on a fresh context, and says so in config.dp
+        eng.close()
+        eng, one_step, dt, dp_mode, healthy = attempt("host")
+        dp_mode = "host"
+        dp_fallback = True
+    else:
+        dp_fallback = False
     times = eng.kernel_times()
     metrics = eng.metrics()
     eng.profile(0)
@@ -327,6 +354,8 @@ def main():
                "p2p": f"in-engine peer exchange over hipIpc mappings, {eff_payload} gradients"
                       + (f", backward in {args.dp_overlap} column ranges" if fused and args.dp_overlap > 1 else ""),
                "rccl": f"in-engine RCCL, {eff_payload} gradients"}[dp_mode]
+    if dp_fallback:
+        dp_desc += " (fallback: the in-engine exchange failed during a first attempt)"
     model_name = {384: "tiny", 512: "base", 768: "small", 1024: "medium", 1280: "large"}.get(d, f"d={d}")
     out = {
         "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",

@@ -100,7 +100,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // Output-tile coordinates of (remapped) workgroup id: tiles are walked in groups of GEMM_GROUP_M tile rows, row index
 // fastest, so that the ~32 workgroups an XCD runs at a time form a compact GROUP_M x (32 / GROUP_M) patch and share
 // their A and B tiles in that XCD's L2 (a plain row-major walk shares only A).
-constexpr int GEMM_GROUP_M = 8;
+#ifndef GEMM_GROUP_M_
+#define GEMM_GROUP_M_ 8      // tools/build_variant.sh can sweep it (4 x 8 / 8 x 4 / 16 x 2 patches per XCD)
+#endif
+constexpr int GEMM_GROUP_M = GEMM_GROUP_M_;
 __device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& bm, int& bn) {
   const int per_group = GEMM_GROUP_M * nbn;
   const int grp = id / per_group, r = id - grp * per_group;
