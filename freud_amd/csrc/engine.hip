@@ -1268,7 +1268,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     };
     ev_begin(c, KID_FWD_FUSED, s);
     int rcl = SAE_OK;
-    if (full_wgs > 0 && c->cfg.debug_flags == 65 && c->fwd_variant != 2) {   // diagnostic: stamps into the (unused here) dpre buffer
+    if (full_wgs > 0 && c->cfg.debug_flags == 65 && c->fwd_variant == 1) {   // diagnostic: stamps into the (unused here) dpre buffer
       a.stamps = reinterpret_cast<unsigned long long*>(c->dpre);
       rcl = launch(fwd_fused_d384_kernel<T, false, true>, full_wgs, 0);
     } else if (c->fwd_variant == 2) {               // the second decomposition (fwd_fused2.h)
