@@ -44,6 +44,14 @@ struct BwdFusedArgs {
   const bf16_t* Wt;    // [n_p][384]
   const float* scal;   // scal[1] = alpha/count, scal[2] = 1/M
   int unscaled;        // 1: dxh holds 2 (x_hat - x)[keep] without the alpha/count factor (fused forward)
+  // cnt_part != null (single GPU, fused forward): alpha/count and 1/M are taken HERE from the forward's per-workgroup
+  // masked-entry counts (exact integers: any summation order gives the same value in every workgroup), so that the one-block
+  // loss finalisation no longer sits between the forward and the backward (it rides in reduce_grads_kernel's last block)
+  const float* cnt_part;
+  int n_cnt;
+  float alpha;
+  int64_t M;
+  int d;
   float* slab;         // [splits][384][n_p]
   float* db_part;      // [splits][n_p]
   int n_p;
@@ -96,8 +104,24 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   const int nw = n0 + 32 * w;             // first column of this wave
   // With an unscaled dx_hat everything is computed in units of 1/scale: dpre' = dc' + (1/M)/scale, and the
   // epilogue multiplies the dW slab and db by scale = alpha/count.
-  const float scale = a.unscaled ? a.scal[1] : 1.0f;
-  const float inv_m = a.unscaled ? a.scal[2] / a.scal[1] : a.scal[2];
+  float scal1, scal2;
+  if (a.cnt_part) {
+    double* redc = reinterpret_cast<double*>(smem + BF_STAGE_BYTES);      // stage 1 is idle until the loop's first hand-over
+    double m = 0;
+    for (int i = t; i < a.n_cnt; i += 256) m += (double)a.cnt_part[i];
+    m = wave_sum_d(m);
+    if (lane == 0) redc[w] = m;
+    __syncthreads();
+    const double count = (double)a.M * a.d - ((redc[0] + redc[1]) + (redc[2] + redc[3]));
+    scal1 = a.alpha / (float)count;          // the same float operations as finalize_losses_kernel
+    scal2 = 1.0f / (float)a.M;
+    __syncthreads();
+  } else {
+    scal1 = a.scal[1];
+    scal2 = a.scal[2];
+  }
+  const float scale = a.unscaled ? scal1 : 1.0f;
+  const float inv_m = a.unscaled ? scal2 / scal1 : scal2;
 
   // W^T fragments of this wave: B[k = d][col = n] -> lane (n = lane & 31, h) holds Wt[nw + n][16 kk + 8 h ..+8]
   bf16x8 wfrag[24];

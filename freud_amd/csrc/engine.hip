@@ -1352,7 +1352,11 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   ev_begin(c, KID_STEP_TOTAL, s);
   int rc = forward_impl<T>(c, x, M, Mp, s, backward);
   if (rc) return rc;
-  if (c->use_fused_fwd) {  // the fused forward counted the masked entries itself: scal[] and the losses are due now
+  // single GPU, fused forward + fused backward in ONE launch: the backward takes alpha/count from the forward's counts itself and
+  // the loss scalars are finalised by reduce_grads_kernel's last block (5 us less between the forward and the backward)
+  const bool fold_finalize = c->use_fused_fwd && c->use_fused_bwd && backward && gs == nullptr && c->bwd_ranges == 1 &&
+                             c->cfg.debug_flags != 78;
+  if (c->use_fused_fwd && !fold_finalize) {  // the fused forward counted the masked entries itself: scal[] and the losses are due now
     StatsPush push{};
     if (gs && inline_stats(c)) {       // peer exchange: the statistics travel inside this kernel (no pass over x, no second stream)
       for (int r = 0; r < c->dp_world; ++r) push.inbox[r] = c->p2p_sig[r] + P2P_SIG_WORDS;
@@ -1374,6 +1378,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       BwdFusedArgs a{};
       a.dxh = c->dxh; a.xb = c->xb_cur; a.c = c->c; a.Wt = c->Wt; a.scal = c->scal; a.slab = c->slab; a.db_part = c->db_part;
       a.unscaled = c->use_fused_fwd ? 1 : 0;
+      if (fold_finalize) { a.cnt_part = c->cnt_part; a.n_cnt = (int)(Mp / 128); a.alpha = alpha; a.M = M; a.d = d; }
       a.n_p = n_p; a.steps_total = (int)(Mp / BF_BM);
       // diagnostic clock stamps go to the second half of the (unused on this path) dpre buffer
       a.clk = c->cfg.debug_flags == 66 ? reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16) : nullptr;
@@ -1475,9 +1480,14 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       const int64_t nW4 = c->nW / 4, n4 = c->nparams / 4;
       int blocks = (int)((n4 + 255) / 256);
       if (blocks > 1024) blocks = 1024;
+      LossFinalize fin{};
+      if (fold_finalize) {
+        fin.l1_part = c->l1_part; fin.sq_part = c->sq_part; fin.cnt_part = c->cnt_part; fin.n_parts = (int)(Mp / 128);
+        fin.scal = c->scal; fin.metrics = c->G + c->nparams; fin.M = M; fin.d = d; fin.alpha = alpha;
+      }
       hipLaunchKernelGGL(reduce_grads_kernel, dim3(blocks), dim3(256), 0, s, c->slab, nW4, splits, c->db_part, db_rows, n_p,
                          c->G, nW4, n4, c->gn_part,
-                         (c->dist && c->dp_world > 0 && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr);
+                         (c->dist && c->dp_world > 0 && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr, fin);
       c->gn_blocks = blocks;
       c->gn_valid = true;
     } else {

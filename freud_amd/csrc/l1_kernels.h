@@ -319,11 +319,57 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 // all-reduce follows).  Fixed order everywhere -> deterministic.
 // grad_bf16 != null (data parallel with a bf16 payload): the same values are also written rounded to bf16, the copy the
 // all-reduce then sums (gnorm_from_bf16_kernel brings the sum back to fp32).
+// fin.cnt_part != null: the LAST block also finalises the loss scalars (what finalize_losses_kernel does, for the single-GPU
+// fused path where the backward took alpha/count from the forward's counts itself): off the forward -> backward critical path.
+struct LossFinalize {
+  const float *l1_part, *sq_part, *cnt_part;
+  int n_parts;
+  float *scal, *metrics;
+  int64_t M;
+  int d;
+  float alpha;
+};
+
+__device__ __forceinline__ void finalize_losses_block256(const LossFinalize& f) {
+  __shared__ double redf[4][4];
+  double a = 0, b = 0, c = 0, m = 0;
+  for (int i = threadIdx.x; i < f.n_parts; i += 256) {
+    a += (double)f.l1_part[i];
+    b += (double)f.sq_part[2 * i];
+    c += (double)f.sq_part[2 * i + 1];
+    m += (double)f.cnt_part[i];
+  }
+  a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c); m = wave_sum_d(m);
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    redf[0][w] = a; redf[1][w] = b; redf[2][w] = c; redf[3][w] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double l1 = (redf[0][0] + redf[0][1]) + (redf[0][2] + redf[0][3]), sq = (redf[1][0] + redf[1][1]) + (redf[1][2] + redf[1][3]);
+    const double pl = (redf[2][0] + redf[2][1]) + (redf[2][2] + redf[2][3]), masked = (redf[3][0] + redf[3][1]) + (redf[3][2] + redf[3][3]);
+    const double local = (double)f.M * f.d - masked;
+    f.scal[0] = (float)local;
+    f.scal[1] = f.alpha / (float)local;
+    f.scal[2] = 1.0f / (float)f.M;
+    f.scal[3] = (float)local;
+    const double count = (double)f.scal[0];
+    f.metrics[0] = (float)((double)f.alpha * (sq / count));
+    f.metrics[1] = (float)(l1 / (double)f.M);
+    f.metrics[2] = (float)(pl / ((double)f.M * f.d));
+    f.metrics[3] = 0.f;
+    f.metrics[4] = f.scal[0];
+    f.metrics[5] = f.metrics[6] = f.metrics[7] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restrict__ slab, int64_t stride4, int splits,
                                                             const float* __restrict__ db_part, int db_rows, int n_p,
                                                             float* __restrict__ grad, int64_t nW4, int64_t n4,
-                                                            double* __restrict__ gn_part, bf16_t* __restrict__ grad_bf16) {
+                                                            double* __restrict__ gn_part, bf16_t* __restrict__ grad_bf16,
+                                                            LossFinalize fin) {
   __shared__ double red[4];
+  if (fin.cnt_part && blockIdx.x == gridDim.x - 1) finalize_losses_block256(fin);
   double ss = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 a;
