@@ -132,6 +132,7 @@ struct sae_ctx {
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
   float* cn_part = nullptr;
+  bool cn_valid = false;       // cn_part holds the column-norm partials of the CURRENT weights (left by optimizer_l1_kernel)
   sae_grad_ready_fn grad_ready = nullptr;   // data-parallel overlap hook (sae_set_grad_ready_callback)
   void* grad_ready_user = nullptr;
   int dw_chunk_rows = 0;       // generic L1 path: rows (of d_p) per weight-gradient GEMM launch when a hook is set
@@ -674,6 +675,7 @@ extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, cons
   USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
+  c->cn_valid = false;
   if (c->topk) {
     if (!p2 || !p3) return fail(SAE_ERR_INVALID, "topk needs 4 parameter tensors");
     float* const ext[4] = {const_cast<float*>(p0), const_cast<float*>(p1), const_cast<float*>(p2), const_cast<float*>(p3)};
@@ -1214,7 +1216,9 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   float* b = c->P + c->nW;
 
   ev_begin(c, KID_PREP_W, s);
-  hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 64, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
+  // (a training step's optimizer left the column-norm partials of the weights it wrote: optimizer_l1_kernel)
+  if (!c->cn_valid) hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 128, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
+  c->cn_valid = false;        // normalize_cast rewrites W in place: the partials describe the weights before it
   hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
                      c->Wt, d_p, n_p);
   if (c->fp8) hipLaunchKernelGGL(fp8_cast_w_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->W8, c->W8t, d_p, n_p);
@@ -2015,8 +2019,15 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   c->gn_valid = false;
   int oblocks = (int)((n4 + 255) / 256);
   if (oblocks > 2048) oblocks = 2048;
-  hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
-                     a, c->G + c->nparams);
+  if (!c->topk && c->cfg.debug_flags != 79) {      // L1: tiled update that also leaves the column-norm partials of the new weights
+    hipLaunchKernelGGL(optimizer_l1_kernel, dim3(c->n_p / 128, c->d_p / 32 + 1), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, c->d_p,
+                       c->n_p, c->gn_part, gblocks, a, c->G + c->nparams, c->cn_part);
+    c->cn_valid = true;
+  } else {
+    hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
+                       a, c->G + c->nparams);
+    c->cn_valid = false;
+  }
   if (c->topk)   // train_sae.py:443-446 with the (possibly data-parallel summed) did_fire flags
     hipLaunchKernelGGL(nfsf_update_kernel, dim3((c->n + 255) / 256), dim3(256), 0, s, c->nfsf, c->G + c->nparams + SAE_NUM_METRICS,
                        c->n, (long long)(c->last_M * (grad_scale > 0 ? (long long)llround(1.0 / grad_scale) : 1)),

@@ -10,21 +10,29 @@
 // encoder / dc).  Phase 1: per-column sums of squares over 32-row slabs (fixed order ->
 // deterministic); phase 2: 64x64 tiles normalise, cast and transpose through LDS.
 // ------------------------------------------------------------------------------------------
+// The partial sum of a (32-row slab, column) has ONE definition, shared with optimizer_l1_kernel (which leaves the same
+// partials of the weights it has just updated, so that a training step needs no colnorm pass): thread ty of 8 adds the
+// squares of rows ty, ty + 8, ty + 16, ty + 24 in that order, the eight results are added as ((0+1)+(2+3))+((4+5)+(6+7)).
+__device__ __forceinline__ float colnorm_tree8(const float (*red)[128], int col) {
+  return ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+}
+
 __global__ __launch_bounds__(256) void colnorm_partial_kernel(const float* __restrict__ W, float* __restrict__ part,
                                                                int n_p) {
-  // grid (n_p/64, d_p/32); thread -> column tx, rows ty, ty+4, ... of the 32-row slab
-  __shared__ float red[4][64];
-  const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-  const int col = blockIdx.x * 64 + tx, r0 = blockIdx.y * 32;
-  float ss = 0.f;
+  // grid (n_p/128, d_p/32); thread -> columns 4 tx .. 4 tx + 3 (tx < 32), rows ty, ty + 8, ty + 16, ty + 24 of the 32-row slab
+  __shared__ float red[8][128];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int col = blockIdx.x * 128 + 4 * tx, r0 = blockIdx.y * 32;
+  f32x4 ss = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float v = W[(int64_t)(r0 + ty + 4 * i) * n_p + col];
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(r0 + ty + 8 * i) * n_p + col);
     ss += v * v;
   }
-  red[ty][tx] = ss;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[ty][4 * tx + q] = ss[q];
   __syncthreads();
-  if (ty == 0) part[(int64_t)blockIdx.y * n_p + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (t < 128) part[(int64_t)blockIdx.y * n_p + blockIdx.x * 128 + t] = colnorm_tree8(red, t);
 }
 
 __global__ __launch_bounds__(256) void normalize_cast_kernel(float* __restrict__ W, const float* __restrict__ part,
@@ -653,6 +661,78 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
   }
+}
+
+// The same update for the L1 weight matrix W[d_p][n_p], tiled like colnorm_partial_kernel (grid (n_p/128, d_p/32)), which
+// ALSO leaves the per-(32-row slab, column) sums of squares of the UPDATED weights in cn_part -- bit-identical to what
+// colnorm_partial_kernel would compute from them -- so that the next forward starts with normalize_cast at once (one 5 us
+// kernel less per training step).  The bias tail [nW, nW + n_p) is updated by the blocks of an extra grid row, flat.
+__global__ __launch_bounds__(256) void optimizer_l1_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                            const float* __restrict__ grad, int d_p, int n_p,
+                                                            const double* __restrict__ gn_part, int n_part, OptArgs a,
+                                                            float* __restrict__ metrics, float* __restrict__ cn_part) {
+  __shared__ double redd[4];
+  __shared__ float red[8][128];
+  double s = 0;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float total = sqrtf((float)(redd[0] + redd[1] + redd[2] + redd[3]));
+  const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    metrics[3] = total;
+    if (a.scale_metrics && a.grad_scale != 1.0f) {
+      metrics[0] *= a.grad_scale;
+      metrics[1] *= a.grad_scale;
+      metrics[2] *= a.grad_scale;
+      metrics[5] *= a.grad_scale;
+    }
+  }
+  auto update4 = [&](int64_t o) -> f32x4 {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(grad + o);
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + o), mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // (the op order of optimizer_kernel, i.e. of torch's single-tensor Adam / RAdam)
+      float gj = (g[j] * a.grad_scale) * coef;
+      if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
+      mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
+      vv[j] = vv[j] * a.beta2;
+      vv[j] = vv[j] + (a.one_minus_beta2 * gj) * gj;
+      if (a.is_radam) {
+        const float mh = mv[j] / a.bc1;
+        if (a.rectify) {
+          const float adaptive = (1.0f / (sqrtf(vv[j]) + a.eps)) * a.bc2_sqrt;
+          pv[j] = pv[j] - ((mh * a.lr) * adaptive) * a.rect;
+        } else {
+          pv[j] = pv[j] - mh * a.lr;
+        }
+      } else {
+        const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+        pv[j] = pv[j] + (-a.step_size * mv[j]) / denom;
+      }
+    }
+    *reinterpret_cast<f32x4*>(p + o) = pv;
+    *reinterpret_cast<f32x4*>(m + o) = mv;
+    *reinterpret_cast<f32x4*>(v + o) = vv;
+    return pv;
+  };
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  if ((int)blockIdx.y == d_p / 32) {      // the bias: 128 columns per block, threads 0..31
+    if (t < 32) update4((int64_t)d_p * n_p + blockIdx.x * 128 + 4 * t);
+    return;
+  }
+  const int col = blockIdx.x * 128 + 4 * tx, r0 = blockIdx.y * 32;
+  f32x4 ss = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 pv = update4((int64_t)(r0 + ty + 8 * i) * n_p + col);
+    ss += pv * pv;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[ty][4 * tx + q] = ss[q];
+  __syncthreads();
+  if (t < 128) cn_part[(int64_t)blockIdx.y * n_p + blockIdx.x * 128 + t] = colnorm_tree8(red, t);
 }
 
 // ------------------------------------------------------------------------------------------
