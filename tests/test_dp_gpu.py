@@ -240,10 +240,19 @@ def _run_children(script, cfg_path, world, extra_env, timeout=900):
     ("l1_fused", "float32", 1),        # d = 384: fused forward / backward, whole gradient exchanged in line
     ("l1_fused", "bfloat16", 1),       # ... as a bf16 copy (rounded once by the owner of each shard)
     ("l1_fused", "float32", 2),        # ... backward in two column-tile ranges, range 0 exchanged under range 1's backward
-    ("l1_generic", "float32", 1),      # d = 1280: three-GEMM backward, dW row chunks exchanged under the remaining chunks
+    ("l1_generic", "float32", 1),      # d = 1280: three-GEMM backward, dW column chunks (2-D segments) exchanged under the remaining ones
     ("topk", "float32", 1),            # TopK with AuxK: statistics (column sums), did_fire OR, dW_dec before dW_enc
 ])
 def test_two_processes_one_gpu_train_like_one_process(tmp_path, case, payload, overlap):
+    _ranks_vs_single_process(tmp_path, case, payload, overlap, world=2)
+
+
+def test_four_processes_one_gpu_train_like_one_process(tmp_path):
+    """The same with FOUR ranks (three peers per exchange workgroup, four shards): L1 fused path, fp32 payload."""
+    _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=4)
+
+
+def _ranks_vs_single_process(tmp_path, case, payload, overlap, world):
     """R x B == 1 x RB on REAL kernels with the REAL exchange: two freshly spawned processes (ranks 0 and 1, both on GPU 0)
     run train() with the in-engine protocol over hipIpc peer mappings -- handles through a gloo group, batch statistics
     summed before the backward, every gradient range summed by the engine's exchange kernels, self-test at start-up -- and
@@ -255,7 +264,7 @@ def test_two_processes_one_gpu_train_like_one_process(tmp_path, case, payload, o
     import os
     from freud_amd.loader import write_shards
     d, n, T = {"l1_fused": (384, 1024, 64), "l1_generic": (1280, 512, 32), "topk": (384, 1024, 32)}[case]
-    n_files, B, steps = 16, 2, 4
+    n_files, B, steps = 16, (2 if world == 2 else 1), 4
     g = torch.Generator().manual_seed(11)
     rows = ((torch.relu(torch.randn(n_files * T, 16, generator=g)) * 0.2) @ torch.randn(16, d, generator=g)).reshape(n_files, T * d)
     for f, frac in ((0, 0.5), (3, 0.3), (5, 0.6), (10, 0.2)):
@@ -278,11 +287,11 @@ def test_two_processes_one_gpu_train_like_one_process(tmp_path, case, payload, o
     script = os.path.join(str(tmp_path), "child.py")
     open(script, "w").write(_TRAIN_CHILD)
     cfg2 = dict(copy.deepcopy(base), batch_size=B, run_dir=os.path.join(str(tmp_path), "dp2"))
-    cfg1 = dict(copy.deepcopy(base), batch_size=2 * B, run_dir=os.path.join(str(tmp_path), "dp1"))
+    cfg1 = dict(copy.deepcopy(base), batch_size=world * B, run_dir=os.path.join(str(tmp_path), "dp1"))
     for name, cfg in (("cfg2.json", cfg2), ("cfg1.json", cfg1)):
         json.dump(cfg, open(os.path.join(str(tmp_path), name), "w"))
     env = {"FREUD_DP": "p2p", "FREUD_DP_PAYLOAD": payload, "FREUD_DP_OVERLAP": str(overlap), "FREUD_P2P_TIMEOUT_MS": "20000"}
-    outs = _run_children(script, os.path.join(str(tmp_path), "cfg2.json"), 2, env)
+    outs = _run_children(script, os.path.join(str(tmp_path), "cfg2.json"), world, env)
     assert "exchange = p2p" in outs[0][0], outs[0][0][-1000:]
     _run_children(script, os.path.join(str(tmp_path), "cfg1.json"), 1, {})
     a = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", f"step{steps}.pth"), map_location="cpu")
