@@ -14,7 +14,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-KERNELS = {"fwd_fused_gemm": "fwd_fused_d384_kernel", "bwd_fused_gemm": "bwd_fused_d384_kernel"}
+KERNELS = {"fwd_fused_gemm": "fwd_fused", "bwd_fused_gemm": "bwd_fused_d384_kernel"}     # fwd_fused_d384 / fwd_fused2_d384
 
 
 def counters(path):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: for the last full step (from one colnorm_partial
+"""Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: for the last full step (from one normalize_cast
 launch to the next) print every dispatch's start offset, duration and the idle gap before it; and the timed-region
 averages (last K launches of every kernel) that the bench line's HIP-event figures are compared with.
 
@@ -23,7 +23,8 @@ def short(name):
 def main(path, K=200):
     rows = list(csv.DictReader(open(path)))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows))
-    starts = [i for i, e in enumerate(ev) if "colnorm_partial" in e[2] or "dead_mask" in e[2]]
+    # first kernel of a step: normalize_cast (L1: a training step needs no colnorm pass since round 3), dead_mask / dead_compact (TopK)
+    starts = [i for i, e in enumerate(ev) if "normalize_cast" in e[2] or "dead_mask" in e[2] or "dead_compact" in e[2]]
     if len(starts) >= 3:
         a, b = starts[-3], starts[-2]
         t0, prev_end = ev[a][0], ev[a][0]
