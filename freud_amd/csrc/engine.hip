@@ -983,6 +983,7 @@ extern "C" int sae_dist_init(sae_ctx* c, const void* unique_id, int64_t id_bytes
   USE_DEVICE(c);
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
+  if (c->bwd_ranges > 1) return fail(SAE_ERR_STATE, "column ranges (sae_dist_set_overlap) need the peer exchange: RCCL sums contiguous buffers");
   NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
   {
     int rc_s = dist_streams_create(c);
