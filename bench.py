@@ -398,8 +398,9 @@ def main():
               (np.median(st[:, 6]), np.median(st[:, 4]), np.median(st[:, 7] - st[:, 6] - st[:, 4]), np.median(st[:, 7])),
               file=sys.stderr)
     if args.dbg == 66 and rank == 0:     # clock stamps of the fused backward
-        st = eng.debug_read(6, (n // 128 + (1 if n % 128 else 0)) * 40).reshape(-1, 4)
-        st = st[st[:, 3] > 0]
+        nt = n // 128 + (1 if n % 128 else 0)
+        st = eng.debug_read(6, nt * 80).reshape(-1, 4)[: nt * 10]      # [workgroup][4] loop stamps (second half: whole-kernel cycles)
+        st = st[st[:, 2] > 0]
         print("bwd in-kernel clock %.0f MHz (median), loop cycles/step %.0f (ideal 72 MFMA x 32 = 2304)" %
               (np.median(st[:, 0] / st[:, 1]) * 100.0, np.median(st[:, 0] / st[:, 2])), file=sys.stderr)
     if args.variant == "topk":
