@@ -222,7 +222,7 @@ struct sae_ctx {
   unsigned int* p2p_status = nullptr;            // device word the exchange kernels set on a barrier timeout
   unsigned long long p2p_epoch[P2P_CHANNELS] = {};
   unsigned long long p2p_epoch_push = 0;         // epoch of the statistics push inside finalize_losses_kernel
-  unsigned long long p2p_timeout_ticks = 200000000ull;     // 2 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS)
+  unsigned long long p2p_timeout_ticks = 1000000000ull;    // 10 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS)
   bool gn_from_exchange = false;                 // gn_part holds the sum of squares of the EXCHANGED gradient
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)

@@ -452,8 +452,11 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                 logger.add_scalar("train/grad_norm", m[3], state["step"])
                 logger.add_scalar("train/activations_per_sec", rows_done / max(time.time() - t_start, 1e-9), state["step"])
 
-            if state["step"] % save_every == 0 and is_main:
-                save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
+            if state["step"] % save_every == 0:
+                if is_main:
+                    save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
+                if use_dist:
+                    dist.barrier()      # rank 0 wrote for a while: re-align before the next step's in-engine exchange (it times out)
 
             if state["step"] % val_every == 0:
                 if is_main:
@@ -491,6 +494,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                         params = eng.get_params()
                         torch.save({k: torch.from_numpy(params[k].copy()) for k in state_dict_order},
                                    (run_dir + "/model")[:-3] + ".bestval")
+                if use_dist:
+                    dist.barrier()      # (rank 0 may have written bestval.pth)
 
             if state["step"] >= steps:
                 break
@@ -498,6 +503,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             raise RuntimeError(f"train loader yields no batches: {dset_len} files, batch_size {batch_size}, world {world}")
         if is_main:    # epoch-end checkpoint (train_sae.py:600-602)
             save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
+        if use_dist:
+            dist.barrier()
     logger.close()
     if use_dist:
         if in_engine:

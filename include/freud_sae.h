@@ -187,7 +187,7 @@ int sae_dist_set_payload(sae_ctx* ctx, int dtype);
  *                       bf16 copy, the statistics buffer and the flag block) to host memory;
  *   sae_p2p_init        takes the blobs of ALL ranks (rank order, gathered over any host channel), maps the peers and runs a
  *                       self-test exchange (collective: every rank must call it; a peer that cannot be reached makes it FAIL
- *                       after FREUD_P2P_TIMEOUT_MS, default 2000, instead of hanging).  Afterwards sae_forward_backward /
+ *                       after FREUD_P2P_TIMEOUT_MS, default 10000, instead of hanging).  Afterwards sae_forward_backward /
  *                       sae_step run the data-parallel protocol through the peer exchange; sae_dist_world() == world.
  *   sae_dist_set_overlap  fused d = 384 path: launch the backward in `nranges` column-tile ranges; each range's gradient is
  *                       exchanged on the communication stream under the next range's backward (needs the peer exchange:
