@@ -156,8 +156,8 @@ def main():
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8 = BASELINE configs[4]: e4m3 encoder / decoder GEMMs (L1 only)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "fp8bwd"],
+                    help="fp8 = BASELINE configs[4]: e4m3 encoder / decoder GEMMs (L1 only); fp8bwd: the dpre GEMM of the backward too")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,7 +321,7 @@ def main():
     fb_ms, fb_cnt = times["fwd_bwd_total"]
 
     breakdown = None
-    if args.breakdown or args.precision == "fp8":        # every rank runs the extra steps (they contain collectives); rank 0 reports
+    if args.breakdown or args.precision != "bf16":        # every rank runs the extra steps (they contain collectives); rank 0 reports
         eng.profile(2)
         for i in range(10):
             one_step(args.warmup + args.steps + i)
@@ -378,12 +378,13 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
-    if args.precision == "fp8" and breakdown:
+    if args.precision != "bf16" and breakdown:
         # the two fp8 GEMMs against the dense fp8 MFMA peak (2 M d n FLOPs each), next to the (bf16) dominant kernel above
-        out["dtype"] = "fp8 (e4m3 encoder/decoder GEMMs, fp32 accumulate) + bf16 backward"
+        out["dtype"] = ("fp8 (e4m3 encoder/decoder GEMMs, fp32 accumulate) + bf16 backward" if args.precision == "fp8" else
+                        "fp8 (e4m3 encoder/decoder/dpre GEMMs, fp32 accumulate) + bf16 weight-gradient GEMMs")
         out["fp8_gemms"] = {k: {"ms": breakdown[k], "tflops": 2.0 * M * d * n / (breakdown[k] * 1e-3) / 1e12,
                                 "frac_of_fp8_peak": 2.0 * M * d * n / (breakdown[k] * 1e-3) / 1e12 / PEAK_FP8_TFLOPS}
-                            for k in ("enc_fwd_gemm", "dec_fwd_gemm") if breakdown.get(k)}
+                            for k in ("enc_fwd_gemm", "dec_fwd_gemm") + (("dpre_gemm",) if args.precision == "fp8bwd" else ()) if breakdown.get(k)}
         out["config"]["workload"] = out["config"]["workload"].replace("L1 SAE train step", "L1 SAE train step, fp8 enc/dec GEMMs")
     if args.dbg == 65 and rank == 0:     # diagnostic build: cycle shares of one fused-forward iteration + in-kernel clock
         st = eng.debug_read(5, (M // 128) * 32).reshape(-1, 8)

@@ -123,6 +123,8 @@ struct sae_ctx {
   bf16_t *Wb = nullptr, *Wt = nullptr;
   // SAE_PREC_FP8: encoder / decoder GEMMs on e4m3 operands (l1_fp8.h); every padded dimension is a multiple of 256 then
   bool fp8 = false;
+  bool fp8_bwd = false;         // SAE_PREC_FP8_BWD: the dpre GEMM of the backward on e4m3 operands too (dxh8 = e4m3(dx_hat s_g))
+  unsigned char* dxh8 = nullptr;
   int row_pad = 128;            // M_p = round_up(M, row_pad)
   unsigned char *x8 = nullptr, *c8 = nullptr, *W8 = nullptr, *W8t = nullptr;
   float *scal8 = nullptr, *x8_part = nullptr;
@@ -450,7 +452,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
-                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part,
+                  c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part, c->dxh8,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
                   c->aux_dbe_part, c->be_r};
@@ -498,16 +500,17 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   HIP_TRY(hipSetDevice(cfg->device_id));
   g_device = cfg->device_id;
 
-  if (cfg->precision != SAE_PREC_BF16 && cfg->precision != SAE_PREC_FP8)
-    return fail(SAE_ERR_INVALID, "Invalid precision: %d, must be SAE_PREC_BF16 or SAE_PREC_FP8", cfg->precision);
-  if (cfg->precision == SAE_PREC_FP8 && cfg->variant != SAE_VARIANT_L1)
+  if (cfg->precision != SAE_PREC_BF16 && cfg->precision != SAE_PREC_FP8 && cfg->precision != SAE_PREC_FP8_BWD)
+    return fail(SAE_ERR_INVALID, "Invalid precision: %d, must be SAE_PREC_BF16, SAE_PREC_FP8 or SAE_PREC_FP8_BWD", cfg->precision);
+  if (cfg->precision != SAE_PREC_BF16 && cfg->variant != SAE_VARIANT_L1)
     return fail(SAE_ERR_INVALID, "fp8 encoder / decoder GEMMs exist for the L1 variant only");
 
   sae_ctx* c = new sae_ctx();
   c->cfg = *cfg;
   c->d = cfg->d_model;
   c->n = cfg->n_dict;
-  c->fp8 = cfg->precision == SAE_PREC_FP8;
+  c->fp8 = cfg->precision != SAE_PREC_BF16;
+  c->fp8_bwd = cfg->precision == SAE_PREC_FP8_BWD;
   const int pad = c->fp8 ? 256 : 128;      // the fp8 GEMM has 256x256 tiles only
   c->row_pad = pad;
   c->d_p = (int)round_up(c->d, pad);
@@ -598,6 +601,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     ALLOC(c->W8t, c->nW);
     ALLOC(c->scal8, S8_COUNT * 4);
     ALLOC(c->x8_part, 2 * 1024 * 4);
+    if (c->fp8_bwd) ALLOC(c->dxh8, Mp * c->d_p);
   }
 #undef ALLOC
   {
@@ -1412,7 +1416,24 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       ev_end(c, KID_BWD_FUSED, s);
       HIP_TRY(hipGetLastError());
     } else {
-      {  // dpre = (dx_hat W + 1/M) [c > 0]
+      if (c->fp8_bwd) {  // dpre = (bf16((dxh8 W8t^T) / (s_g s_w)) + 1/M) [c > 0]: dx_hat quantised with a scale from its own maximum
+        const int sgrid = (int)((Mp / 4) < 1024 ? (Mp / 4) : 1024);
+        hipLaunchKernelGGL(fp8_x_stats_kernel, dim3(sgrid), dim3(256), 0, s, c->dxh, Mp, d_p, c->x8_part);
+        hipLaunchKernelGGL(fp8_g_scale_kernel, dim3(1), dim3(256), 0, s, c->x8_part, sgrid, c->scal8);
+        const int64_t n8 = Mp * (d_p / 8);
+        int qgrid = (int)((n8 + 255) / 256);
+        if (qgrid > 2048) qgrid = 2048;
+        hipLaunchKernelGGL(fp8_quant_x_kernel, dim3(qgrid), dim3(256), 0, s, c->dxh, c->dxh8, n8, c->scal8, (int)S8_SG);
+        Gemm8Args g{};
+        g.A = c->dxh8; g.B = c->W8t; g.lda = d_p; g.ldb = d_p;
+        g.nbm = (int)(Mp / 256); g.nbn = n_p / 256; g.ktiles = d_p / 128;
+        EpiDpre8 e{};
+        e.c = c->c; e.dpre = c->dpre; e.db_part = c->db_part; e.scal = c->scal; e.scal8 = c->scal8; e.n_p = n_p;
+        ev_begin(c, KID_DPRE, s);
+        rc = launch_gemm8(g, e, s);
+        ev_end(c, KID_DPRE, s);
+        if (rc) return rc;
+      } else {  // dpre = (dx_hat W + 1/M) [c > 0]
         GemmArgs g{};
         g.A0 = c->dxh; g.B0 = c->Wt; g.lda = d_p; g.ldb = d_p;
         g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;

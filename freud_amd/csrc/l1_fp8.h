@@ -17,8 +17,9 @@
 constexpr float FP8_E4M3_MAX = 448.0f;
 constexpr float FP8_W_SCALE = 256.0f;
 
-// scal8: [0] s_x  [1] 1/(s_x s_w)  [2] s_c  [3] 1/(s_c s_w)  [4] max|x|  [5] latent bound
-enum { S8_SX = 0, S8_INV_ENC = 1, S8_SC = 2, S8_INV_DEC = 3, S8_AMAX_X = 4, S8_C_BOUND = 5, S8_COUNT = 8 };
+// scal8: [0] s_x  [1] 1/(s_x s_w)  [2] s_c  [3] 1/(s_c s_w)  [4] max|x|  [5] latent bound  [6] s_g  [7] 1/(s_g s_w)
+// (s_g: SAE_PREC_FP8_BWD only -- the scale of the quantised dx_hat, the A operand of the fp8 dpre GEMM)
+enum { S8_SX = 0, S8_INV_ENC = 1, S8_SC = 2, S8_INV_DEC = 3, S8_AMAX_X = 4, S8_C_BOUND = 5, S8_SG = 6, S8_INV_DPRE = 7, S8_COUNT = 8 };
 
 __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
   unsigned r = 0;
@@ -112,10 +113,26 @@ __global__ __launch_bounds__(256) void fp8_scales_kernel(const float* __restrict
   }
 }
 
-// x8[M_p][d_p] = e4m3(xb * s_x)
+// s_g = 2^floor(log2(448 / max|dx_hat|)) from the per-block maxima of fp8_x_stats_kernel run over dx_hat
+__global__ __launch_bounds__(256) void fp8_g_scale_kernel(const float* __restrict__ part, int nparts, float* __restrict__ scal8) {
+  __shared__ float red[4];
+  float amax = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) amax = fmaxf(amax, part[2 * i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sg = fp8_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    scal8[S8_SG] = sg;
+    scal8[S8_INV_DPRE] = 1.0f / (sg * FP8_W_SCALE);
+  }
+}
+
+// x8[M_p][d_p] = e4m3(xb * scal8[sidx])      (sidx = S8_SX: the activations; S8_SG: dx_hat)
 __global__ __launch_bounds__(256) void fp8_quant_x_kernel(const bf16_t* __restrict__ xb, unsigned char* __restrict__ x8, int64_t n8,
-                                                          const float* __restrict__ scal8) {
-  const float sx = scal8[S8_SX];
+                                                          const float* __restrict__ scal8, int sidx = S8_SX) {
+  const float sx = scal8[sidx];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const bf16x8 v = reinterpret_cast<const bf16x8*>(xb)[i];
     uint2 o;
@@ -184,5 +201,52 @@ struct EpiEnc8 {
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
+  }
+};
+
+// dpre epilogue of the fp8 dc GEMM (SAE_PREC_FP8_BWD): dpre = (bf16(acc / (s_g s_w)) + 1/M) [c > 0], column sums for db --
+// EpiDpre (l1_kernels.h) with the accumulator un-scaled first; the reference arithmetic is the autograd of
+// src/models/l1autoencoder.py:74,84, here with e4m3 operands for the dx_hat W product.
+struct EpiDpre8 {
+  const bf16_t* c;      // [M_p][n_p]
+  bf16_t* dpre;         // [M_p][n_p]
+  float* db_part;       // [M_p / 128][n_p]
+  const float* scal;    // scal[2] = 1/M
+  const float* scal8;
+  int n_p;
+  float colsum[4];
+  float inv_m, inv;
+  int row_tile, col0_;
+  __device__ void tile_begin(int row0, int col0, int) {
+    colsum[0] = colsum[1] = colsum[2] = colsum[3] = 0.f;
+    inv_m = scal[2];
+    inv = scal8[S8_INV_DPRE];
+    row_tile = row0 / GEMM_BM;
+    col0_ = col0;
+  }
+  struct Pre { bf16x4 cv; };
+  __device__ Pre prefetch(int row, int col) const { return Pre{EPI_LOAD(reinterpret_cast<const bf16x4*>(c + (int64_t)row * n_p + col))}; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre& pre) {
+    const bf16x4 cv = pre.cv;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = ((float)cv[j] > 0.f) ? (bf16_round(v[j] * inv) + inv_m) : 0.f;
+      colsum[j] += g;
+      o[j] = (bf16_t)g;
+    }
+    EPI_STORE(reinterpret_cast<bf16x4*>(dpre + (int64_t)row * n_p + col), o);
+  }
+  __device__ void tile_end(float* scratch) {
+    const int t = threadIdx.x & 255;
+    f32x4 cs = {colsum[0], colsum[1], colsum[2], colsum[3]};
+    *reinterpret_cast<f32x4*>(scratch + (t >> 5) * 128 + (t & 31) * 4) = cs;
+    lds_barrier();
+    if (t < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int gidx = 0; gidx < 8; ++gidx) s += scratch[gidx * 128 + t];
+      db_part[(int64_t)row_tile * n_p + col0_ + t] = s;
+    }
   }
 };

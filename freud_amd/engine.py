@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 VARIANT = {"l1": 0, "topk": 1}
 OPTIMIZER = {"radam": 0, "adam": 1}
 DTYPE = {"float32": 0, "float16": 1, "bfloat16": 2}
-PRECISION = {"bf16": 0, "fp8": 1}
+PRECISION = {"bf16": 0, "fp8": 1, "fp8bwd": 2}      # fp8bwd: fp8 encoder / decoder AND dpre GEMMs (include/freud_sae.h)
 NUM_METRICS = 8
 M_LOSS_RECON, M_LOSS_L1, M_MSE, M_GRAD_NORM, M_COUNT, M_DEAD_PCT, M_MULTI_TOPK_FVU = 0, 1, 2, 3, 4, 5, 6
 

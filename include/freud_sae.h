@@ -83,7 +83,11 @@ typedef struct sae_config {
  * SAE_PREC_FP8 : BASELINE configs[4] -- encoder and decoder GEMMs on OCP e4m3 operands (x, W and the latent quantised
  *                with per-tensor power-of-two scales), fp32 MFMA accumulation, outputs rounded to bf16 like the bf16 path;
  *                the backward GEMMs and the fp32 master weights / optimizer are unchanged. */
-enum { SAE_PREC_BF16 = 0, SAE_PREC_FP8 = 1 };
+/* SAE_PREC_FP8_BWD: SAE_PREC_FP8 plus the dpre GEMM of the backward (dc = dx_hat W: a third of the backward's FLOPs) on e4m3
+ *                operands -- dx_hat quantised per tensor with a power-of-two scale from its own maximum, W as above; the
+ *                weight-gradient GEMMs stay bf16.  Beyond BASELINE configs[4] ("fp8 enc/dec"); an option with a stated cost:
+ *                raw gradients within 5e-2 (rel-Frobenius) of the bf16 arithmetic (tests/test_fp8_gpu.py). */
+enum { SAE_PREC_BF16 = 0, SAE_PREC_FP8 = 1, SAE_PREC_FP8_BWD = 2 };
 
 /* Metrics of the most recent sae_forward_backward / sae_eval (all fp32). */
 enum {

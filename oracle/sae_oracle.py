@@ -173,7 +173,7 @@ def l1_forward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, recon_alpha: f
 
 
 def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str, torch.Tensor],
-                recon_alpha: float, autocast: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                recon_alpha: float, autocast: bool = True, precision: str = "bf16") -> Tuple[torch.Tensor, torch.Tensor]:
     """Hand-written backward of loss = reconstruction_loss + l1_loss (train_sae.py:434,448).
 
       dx_hat = alpha * 2 * (x_hat - x) * [x != -1] / count
@@ -193,7 +193,16 @@ def l1_backward(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, fwd: Dict[str
     if autocast:
         xb, Wb, cb = x.to(BF16), W.to(BF16), c.to(BF16)
         dxb = dx_hat.to(BF16)
-        dc = _mm(dxb, Wb).to(torch.float32) + torch.sign(c) / M
+        if precision == "fp8bwd":
+            # not a reference mode (include/freud_sae.h, SAE_PREC_FP8_BWD): the dx_hat W product on e4m3 operands --
+            # g8 = e4m3(bf16(dx_hat) s_g) with the power-of-two scale of its own maximum, W8 = e4m3(W 2^8), fp32 accumulation,
+            # one rounding to bf16 where the bf16 GEMM rounds; the weight-gradient GEMMs below stay bf16
+            sg = _pow2_scale(float(dxb.to(torch.float32).abs().max()))
+            g8 = _q8(dxb.to(torch.float32) * sg)
+            W8 = _q8(W * FP8_W_SCALE)
+            dc = _r((g8 @ W8) / (sg * FP8_W_SCALE)) + torch.sign(c) / M
+        else:
+            dc = _mm(dxb, Wb).to(torch.float32) + torch.sign(c) / M
         dpre = dc * gate
         dW_dec = _mm(dxb.t(), cb)                        # bf16 [d, n]
         dW_enc = _mm(xb.t(), dpre.to(BF16))              # bf16 [d, n]
@@ -475,8 +484,8 @@ def l1_train_step(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, st: OptStat
     """One iteration of train_sae.py:429-451 for the L1 variant.  W, b updated in place
     (W is first column-normalised in place, as encode() does)."""
     W.copy_(normalize_columns(W))
-    fwd = l1_forward(x, W, b, recon_alpha, autocast, precision)
-    dW, db = l1_backward(x, W, b, fwd, recon_alpha, autocast)
+    fwd = l1_forward(x, W, b, recon_alpha, autocast, "fp8" if precision == "fp8bwd" else precision)
+    dW, db = l1_backward(x, W, b, fwd, recon_alpha, autocast, precision)
     gnorm, (db_c, dW_c) = clip_grad_norm([db, dW], clip_thresh)
     params = {"encoder_bias": b, "decoder.weight": W}
     grads = {"encoder_bias": db_c, "decoder.weight": dW_c}

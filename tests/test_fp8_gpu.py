@@ -128,3 +128,33 @@ def test_fp8_c5_full_size_properties():
     eng.close()
     assert runs[0][0][0] == pytest.approx(ref[0], rel=2e-2)
     assert runs[0][0][1] == pytest.approx(ref[1], rel=2e-2)
+
+
+@pytest.mark.parametrize("d,n,M", [(1280, 2560, 600), (1280, 81920, 512)])
+def test_fp8_dpre_gemm_matches_oracle_and_states_its_cost(d, n, M):
+    """SAE_PREC_FP8_BWD (beyond BASELINE configs[4]): the dc = dx_hat W GEMM of the backward on e4m3 operands.
+    (a) against the oracle's fp8bwd mode (same scale s_g = 2^floor(log2(448 / max|dx_hat|)), torch's e4m3fn rounding): losses
+        as in the fp8 forward test, raw gradients rel-Frobenius 1e-2;
+    (b) what it costs: raw gradients within 5e-2 (rel-Frobenius) of the fp8-forward / bf16-backward arithmetic."""
+    from freud_amd.engine import SaeEngine
+    W, b, x = _case(d, n, M, d + n + M + 1)
+    alpha = 1e4
+    eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=alpha, precision="fp8bwd")
+    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    eng.forward_backward(x.cuda())
+    g = eng.debug_read(2, d * n + n)
+    gW, gb = g[: d * n].reshape(d, n), g[d * n:]
+    m = eng.metrics()
+    Wn = O.normalize_columns(W.clone())
+    f8 = O.l1_forward(x.float(), Wn, b, alpha, True, "fp8")
+    assert m[0] == pytest.approx(f8["reconstruction_loss"].item(), rel=2e-3)
+    assert m[1] == pytest.approx(f8["l1_loss"].item(), rel=2e-3)
+    dW8, db8 = O.l1_backward(x.float(), Wn, b, f8, alpha, True, "fp8bwd")
+    dW16, db16 = O.l1_backward(x.float(), Wn, b, f8, alpha, True)
+    sg = eng.debug_read(7, 8)[6]
+    dxb = ((f8["diff"] * 2.0) * (alpha / f8["count"].to(torch.float32))).to(torch.bfloat16).float()
+    assert sg == O._pow2_scale(float(dxb.abs().max()))
+    assert _rel(gW, dW8.numpy()) < 1e-2 and _rel(gb, db8.numpy()) < 1e-2                 # (a) same quantisation
+    cost_W, cost_b = _rel(gW, dW16.numpy()), _rel(gb, db16.numpy())
+    assert cost_W < 5e-2 and cost_b < 5e-2, (cost_W, cost_b)                             # (b) the stated cost of e4m3 there
+    eng.close()
