@@ -639,6 +639,7 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#pragma clang fp contract(off)      // one rounding per torch op: no fused multiply-adds across them (and the same bits as optimizer_l1_kernel)
       float gj = (g[j] * a.grad_scale) * coef;
       if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
       mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(256) void optimizer_l1_kernel(float* __restrict__ p
     f32x4 pv = *reinterpret_cast<f32x4*>(p + o), mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {       // (the op order of optimizer_kernel, i.e. of torch's single-tensor Adam / RAdam)
+#pragma clang fp contract(off)
       float gj = (g[j] * a.grad_scale) * coef;
       if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
       mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);

@@ -284,3 +284,39 @@ def test_full_size_properties():
         losses.append(m[0] + m[1])
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     eng.close()
+
+
+def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
+    """Round 3 changed HOW the fused d = 384 step is launched, not what it computes: the second forward decomposition
+    (fwd_fused2.h; FREUD_FWD=1 selects the first), the loss finalisation folded into reduce_grads (debug_flags 78 = own kernel),
+    the optimizer that leaves the column-norm partials (debug_flags 79 = flat optimizer + separate pass).  Same arithmetic in
+    the same order: weights and optimizer moments after three steps must be BITWISE equal across all of them (the logged loss
+    scalars agree to fp32 round-off: their partial sums are taken in another order)."""
+    from freud_amd.engine import SaeEngine
+    d, n, M = 384, 1024, 1024
+    g = torch.Generator().manual_seed(5)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    b = 0.01 * torch.randn(n, generator=g)
+    x = ((torch.relu(torch.randn(M, 32, generator=g)) * 0.1) @ torch.randn(32, d, generator=g)).to(torch.bfloat16)
+    x.view(-1)[::501] = -1.0
+    xd = x.cuda()
+    results = []
+    for fwd, dbg in (("2", 0), ("1", 0), ("2", 78), ("2", 79)):
+        monkeypatch.setenv("FREUD_FWD", fwd)
+        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4, debug_flags=dbg)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        for i in range(3):
+            eng.step(xd, 4e-4)
+        _, m1, v1 = eng.get_opt_state()
+        results.append((eng.get_params(), m1, v1, eng.metrics().copy()))
+        eng.close()
+    ref = results[0]
+    names = ["fwd1", "dbg78", "dbg79"]
+    for name, other in zip(names, results[1:]):
+        for k in ref[0]:
+            dw = np.abs(ref[0][k] - other[0][k]).max()
+            assert np.array_equal(ref[0][k], other[0][k]), (name, k, "params", dw)
+            assert np.array_equal(ref[1][k], other[1][k]) and np.array_equal(ref[2][k], other[2][k]), (name, k, "moments")
+        # (the loss SCALARS are sums over per-workgroup partials taken in another order: equal to fp32 round-off, not bitwise)
+        np.testing.assert_allclose(other[3], ref[3], rtol=2e-6, err_msg=name)
