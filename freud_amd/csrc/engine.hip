@@ -135,6 +135,7 @@ struct sae_ctx {
   double* gn_part = nullptr;
   float* cn_part = nullptr;
   bool cn_valid = false;       // cn_part holds the column-norm partials of the CURRENT weights (left by optimizer_l1_kernel)
+  bool wb_valid = false;       // TopK: We_b / Wd_b are the bf16 copies of the CURRENT weights (left by optimizer_kernel)
   sae_grad_ready_fn grad_ready = nullptr;   // data-parallel overlap hook (sae_set_grad_ready_callback)
   void* grad_ready_user = nullptr;
   int dw_chunk_rows = 0;       // generic L1 path: rows (of d_p) per weight-gradient GEMM launch when a hook is set
@@ -531,6 +532,10 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   }
   g_force_gemm128 = cfg->force_gemm128 == 1;
   c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
+  if (const char* ov = getenv("FREUD_DW_SPLITS")) {       // timing sweeps of the split-K factor of the weight-gradient GEMM
+    const int v = atoi(ov);
+    if (v >= 1 && v <= 64) c->dw_splits = v;
+  }
   // with a gradient-ready hook the weight-gradient GEMM is issued in 512-row chunks (d_p >= 1024 only: smaller
   // models finish their gradient in one piece); the chunk's split-K factor keeps its launch rounds full
   c->dw_chunk_rows = c->d_p >= 1024 ? 512 : c->d_p;
@@ -680,6 +685,7 @@ extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, cons
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
   c->cn_valid = false;
+  c->wb_valid = false;
   if (c->topk) {
     if (!p2 || !p3) return fail(SAE_ERR_INVALID, "topk needs 4 parameter tensors");
     float* const ext[4] = {const_cast<float*>(p0), const_cast<float*>(p1), const_cast<float*>(p2), const_cast<float*>(p3)};
@@ -1603,8 +1609,10 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     const int64_t n8 = c->nW / 8;
     int grid = (int)((n8 + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, We, c->We_b, n8);
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, Wd, c->Wd_b, n8);
+    if (!c->wb_valid) {        // (a training step's optimizer already wrote the bf16 copies of the weights it updated)
+      hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, We, c->We_b, n8);
+      hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, Wd, c->Wd_b, n8);
+    }
     if (auxc) hipLaunchKernelGGL(aux_gather_rows_kernel, dim3(n_p / 4), dim3(256), 0, s, c->Wd_b, c->dead_cols, c->tkd, c->Wdd_b, d_p);
     const int64_t chunks = Mp * (d_p / 8);
     int g2 = (int)((chunks + 255) / 256);
@@ -2046,9 +2054,15 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
                        c->n_p, c->gn_part, gblocks, a, c->G + c->nparams, c->cn_part);
     c->cn_valid = true;
   } else {
+    OptCast cast{};
+    if (c->topk) {       // the bf16 copies of W_enc and W_dec leave with the update: no cast pass in the next step
+      cast.off4[0] = 0; cast.len4[0] = c->nW / 4; cast.dst[0] = c->We_b;
+      cast.off4[1] = (c->nW + c->n_p) / 4; cast.len4[1] = c->nW / 4; cast.dst[1] = c->Wd_b;
+    }
     hipLaunchKernelGGL(optimizer_kernel, dim3(oblocks), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, n4, c->gn_part, gblocks,
-                       a, c->G + c->nparams);
+                       a, c->G + c->nparams, cast);
     c->cn_valid = false;
+    c->wb_valid = c->topk;
   }
   if (c->topk)   // train_sae.py:443-446 with the (possibly data-parallel summed) did_fire flags
     hipLaunchKernelGGL(nfsf_update_kernel, dim3((c->n + 255) / 256), dim3(256), 0, s, c->nfsf, c->G + c->nparams + SAE_NUM_METRICS,

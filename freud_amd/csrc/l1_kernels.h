@@ -611,10 +611,17 @@ struct OptArgs {
 
 // clip_grad_norm_ (coef = min(1, thresh/(norm+1e-6))) fused with the torch single-tensor
 // Adam / RAdam update (op order of torch/optim/{adam,radam}.py kept for fp32 agreement).
+// cast (TopK): up to two ranges [off4, off4 + len4) (float4 units) of the parameter vector whose UPDATED values are also written
+// as bf16 (the GEMM / gather copies of W_enc and W_dec: the next step then needs no cast pass over them).
+struct OptCast {
+  int64_t off4[2], len4[2];
+  bf16_t* dst[2];
+};
+
 __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, const float* __restrict__ grad,
                                                          int64_t n4, const double* __restrict__ gn_part, int n_part,
-                                                         OptArgs a, float* __restrict__ metrics) {
+                                                         OptArgs a, float* __restrict__ metrics, OptCast cast) {
   __shared__ double red[4];
   double s = 0;
   for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
@@ -661,6 +668,10 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, f
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (cast.dst[q] && i >= cast.off4[q] && i < cast.off4[q] + cast.len4[q])
+        reinterpret_cast<bf16x4*>(cast.dst[q])[i - cast.off4[q]] = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
   }
 }
 
