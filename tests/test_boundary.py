@@ -71,3 +71,19 @@ def test_inference_models_refuse_cpu_device():
         L1AutoEncoder(16, L1AutoEncoderConfig(expansion_factor=2), device="cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         TopKAutoEncoder(16, TopKAutoEncoderConfig(expansion_factor=2, k=4), device="cpu")
+
+
+def test_dp_mode_selection_from_environment(monkeypatch):
+    """freud_amd/dp.py: FREUD_DP=auto|p2p|rccl|host (FREUD_DP_HOST=1 is the older spelling of host); anything else is refused."""
+    from freud_amd import dp
+    for k in ("FREUD_DP", "FREUD_DP_HOST"):
+        monkeypatch.delenv(k, raising=False)
+    assert dp.requested_mode() == "auto"
+    for m in ("p2p", "rccl", "host", "AUTO"):
+        monkeypatch.setenv("FREUD_DP", m)
+        assert dp.requested_mode() == m.lower()
+    monkeypatch.setenv("FREUD_DP", "ring")
+    with pytest.raises(ValueError):
+        dp.requested_mode()
+    monkeypatch.setenv("FREUD_DP_HOST", "1")
+    assert dp.requested_mode() == "host"
