@@ -1210,8 +1210,9 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
 template <class Epi>
 static int launch_gemm8(const Gemm8Args& g, const Epi& epi, hipStream_t s) {
   auto kern = gemm256_fp8_kernel<Epi>;
-  LDS_ATTR(kern, G2_LDS_BYTES, g_device);
-  hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn), dim3(512), G2_LDS_BYTES, s, g, epi);
+  constexpr int lds = g8_lds_bytes<Epi>();
+  LDS_ATTR(kern, lds, g_device);
+  hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn), dim3(512), lds, s, g, epi);
   HIP_TRY(hipGetLastError());
   return SAE_OK;
 }

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void fp8_cast_w_kernel(const float* __restrict
 // encoder epilogue: c = relu(bf16(acc / (s_x s_w)) + b) (l1autoencoder.py:74), rows >= M forced to 0;
 // stored as bf16 (backward) and as e4m3(c s_c) (decoder operand); L1 partial sum per tile.
 struct EpiEnc8 {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256_fp8.h: s_x s_w is a power of two, bf16(acc) / (s_x s_w) == bf16(acc / (s_x s_w))
   bf16_t* c;            // [M_p][n_p]
   unsigned char* c8;    // [M_p][n_p]
   const float* bias;    // [n_p]
@@ -208,6 +209,8 @@ struct EpiEnc8 {
 // EpiDpre (l1_kernels.h) with the accumulator un-scaled first; the reference arithmetic is the autograd of
 // src/models/l1autoencoder.py:74,84, here with e4m3 operands for the dx_hat W product.
 struct EpiDpre8 {
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // (see EpiEnc8)
+  static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const bf16_t* c;      // [M_p][n_p]
   bf16_t* dpre;         // [M_p][n_p]
   float* db_part;       // [M_p / 128][n_p]

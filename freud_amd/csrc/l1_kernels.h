@@ -198,7 +198,7 @@ struct EpiEnc {
 template <typename T>
 struct EpiDec {
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
-  static constexpr bool ROUNDS_BF16_FIRST = true;     // consulted by the bf16 kernel only, where vs == 1 (the fp8 kernel scales first)
+  static constexpr bool ROUNDS_BF16_FIRST = true;     // (exact in the fp8 kernel too: vs is a power of two, gemm256_fp8.h)
   const T* x;           // original activations [M][d]
   bf16_t* dxh;          // [M_p][d_p]
   const float* scal;    // scal[1] = alpha / count
