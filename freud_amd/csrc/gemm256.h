@@ -44,6 +44,13 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* img, int base32, int kk, i
   else return frag_read<OP_KMAJOR>(img + (base32 >> 7) * 16384, base32 & 127, kk, lane);
 }
 
+// ---- half-granular staging of the k-major x k-major GEMMs (the K loop's ring of four 32 KiB slots: stage x k half) ------
+// A k-major image is k rows of 256 B (g2_src_off), so k rows 32 h .. 32 h + 31 of a sub-image are whole pieces: 8 h .. 8 h + 7
+// of it.  Wave w moves two pieces (q = 0, 1) of each operand per half: k rows 32 h + 8 (w % 4) .. + 7 of sub-image w / 4.
+// (Row-major operands would need half images with 64-byte rows, and LDS-DMA from 64-byte global segments made every
+// row-major shape 8 % slower -- tools/kbench/gemm256_half_row.patch -- so those GEMMs hand their stages over whole.)
+__device__ __forceinline__ int g2h_piece(int w, int h, int q) { return (w >> 2) * 16 + 8 * h + 2 * (w & 3) + q; }
+
 // Epilogue shared by the bf16 and fp8 256x256 kernels: the tile leaves as two passes (sub-tile columns), each pass two
 // 128x128 sub-tiles (rows), one per 256-thread half, through fp32 LDS and the row-major functor.
 template <class Epi>
@@ -159,6 +166,10 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
   if (FINAL_BARRIER) lds_barrier();        // the tile and the scratch areas are free again (persistent instantiation only)
 }
 
+#ifndef G2_HALF_KMAJOR
+#define G2_HALF_KMAJOR 1     // tools/kbench A/B switch: 0 = the k-major GEMMs hand their stages over whole, like the others
+#endif
+
 // One 256x256 output tile (workgroup-level id `blk` of nblk).  g.nbm / g.nbn count 256-wide tiles here.
 template <int AMODE, int BMODE, bool PERSIST, class Epi>
 __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* smem, int blk, int nbm, int nbn, int ktiles0,
@@ -221,6 +232,22 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
     glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
   };
+  // HALF (k-major x k-major: the weight-gradient GEMMs, K = the batch rows, every operand byte streams from HBM once): the
+  // two stages are handed over in k HALVES -- a ring of four 32 KiB slots, three half tiles (1.5 K tiles) of lead for every
+  // piece instead of one tile.  With whole-stage hand-over a wave waited ~410 cycles per K tile for its own pieces
+  // (tools/kbench -DG2X_WAITSTAMP); with halves ~20, and the GEMM is 5-7 % faster with bit-identical output.
+  constexpr bool HALF = G2_HALF_KMAJOR && AMODE == OP_KMAJOR && BMODE == OP_KMAJOR;
+  if constexpr (HALF) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      voff_a[q] = g2_src_off<AMODE>(g2h_piece(w, q >> 1, q & 1), lane, g.lda);
+      voff_b[q] = g2_src_off<BMODE>(g2h_piece(w, q >> 1, q & 1), lane, g.ldb);
+    }
+  }
+  auto issue_h = [&](int kt, int stage, int h, int q) {
+    const unsigned dst = smem_base + stage * G2_STAGE_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(g2h_piece(w, h, q) * 1024);
+    glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[2 * h + q], voff_b[2 * h + q], dst, dst + G2_OPER_BYTES);
+  };
 
   // Tile t lives in stage t & 1.  The hand-over barrier B_t sits inside the LAST MFMA group of tile t: by then every
   // fragment of tile t is in registers and tile t+1 has landed, so the slots after B_t already read tile t+1's first
@@ -233,31 +260,44 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   const int kt_last = kt_end - 1;
   auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
   bf16x8 fa[2][4], fb[2][2];
+  auto frag_a = [&](const char* img, int base32, int ks) { return g2_frag<AMODE>(img, base32, ks, lane); };
+  auto frag_b = [&](const char* img, int base32, int ks) { return g2_frag<BMODE>(img, base32, ks, lane); };
   if (kt_begin < kt_end) {
+    if constexpr (HALF) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue(kt_begin, 0, q);
+      for (int q = 0; q < 4; ++q) issue_h(kt_begin, 0, q >> 1, q & 1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue(clampk(kt_begin + 1), 1, q);
+      for (int q = 0; q < 4; ++q) issue_h(clampk(kt_begin + 1), 1, q >> 1, q & 1);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue(kt_begin, 0, q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue(clampk(kt_begin + 1), 1, q);
+    }
   }
 #ifdef G2X_PROLOGUE_WAIT_ALL
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
   // only tile 0 has to be there (this wave's 8 older DMA instructions); tile 1 keeps landing under tile 0's MFMAs and is
   // waited for at the first hand-over barrier, like every later tile
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (HALF) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the first HALF of tile 0 (4 of this wave's 16 DMA instructions)
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
   __syncthreads();
   if (kt_begin < kt_end) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = g2_frag<AMODE>(smem, 128 * wm + 32 * i, 0, lane);
+    for (int i = 0; i < 4; ++i) fa[0][i] = frag_a(smem, 128 * wm + 32 * i, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = g2_frag<BMODE>(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+    for (int j = 0; j < 2; ++j) fb[0][j] = frag_b(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0);
   }
 
 #ifdef G2X_STAMP
   st1 = __builtin_readcyclecounter();
 #endif
   int cur = 0;
+#ifdef G2X_WAITSTAMP
+  unsigned long long g2x_wait_vm = 0, g2x_wait_bar = 0;
+#endif
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const char* sa = smem + cur * G2_STAGE_BYTES;
     const char* sb = sa + G2_OPER_BYTES;
@@ -265,8 +305,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     const char* nb = na + G2_OPER_BYTES;
     // fragment f (0..3: A rows 32 f, 4..5: B columns 32 (f - 4)) of K step `ks` of the tile whose images are (ia, ib)
     auto ldfrag = [&](const char* ia, const char* ib, int ks, int f) {
-      if (f < 4) fa[ks & 1][f] = g2_frag<AMODE>(ia, 128 * wm + 32 * f, ks, lane);
-      else fb[ks & 1][f - 4] = g2_frag<BMODE>(ib, 64 * wn + 32 * (f - 4), ks, lane);
+      if (f < 4) fa[ks & 1][f] = frag_a(ia, 128 * wm + 32 * f, ks);
+      else fb[ks & 1][f - 4] = frag_b(ib, 64 * wn + 32 * (f - 4), ks);
     };
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -274,6 +314,38 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       for (int m = 0; m < 8; ++m) {
         acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], acc[m >> 1][m & 1], 0, 0, 0);   // D^T = B A^T
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF) {
+          // half u = (kt, kk / 2).  Even K step: the fragments of the odd one.  Odd K step: hand-over H_u -- half u + 1 has
+          // landed (this wave: all but its 8 youngest DMA instructions, the halves u + 2 and u + 3), every fragment of
+          // half u is in registers -- then half u + 4 into the freed slot and the first fragments of half u + 1.
+          if ((kk & 1) == 0) {
+            if (m < 6) ldfrag(sa, sb, kk + 1, m);
+          } else {
+            const char* ia = kk == 1 ? sa : na;
+            const char* ib = kk == 1 ? sb : nb;
+            const int ks = kk == 1 ? 2 : 0;
+            if (m == 1) {
+#ifdef G2X_WAITSTAMP
+              const unsigned long long w0 = __builtin_readcyclecounter();
+              asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              const unsigned long long w1 = __builtin_readcyclecounter();
+              __syncthreads();
+              const unsigned long long w2 = __builtin_readcyclecounter();
+              g2x_wait_vm += w1 - w0; g2x_wait_bar += w2 - w1;
+#else
+              asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              __syncthreads();
+#endif
+            } else if (m == 2) {
+              issue_h(clampk(kt + 2), cur, kk >> 1, 0);
+            } else if (m >= 3 && m <= 5) {
+              ldfrag(ia, ib, ks, 2 * (m - 3));
+              ldfrag(ia, ib, ks, 2 * (m - 3) + 1);
+            } else if (m == 6) {
+              issue_h(clampk(kt + 2), cur, kk >> 1, 1);
+            }
+          }
+        } else
         if (kk == 0) {            // second half of tile kt+1's pieces + the fragments of K step 1
           if (m == 0) issue(clampk(kt + 1), cur ^ 1, 2);
           else if (m == 3) issue(clampk(kt + 1), cur ^ 1, 3);
@@ -282,8 +354,17 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
           if (m < 6) ldfrag(sa, sb, kk + 1, m);
         } else {                  // hand-over, first half of tile kt+2's pieces, tile kt+1's first fragments
           if (m == 1) {
+#ifdef G2X_WAITSTAMP
+            const unsigned long long w0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long w1 = __builtin_readcyclecounter();
+            __syncthreads();
+            const unsigned long long w2 = __builtin_readcyclecounter();
+            g2x_wait_vm += w1 - w0; g2x_wait_bar += w2 - w1;
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
             __syncthreads();                                    // B_kt: ... and everybody's; all reads of this stage are done
+#endif
           } else if (m == 2) {
             issue(clampk(kt + 2), cur, 0);
           } else if (m == 3) {
@@ -317,6 +398,9 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     unsigned long long st3 = __builtin_readcyclecounter();
     unsigned long long* o = g2x_stamps + 4 * (size_t)blk;
     o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st3 - st2; o[3] = st0;
+#ifdef G2X_WAITSTAMP
+    o[0] = g2x_wait_vm; o[2] = g2x_wait_bar;      // (wave 0's waits at the hand-over barriers, summed over the K tiles)
+#endif
   }
 #endif
 }

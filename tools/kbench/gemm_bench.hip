@@ -141,6 +141,13 @@ int main(int argc, char** argv) {
            a / ntile, b / ntile, c / ntile, 100 * a / (a + b + c), 100 * b / (a + b + c), 100 * c / (a + b + c));
   }
 #endif
+  if (kmajor == 1 && getenv("KB_HASH")) {      // FNV-1a over the fp32 slab bits: two builds of the k-major kernel must print the same value
+    std::vector<unsigned> hs((size_t)splits * M * N);
+    CK(hipMemcpy(hs.data(), slab, hs.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;
+    for (unsigned v : hs) { hsh ^= v; hsh *= 1099511628211ull; }
+    printf("slab hash %016llx\n", hsh);
+  }
   const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
   printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
          (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
