@@ -166,6 +166,17 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
   if (FINAL_BARRIER) lds_barrier();        // the tile and the scratch areas are free again (persistent instantiation only)
 }
 
+// Functors of long-K row-major GEMMs whose A operand streams from HBM (static constexpr bool DEEP_A_RING: the decoder,
+// x_hat = c W^T with K = n_dict) get a THREE-deep ring for the A tiles (see the K loop).
+template <class E, class = void>
+struct epi_deep_a_ring { static constexpr bool value = false; };
+template <class E>
+struct epi_deep_a_ring<E, std::void_t<decltype(E::DEEP_A_RING)>> { static constexpr bool value = E::DEEP_A_RING; };
+constexpr int G2_A3_LDS_BYTES = 5 * G2_OPER_BYTES;      // 3 A slots + 2 B slots = 160 KiB: the whole LDS of a CU
+
+#ifndef G2_A3
+#define G2_A3 1              // tools/kbench A/B switch: 0 = no three-deep A ring (Epi::DEEP_A_RING ignored)
+#endif
 #ifndef G2_HALF_KMAJOR
 #define G2_HALF_KMAJOR 1     // tools/kbench A/B switch: 0 = the k-major GEMMs hand their stages over whole, like the others
 #endif
@@ -232,6 +243,20 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
     glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
   };
+  // A3 (row-major x row-major with Epi::DEEP_A_RING: the decoder, K = n_dict, whose A operand -- the latent -- streams from
+  // HBM while the weight panel stays in L2): three 32 KiB slots for the A tiles at LDS 0, two for the B tiles behind them.
+  // A tile t + 2 is requested at the START of tile t (into the slot tile t - 1 left at its hand-over): two tiles of lead;
+  // B tile t + 2 right after hand-over t, as before.  With two whole stages a wave waited ~770 cycles per K tile for its
+  // own pieces at this shape (tools/kbench -DG2X_WAITSTAMP).
+  constexpr bool A3 = G2_A3 && epi_deep_a_ring<Epi>::value && AMODE == OP_ROW && BMODE == OP_ROW;
+  auto issue_aa = [&](int kt, int slot, int qp) {
+    const unsigned dst = smem_base + slot * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(a_ptr(kt), a_ptr(kt), voff_a[2 * qp], voff_a[2 * qp + 1], dst, dst + 1024);
+  };
+  auto issue_bb = [&](int kt, int slot, int qp) {
+    const unsigned dst = smem_base + (3 + slot) * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(b_ptr(kt), b_ptr(kt), voff_b[2 * qp], voff_b[2 * qp + 1], dst, dst + 1024);
+  };
   // HALF (k-major x k-major: the weight-gradient GEMMs, K = the batch rows, every operand byte streams from HBM once): the
   // two stages are handed over in k HALVES -- a ring of four 32 KiB slots, three half tiles (1.5 K tiles) of lead for every
   // piece instead of one tile.  With whole-stage hand-over a wave waited ~410 cycles per K tile for its own pieces
@@ -263,7 +288,12 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   auto frag_a = [&](const char* img, int base32, int ks) { return g2_frag<AMODE>(img, base32, ks, lane); };
   auto frag_b = [&](const char* img, int base32, int ks) { return g2_frag<BMODE>(img, base32, ks, lane); };
   if (kt_begin < kt_end) {
-    if constexpr (HALF) {
+    if constexpr (A3) {
+      issue_aa(kt_begin, 0, 0); issue_aa(kt_begin, 0, 1);
+      issue_bb(kt_begin, 0, 0); issue_bb(kt_begin, 0, 1);
+      issue_bb(clampk(kt_begin + 1), 1, 0); issue_bb(clampk(kt_begin + 1), 1, 1);
+      issue_aa(clampk(kt_begin + 1), 1, 0); issue_aa(clampk(kt_begin + 1), 1, 1);
+    } else if constexpr (HALF) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) issue_h(kt_begin, 0, q >> 1, q & 1);
 #pragma unroll
@@ -288,7 +318,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = frag_a(smem, 128 * wm + 32 * i, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = frag_b(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0);
+    for (int j = 0; j < 2; ++j) fb[0][j] = frag_b(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, 64 * wn + 32 * j, 0);
   }
 
 #ifdef G2X_STAMP
@@ -298,11 +328,13 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #ifdef G2X_WAITSTAMP
   unsigned long long g2x_wait_vm = 0, g2x_wait_bar = 0;
 #endif
+  int aslot = 0;        // A3: the A slot of tile kt
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const char* sa = smem + cur * G2_STAGE_BYTES;
-    const char* sb = sa + G2_OPER_BYTES;
-    const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
-    const char* nb = na + G2_OPER_BYTES;
+    const int anext = aslot == 2 ? 0 : aslot + 1, aprev = anext == 2 ? 0 : anext + 1;
+    const char* sa = A3 ? smem + aslot * G2_OPER_BYTES : smem + cur * G2_STAGE_BYTES;
+    const char* sb = A3 ? smem + (3 + cur) * G2_OPER_BYTES : sa + G2_OPER_BYTES;
+    const char* na = A3 ? smem + anext * G2_OPER_BYTES : smem + (cur ^ 1) * G2_STAGE_BYTES;
+    const char* nb = A3 ? smem + (3 + (cur ^ 1)) * G2_OPER_BYTES : na + G2_OPER_BYTES;
     // fragment f (0..3: A rows 32 f, 4..5: B columns 32 (f - 4)) of K step `ks` of the tile whose images are (ia, ib)
     auto ldfrag = [&](const char* ia, const char* ib, int ks, int f) {
       if (f < 4) fa[ks & 1][f] = frag_a(ia, 128 * wm + 32 * f, ks);
@@ -346,9 +378,9 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
             }
           }
         } else
-        if (kk == 0) {            // second half of tile kt+1's pieces + the fragments of K step 1
-          if (m == 0) issue(clampk(kt + 1), cur ^ 1, 2);
-          else if (m == 3) issue(clampk(kt + 1), cur ^ 1, 3);
+        if (kk == 0) {            // second half of tile kt+1's pieces (A3: A tile kt+2) + the fragments of K step 1
+          if (m == 0) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 0); else issue(clampk(kt + 1), cur ^ 1, 2); }
+          else if (m == 3) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 1); else issue(clampk(kt + 1), cur ^ 1, 3); }
           else ldfrag(sa, sb, 1, m < 3 ? m - 1 : m - 2);
         } else if (kk < 3) {      // the fragments of K step kk + 1
           if (m < 6) ldfrag(sa, sb, kk + 1, m);
@@ -356,16 +388,19 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
           if (m == 1) {
 #ifdef G2X_WAITSTAMP
             const unsigned long long w0 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long w1 = __builtin_readcyclecounter();
             __syncthreads();
             const unsigned long long w2 = __builtin_readcyclecounter();
             g2x_wait_vm += w1 - w0; g2x_wait_bar += w2 - w1;
 #else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+            if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but A tile kt+2 (this wave's 4 youngest DMA instructions)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
             __syncthreads();                                    // B_kt: ... and everybody's; all reads of this stage are done
 #endif
           } else if (m == 2) {
+            if constexpr (A3) issue_bb(clampk(kt + 2), cur, 0); else
             issue(clampk(kt + 2), cur, 0);
           } else if (m == 3) {
             ldfrag(na, nb, 0, 0);
@@ -377,6 +412,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
             ldfrag(na, nb, 0, 4);
             ldfrag(na, nb, 0, 5);
           } else if (m == 6) {
+            if constexpr (A3) issue_bb(clampk(kt + 2), cur, 1); else
             issue(clampk(kt + 2), cur, 1);
           }
         }
@@ -384,6 +420,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       }
     }
     cur ^= 1;
+    aslot = anext;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
   __syncthreads();

@@ -77,13 +77,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
     const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
     glds16_x2(a_base + (int64_t)kt * 128, b_base + (int64_t)kt * 128, voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
   };
+  // A3 (Epi::DEEP_A_RING, the decoder: K = n_dict, the fp8 latent streams from HBM): three A slots at LDS 0, two B slots
+  // behind them; A tile kt + 2 is requested at the START of tile kt, B tile kt + 2 after hand-over kt -- gemm256.h.
+  constexpr bool A3 = G2_A3 && epi_deep_a_ring<Epi>::value;
+  auto issue_aa = [&](int kt, int slot, int qp) {
+    const unsigned dst = smem_base + slot * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    const unsigned char* src = a_base + (int64_t)kt * 128;
+    glds16_x2(src, src, voff_a[2 * qp], voff_a[2 * qp + 1], dst, dst + 1024);
+  };
+  auto issue_bb = [&](int kt, int slot, int qp) {
+    const unsigned dst = smem_base + (3 + slot) * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    const unsigned char* src = b_base + (int64_t)kt * 128;
+    glds16_x2(src, src, voff_b[2 * qp], voff_b[2 * qp + 1], dst, dst + 1024);
+  };
 
   const int kt_last = g.ktiles - 1;
   auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
+  if constexpr (A3) {
+    issue_aa(0, 0, 0); issue_aa(0, 0, 1);
+    issue_bb(0, 0, 0); issue_bb(0, 0, 1);
+    issue_bb(clampk(1), 1, 0); issue_bb(clampk(1), 1, 1);
+    issue_aa(clampk(1), 1, 0); issue_aa(clampk(1), 1, 1);
+  } else {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue(0, 0, q);
+    for (int q = 0; q < 4; ++q) issue(0, 0, q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue(clampk(1), 1, q);
+    for (int q = 0; q < 4; ++q) issue(clampk(1), 1, q);
+  }
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 only (8 older DMA instructions); tile 1 is waited for at the first hand-over
   __syncthreads();
 
@@ -91,14 +111,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
 #pragma unroll
   for (int i = 0; i < 4; ++i) fa[i] = g8_frag(smem, 128 * wm + 32 * i, 0, lane);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+  for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
 
-  int cur = 0;
+  int cur = 0, aslot = 0;
   for (int kt = 0; kt < g.ktiles; ++kt) {
-    const char* sa = smem + cur * G2_STAGE_BYTES;
-    const char* sb = sa + G2_OPER_BYTES;
-    const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
-    const char* nb = na + G2_OPER_BYTES;
+    const int anext = aslot == 2 ? 0 : aslot + 1, aprev = anext == 2 ? 0 : anext + 1;
+    const char* sa = A3 ? smem + aslot * G2_OPER_BYTES : smem + cur * G2_STAGE_BYTES;
+    const char* sb = A3 ? smem + (3 + cur) * G2_OPER_BYTES : sa + G2_OPER_BYTES;
+    const char* na = A3 ? smem + anext * G2_OPER_BYTES : smem + (cur ^ 1) * G2_STAGE_BYTES;
+    const char* nb = A3 ? smem + (3 + (cur ^ 1)) * G2_OPER_BYTES : na + G2_OPER_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // where the NEXT step's fragments come from: step 1 of this tile, or step 0 of the next tile (other stage)
@@ -106,13 +127,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
       const char* xb = s == 0 ? sb : nb;
       const int xs = s == 0 ? 1 : 0;
       if (s == 0) {            // second half of tile kt+1's pieces (its first half left right after the last hand-over)
-        issue(clampk(kt + 1), cur ^ 1, 2);
-        issue(clampk(kt + 1), cur ^ 1, 3);
+        if constexpr (A3) {    // ... A3: A tile kt+2 into the slot tile kt-1 left
+          issue_aa(clampk(kt + 2), aprev, 0);
+          issue_aa(clampk(kt + 2), aprev, 1);
+        } else {
+          issue(clampk(kt + 1), cur ^ 1, 2);
+          issue(clampk(kt + 1), cur ^ 1, 3);
+        }
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+        if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but A tile kt+2 (this wave's 4 youngest DMA instructions)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
         __syncthreads();                                    // ... and everybody's; every read of this stage has returned
-        issue(clampk(kt + 2), cur, 0);
-        issue(clampk(kt + 2), cur, 1);
+        if constexpr (A3) {
+          issue_bb(clampk(kt + 2), cur, 0);
+          issue_bb(clampk(kt + 2), cur, 1);
+        } else {
+          issue(clampk(kt + 2), cur, 0);
+          issue(clampk(kt + 2), cur, 1);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[xs][j] = g8_frag(xb, 64 * wn + 32 * j, xs, lane);
@@ -127,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
       }
     }
     cur ^= 1;
+    aslot = anext;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing re-copies before LDS is reused
   __syncthreads();
@@ -139,5 +172,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
 
 template <class Epi>
 constexpr int g8_lds_bytes() {
-  return epi_rounds_first<Epi>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
+  return G2_A3 && epi_deep_a_ring<Epi>::value ? G2_A3_LDS_BYTES
+         : epi_rounds_first<Epi>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
 }

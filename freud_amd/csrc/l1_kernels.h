@@ -199,6 +199,7 @@ template <typename T>
 struct EpiDec {
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   static constexpr bool ROUNDS_BF16_FIRST = true;     // (exact in the fp8 kernel too: vs is a power of two, gemm256_fp8.h)
+  static constexpr bool DEEP_A_RING = true;           // gemm256.h: K = n_dict, the latent streams from HBM
   const T* x;           // original activations [M][d]
   bf16_t* dxh;          // [M_p][d_p]
   const float* scal;    // scal[1] = alpha / count

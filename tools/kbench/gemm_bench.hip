@@ -13,6 +13,9 @@
 #include "../../freud_amd/csrc/l1_kernels.h"
 
 struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias / ReLU)
+#ifdef KB_A3
+  static constexpr bool DEEP_A_RING = true;      // three-deep A ring (the decoder's form)
+#endif
   bf16_t* out;
   int64_t ld;
   __device__ void tile_begin(int, int, int) {}
@@ -75,8 +78,9 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(KB_PERSIST), dim3(512), G2_LDS_BYTES, 0, g, e);
 #else
       auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16>;
-      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
+      constexpr int lds = epi_deep_a_ring<EpiBf16>::value ? G2_A3_LDS_BYTES : G2_LDS_BYTES;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), lds, 0, g, e);
 #endif
     } else {
       EpiSlab e{};
