@@ -1174,7 +1174,7 @@ template <int AM, int BM_, class Epi>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
   if (!g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0) {   // both output dimensions are multiples of 256
     auto kern256 = gemm256_bf16_kernel<AM, BM_, Epi>;
-    constexpr bool a3 = G2_A3 && epi_deep_a_ring<Epi>::value && AM == OP_ROW && BM_ == OP_ROW;     // (gemm256.h: three A slots + two B slots)
+    constexpr bool a3 = G2_A3 && epi_deep_a_ring<Epi>::value;     // (gemm256.h: three A slots + two B slots)
     constexpr int lds256 = a3 ? G2_A3_LDS_BYTES : (epi_rounds_first<Epi>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES) ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
     static_assert(G2_A3_LDS_BYTES >= G2_BF16_LDS_BYTES && G2_A3_LDS_BYTES >= G2_LDS_BYTES, "the epilogues reuse the ring's LDS");
     LDS_ATTR(kern256, lds256, g_device);

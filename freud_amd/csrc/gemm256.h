@@ -248,7 +248,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   // A tile t + 2 is requested at the START of tile t (into the slot tile t - 1 left at its hand-over): two tiles of lead;
   // B tile t + 2 right after hand-over t, as before.  With two whole stages a wave waited ~770 cycles per K tile for its
   // own pieces at this shape (tools/kbench -DG2X_WAITSTAMP).
-  constexpr bool A3 = G2_A3 && epi_deep_a_ring<Epi>::value && AMODE == OP_ROW && BMODE == OP_ROW;
+  constexpr bool A3 = G2_A3 && epi_deep_a_ring<Epi>::value;
   auto issue_aa = [&](int kt, int slot, int qp) {
     const unsigned dst = smem_base + slot * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
     glds16_x2(a_ptr(kt), a_ptr(kt), voff_a[2 * qp], voff_a[2 * qp + 1], dst, dst + 1024);
@@ -261,7 +261,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   // two stages are handed over in k HALVES -- a ring of four 32 KiB slots, three half tiles (1.5 K tiles) of lead for every
   // piece instead of one tile.  With whole-stage hand-over a wave waited ~410 cycles per K tile for its own pieces
   // (tools/kbench -DG2X_WAITSTAMP); with halves ~20, and the GEMM is 5-7 % faster with bit-identical output.
-  constexpr bool HALF = G2_HALF_KMAJOR && AMODE == OP_KMAJOR && BMODE == OP_KMAJOR;
+  constexpr bool HALF = !A3 && G2_HALF_KMAJOR && AMODE == OP_KMAJOR && BMODE == OP_KMAJOR;
   if constexpr (HALF) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -28,6 +28,12 @@ struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias
   __device__ void tile_end(float*) {}
 };
 
+#ifdef KB_A3
+struct EpiSlabK : EpiSlab { static constexpr bool DEEP_A_RING = true; };
+#else
+typedef EpiSlab EpiSlabK;
+#endif
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -83,11 +89,12 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), lds, 0, g, e);
 #endif
     } else {
-      EpiSlab e{};
+      EpiSlabK e{};
       e.slab = slab; e.slab_stride = M * N; e.ld = (int)N;
-      auto kern = gemm256_bf16_kernel<OP_KMAJOR, OP_KMAJOR, EpiSlab>;
-      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
-      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), G2_LDS_BYTES, 0, g, e);
+      auto kern = gemm256_bf16_kernel<OP_KMAJOR, OP_KMAJOR, EpiSlabK>;
+      constexpr int lds = epi_deep_a_ring<EpiSlabK>::value ? G2_A3_LDS_BYTES : G2_LDS_BYTES;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), lds, 0, g, e);
     }
   };
   if (compare) {
