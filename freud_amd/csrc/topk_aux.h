@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void aux_gather_rows_kernel(const bf16_t* __re
 // squares per 128x128 tile -> part[tile] (the caller zero-fills part[0 .. M_p) first; topk_finalize_kernel sums all of it).
 struct EpiAuxDecode {
   static constexpr bool ROUNDS_BF16_FIRST = true;     // gemm256.h: the tile goes through LDS as bf16
+  static constexpr bool DEEP_A_RING = true;           // gemm256.h: K = the dead latents, the AuxK activations stream from HBM
   static constexpr int PREFETCH_BATCH = EPI_BATCH_HEAVY;
   const float* e;       // [M_p][d_p]
   const float* b_dec;   // [d_p]
