@@ -136,6 +136,14 @@ struct sae_ctx {
   float* cn_part = nullptr;
   bool cn_valid = false;       // cn_part holds the column-norm partials of the CURRENT weights (left by optimizer_l1_kernel)
   bool wb_valid = false;       // TopK: We_b / Wd_b are the bf16 copies of the CURRENT weights (left by optimizer_kernel)
+  // L1, d_p <= 384 (optimizer_l1_cols_kernel): the update left the fp32 master UN-normalised (the reference's state after
+  // optimizer.step()), the column denominators in cnorm and the bf16 copies Wb / Wt of the NORMALISED weights.
+  //   wn_pending              that state holds;
+  //   wn_fwd_seen             ... and one forward has used the copies since: the reference's W is normalised by now
+  //                           (l1autoencoder.py:71-73), ours is so in effect -- the next update divides while loading, any other
+  //                           reader of the master (settle_weights) has the division carried out first.
+  float* cnorm = nullptr;
+  bool wn_pending = false, wn_fwd_seen = false;
   sae_grad_ready_fn grad_ready = nullptr;   // data-parallel overlap hook (sae_set_grad_ready_callback)
   void* grad_ready_user = nullptr;
   int dw_chunk_rows = 0;       // generic L1 path: rows (of d_p) per weight-gradient GEMM launch when a hook is set
@@ -456,7 +464,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part, c->dxh8,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
-                  c->aux_dbe_part, c->be_r};
+                  c->aux_dbe_part, c->be_r, c->cnorm};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
@@ -594,6 +602,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->scal, 16 * 4);
   ALLOC(c->gn_part, 1024 * 8);
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
+  ALLOC(c->cnorm, (int64_t)c->n_p * 4);
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
   c->stats_cap = DP_STATS_HEAD;
@@ -679,6 +688,21 @@ static int xfer_flat_topk(sae_ctx* c, float* internal, float* const ext[4], int 
   return SAE_OK;
 }
 
+// Brings the fp32 master of an L1 context to what the reference holds at this point (see sae_ctx::wn_pending): if a forward
+// has run since the last update, the in-place normalisation it stands for is carried out.  Afterwards the next forward takes
+// the plain path (column norms + normalize_cast), exactly as if the folded update had never been used.
+static void settle_weights(sae_ctx* c, hipStream_t s) {
+  if (!c->wn_pending) return;
+  if (c->wn_fwd_seen) {
+    const int64_t n4 = c->nW / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(normalize_inplace_kernel, dim3(grid), dim3(256), 0, s, c->P, c->cnorm, n4, c->n_p);
+  }
+  c->wn_pending = c->wn_fwd_seen = false;
+  c->cn_valid = false;
+}
+
 extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, const float* p2, const float* p3, int is_device) {
   if (!c || !p0 || !p1) return fail(SAE_ERR_INVALID, "null argument");
   USE_DEVICE(c);
@@ -686,6 +710,7 @@ extern "C" int sae_set_params(sae_ctx* c, const float* p0, const float* p1, cons
   HIP_TRY(hipMemset(c->P, 0, c->nparams * 4));
   c->cn_valid = false;
   c->wb_valid = false;
+  c->wn_pending = c->wn_fwd_seen = false;
   if (c->topk) {
     if (!p2 || !p3) return fail(SAE_ERR_INVALID, "topk needs 4 parameter tensors");
     float* const ext[4] = {const_cast<float*>(p0), const_cast<float*>(p1), const_cast<float*>(p2), const_cast<float*>(p3)};
@@ -698,6 +723,10 @@ extern "C" int sae_get_params(sae_ctx* c, float* p0, float* p1, float* p2, float
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
   USE_DEVICE(c);
   HIP_TRY(hipDeviceSynchronize());
+  if (c->wn_pending) {
+    settle_weights(c, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+  }
   if (c->topk) {
     float* const ext[4] = {p0, p1, p2, p3};
     return xfer_flat_topk(c, c->P, ext, 0, is_device);
@@ -1230,11 +1259,18 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
   float* b = c->P + c->nW;
 
   ev_begin(c, KID_PREP_W, s);
-  // (a training step's optimizer left the column-norm partials of the weights it wrote: optimizer_l1_kernel)
-  if (!c->cn_valid) hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 128, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
-  c->cn_valid = false;        // normalize_cast rewrites W in place: the partials describe the weights before it
-  hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
-                     c->Wt, d_p, n_p);
+  if (c->wn_pending && !c->wn_fwd_seen) {
+    // the update of the last training step already wrote Wb / Wt for the normalised weights (optimizer_l1_cols_kernel): this
+    // forward IS the reference's in-place normalisation -- no kernel
+    c->wn_fwd_seen = true;
+  } else {
+    settle_weights(c, s);       // (a second forward since the update: the first one's normalisation becomes real, then the usual one)
+    // (a training step's optimizer left the column-norm partials of the weights it wrote: optimizer_l1_kernel)
+    if (!c->cn_valid) hipLaunchKernelGGL(colnorm_partial_kernel, dim3(n_p / 128, d_p / 32), dim3(256), 0, s, W, c->cn_part, n_p);
+    c->cn_valid = false;        // normalize_cast rewrites W in place: the partials describe the weights before it
+    hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
+                       c->Wt, d_p, n_p);
+  }
   if (c->fp8) hipLaunchKernelGGL(fp8_cast_w_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->W8, c->W8t, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
@@ -2052,11 +2088,22 @@ extern "C" int sae_optimizer_step(sae_ctx* c, double lr, double grad_scale, void
   c->gn_valid = false;
   int oblocks = (int)((n4 + 255) / 256);
   if (oblocks > 2048) oblocks = 2048;
-  if (!c->topk && c->cfg.debug_flags != 79) {      // L1: tiled update that also leaves the column-norm partials of the new weights
+  if (!c->topk && !c->fp8 && c->d_p <= 384 && c->cfg.debug_flags != 79 && c->cfg.debug_flags != 80) {
+    // L1, small d: the update that also prepares the next forward's weights (column norms, bf16 copies)
+    const int norm_on_load = (c->wn_pending && c->wn_fwd_seen) ? 1 : 0;
+    hipLaunchKernelGGL(optimizer_l1_cols_kernel, dim3(c->n_p / OPTC_COLS + c->n_p / 128), dim3(OPTC_THREADS), optc_lds_bytes(c->d_p), s, c->P,
+                       c->Mom, c->Var, c->G, c->d_p, c->n_p, c->gn_part, gblocks, a, c->G + c->nparams, c->cnorm, norm_on_load, c->Wb,
+                       c->Wt);
+    c->wn_pending = true;
+    c->wn_fwd_seen = false;
+    c->cn_valid = false;
+  } else if (!c->topk && c->cfg.debug_flags != 79) {      // L1: tiled update that also leaves the column-norm partials of the new weights
+    settle_weights(c, s);
     hipLaunchKernelGGL(optimizer_l1_kernel, dim3(c->n_p / 128, c->d_p / 32 + 1), dim3(256), 0, s, c->P, c->Mom, c->Var, c->G, c->d_p,
                        c->n_p, c->gn_part, gblocks, a, c->G + c->nparams, c->cn_part);
     c->cn_valid = true;
   } else {
+    if (!c->topk) settle_weights(c, s);
     OptCast cast{};
     if (c->topk) {       // the bf16 copies of W_enc and W_dec leave with the update: no cast pass in the next step
       cast.off4[0] = 0; cast.len4[0] = c->nW / 4; cast.dst[0] = c->We_b;
@@ -2274,6 +2321,7 @@ extern "C" int sae_decode(sae_ctx* c, const void* latent, int latent_dtype, int6
     rc = launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
   } else {
     // current W [d_p][n_p] as is (decode() does not renormalise); the copy is refreshed by the next forward anyway
+    settle_weights(c, s);
     const int64_t n8 = c->nW / 8;
     int cg = (int)((n8 + 255) / 256);
     if (cg > 2048) cg = 2048;

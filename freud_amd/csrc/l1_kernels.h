@@ -12,7 +12,9 @@
 // ------------------------------------------------------------------------------------------
 // The partial sum of a (32-row slab, column) has ONE definition, shared with optimizer_l1_kernel (which leaves the same
 // partials of the weights it has just updated, so that a training step needs no colnorm pass): thread ty of 8 adds the
-// squares of rows ty, ty + 8, ty + 16, ty + 24 in that order, the eight results are added as ((0+1)+(2+3))+((4+5)+(6+7)).
+// squares of rows ty, ty + 8, ty + 16, ty + 24 in that order (ss = fma(v, v, ss) from 0: spelled out, so that every kernel
+// that forms these sums -- colnorm_partial, optimizer_l1, optimizer_l1_cols -- rounds alike whatever the compiler would
+// contract), the eight results are added as ((0+1)+(2+3))+((4+5)+(6+7)).
 __device__ __forceinline__ float colnorm_tree8(const float (*red)[128], int col) {
   return ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
 }
@@ -27,7 +29,8 @@ __global__ __launch_bounds__(256) void colnorm_partial_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(r0 + ty + 8 * i) * n_p + col);
-    ss += v * v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ss[q] = __builtin_fmaf(v[q], v[q], ss[q]);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) red[ty][4 * tx + q] = ss[q];
@@ -619,53 +622,68 @@ struct OptCast {
   bf16_t* dst[2];
 };
 
+// One torch single-tensor Adam / RAdam update of four elements (the op order of torch/optim/{adam,radam}.py, one rounding per
+// torch op: no fused multiply-adds across them) -- the ONE definition the three optimizer kernels share, so that they agree
+// to the bit.
+__device__ __forceinline__ void adam_update4(const f32x4 g, f32x4& pv, f32x4& mv, f32x4& vv, const OptArgs& a, const float coef) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma clang fp contract(off)
+    float gj = (g[j] * a.grad_scale) * coef;
+    if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
+    mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
+    vv[j] = vv[j] * a.beta2;
+    vv[j] = vv[j] + (a.one_minus_beta2 * gj) * gj;
+    if (a.is_radam) {
+      const float mh = mv[j] / a.bc1;
+      if (a.rectify) {
+        const float adaptive = (1.0f / (sqrtf(vv[j]) + a.eps)) * a.bc2_sqrt;
+        pv[j] = pv[j] - ((mh * a.lr) * adaptive) * a.rect;
+      } else {
+        pv[j] = pv[j] - mh * a.lr;
+      }
+    } else {
+      const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+      pv[j] = pv[j] + (-a.step_size * mv[j]) / denom;
+    }
+  }
+}
+
+// sqrt(sum of the gradient-norm partials) -> clip coefficient; block (0, 0) also publishes the norm and, after a data-parallel
+// sum, turns the loss scalars into means over ranks (the host clears scale_metrics after the first optimizer step that
+// follows a forward_backward: a second call must not rescale; TopK's dead_pct rides in the same summed buffer)
+__device__ __forceinline__ float clip_coef_and_metrics(const double* __restrict__ gn_part, int n_part, const OptArgs& a,
+                                                       float* __restrict__ metrics, double* redd, bool first_block) {
+  double s = 0;
+  for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float total = sqrtf((float)(redd[0] + redd[1] + redd[2] + redd[3]));
+  if (first_block && threadIdx.x == 0) {
+    metrics[3] = total;
+    if (a.scale_metrics && a.grad_scale != 1.0f) {
+      metrics[0] *= a.grad_scale;
+      metrics[1] *= a.grad_scale;
+      metrics[2] *= a.grad_scale;
+      metrics[5] *= a.grad_scale;
+    }
+  }
+  return fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
+}
+
 __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, const float* __restrict__ grad,
                                                          int64_t n4, const double* __restrict__ gn_part, int n_part,
                                                          OptArgs a, float* __restrict__ metrics, OptCast cast) {
   __shared__ double red[4];
-  double s = 0;
-  for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
-  s = wave_sum_d(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const float total = sqrtf((float)(red[0] + red[1] + red[2] + red[3]));
-  const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    metrics[3] = total;
-    if (a.scale_metrics && a.grad_scale != 1.0f) {   // after a data-parallel sum the loss scalars become means over ranks
-      metrics[0] *= a.grad_scale;                      // (the host clears scale_metrics after the first optimizer step
-      metrics[1] *= a.grad_scale;                      // that follows a forward_backward: a second call must not rescale)
-      metrics[2] *= a.grad_scale;
-      metrics[5] *= a.grad_scale;                      // TopK dead_pct rides in the same summed buffer
-    }
-  }
+  const float coef = clip_coef_and_metrics(gn_part, n_part, a, metrics, red, blockIdx.x == 0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 g = reinterpret_cast<const f32x4*>(grad)[i];
+    const f32x4 g = reinterpret_cast<const f32x4*>(grad)[i];
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma clang fp contract(off)      // one rounding per torch op: no fused multiply-adds across them (and the same bits as optimizer_l1_kernel)
-      float gj = (g[j] * a.grad_scale) * coef;
-      if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
-      mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
-      vv[j] = vv[j] * a.beta2;
-      vv[j] = vv[j] + (a.one_minus_beta2 * gj) * gj;
-      if (a.is_radam) {
-        const float mh = mv[j] / a.bc1;
-        if (a.rectify) {
-          const float adaptive = (1.0f / (sqrtf(vv[j]) + a.eps)) * a.bc2_sqrt;
-          pv[j] = pv[j] - ((mh * a.lr) * adaptive) * a.rect;
-        } else {
-          pv[j] = pv[j] - mh * a.lr;
-        }
-      } else {
-        const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
-        pv[j] = pv[j] + (-a.step_size * mv[j]) / denom;
-      }
-    }
+    adam_update4(g, pv, mv, vv, a, coef);
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -686,46 +704,11 @@ __global__ __launch_bounds__(256) void optimizer_l1_kernel(float* __restrict__ p
                                                             float* __restrict__ metrics, float* __restrict__ cn_part) {
   __shared__ double redd[4];
   __shared__ float red[8][128];
-  double s = 0;
-  for (int i = threadIdx.x; i < n_part; i += 256) s += gn_part[i];
-  s = wave_sum_d(s);
-  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const float total = sqrtf((float)(redd[0] + redd[1] + redd[2] + redd[3]));
-  const float coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    metrics[3] = total;
-    if (a.scale_metrics && a.grad_scale != 1.0f) {
-      metrics[0] *= a.grad_scale;
-      metrics[1] *= a.grad_scale;
-      metrics[2] *= a.grad_scale;
-      metrics[5] *= a.grad_scale;
-    }
-  }
+  const float coef = clip_coef_and_metrics(gn_part, n_part, a, metrics, redd, blockIdx.x == 0 && blockIdx.y == 0);
   auto update4 = [&](int64_t o) -> f32x4 {
     const f32x4 g = *reinterpret_cast<const f32x4*>(grad + o);
     f32x4 pv = *reinterpret_cast<f32x4*>(p + o), mv = *reinterpret_cast<f32x4*>(m + o), vv = *reinterpret_cast<f32x4*>(v + o);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {       // (the op order of optimizer_kernel, i.e. of torch's single-tensor Adam / RAdam)
-#pragma clang fp contract(off)
-      float gj = (g[j] * a.grad_scale) * coef;
-      if (a.is_radam && a.weight_decay != 0.f) gj = gj + a.weight_decay * pv[j];
-      mv[j] = mv[j] + a.one_minus_beta1 * (gj - mv[j]);
-      vv[j] = vv[j] * a.beta2;
-      vv[j] = vv[j] + (a.one_minus_beta2 * gj) * gj;
-      if (a.is_radam) {
-        const float mh = mv[j] / a.bc1;
-        if (a.rectify) {
-          const float adaptive = (1.0f / (sqrtf(vv[j]) + a.eps)) * a.bc2_sqrt;
-          pv[j] = pv[j] - ((mh * a.lr) * adaptive) * a.rect;
-        } else {
-          pv[j] = pv[j] - mh * a.lr;
-        }
-      } else {
-        const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
-        pv[j] = pv[j] + (-a.step_size * mv[j]) / denom;
-      }
-    }
+    adam_update4(g, pv, mv, vv, a, coef);
     *reinterpret_cast<f32x4*>(p + o) = pv;
     *reinterpret_cast<f32x4*>(m + o) = mv;
     *reinterpret_cast<f32x4*>(v + o) = vv;
@@ -741,12 +724,175 @@ __global__ __launch_bounds__(256) void optimizer_l1_kernel(float* __restrict__ p
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f32x4 pv = update4((int64_t)(r0 + ty + 8 * i) * n_p + col);
-    ss += pv * pv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ss[q] = __builtin_fmaf(pv[q], pv[q], ss[q]);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) red[ty][4 * tx + q] = ss[q];
   __syncthreads();
   if (t < 128) cn_part[(int64_t)blockIdx.y * n_p + blockIdx.x * 128 + t] = colnorm_tree8(red, t);
+}
+
+// The L1 update for d_p <= 384 with the NEXT forward's weight preparation folded in: a workgroup owns OPTC_COLS columns and ALL d_p
+// rows of W, so after the update it holds whole columns -- it forms their norms (the canonical partial sums above, summed
+// over the slabs in order: the very value colnorm_partial + normalize_cast would produce), and writes the bf16 copies of the
+// NORMALISED weights (Wb [d_p][n_p], Wt [n_p][d_p]) that the next forward / backward read.  The fp32 master keeps the
+// un-normalised update -- what the reference holds after optimizer.step() (train_sae.py:450) until its next forward
+// normalises in place (l1autoencoder.py:71-73) -- and the denominators go to cnorm[n_p]: the NEXT update divides by them
+// while loading (norm_on_load), observers of the master normalise it in place first (normalize_inplace_kernel).  A training
+// step then needs neither colnorm_partial nor normalize_cast: 5 kernels -> 4.
+//   grid n_p / OPTC_COLS + n_p / 128 (the extra blocks update the bias, flat).  OPTC_COLS = 16 columns and 512 threads per
+//   workgroup: a thread updates d_p / 128 <= 3 rows of four columns and has all their loads in flight at once (with 256 threads
+//   and 12 dependent load-update-store rounds per thread the kernel took 25 us), and C2's 3072 columns make 192 workgroups
+//   (32 columns: 96 workgroups, each CU then moves 400 KB through its own 64 B/clk path: 14.5 us).
+//   dynamic LDS (d_p x OPTC_COLS + d_p / 32 x 8 x OPTC_COLS + OPTC_COLS) x 4 B
+constexpr int OPTC_COLS = 16, OPTC_THREADS = 512, OPTC_MAX_PASS = 3;
+constexpr int OPTC_TPR = OPTC_COLS / 4;                       // threads per row in the update mapping
+constexpr int OPTC_ROWS = OPTC_THREADS / OPTC_TPR;            // rows per pass
+static_assert(OPTC_ROWS == 128, "rows ty + 128 i: d_p is a multiple of 128");
+__host__ __device__ constexpr int optc_lds_bytes(int d_p) { return (d_p * OPTC_COLS + (d_p / 32) * 8 * OPTC_COLS + OPTC_COLS) * 4; }
+
+__global__ __launch_bounds__(OPTC_THREADS) void optimizer_l1_cols_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                                          const float* __restrict__ grad, int d_p, int n_p,
+                                                                          const double* __restrict__ gn_part, int n_part, OptArgs a,
+                                                                          float* __restrict__ metrics, float* __restrict__ cnorm,
+                                                                          int norm_on_load, bf16_t* __restrict__ Wb, bf16_t* __restrict__ Wt) {
+  extern __shared__ __attribute__((aligned(16))) float optc_smem[];
+  __shared__ double redd[OPTC_THREADS / 64];
+  const int t = threadIdx.x, nslab = d_p / 32, npass = d_p / 128;
+  const int ncb = n_p / OPTC_COLS;
+  const bool bias_block = (int)blockIdx.x >= ncb;
+  float* pn = optc_smem;                              // [d_p][OPTC_COLS] updated weights of this workgroup's columns
+  float* red = pn + d_p * OPTC_COLS;                  // [nslab][8][OPTC_COLS]
+  float* den = red + nslab * 8 * OPTC_COLS;           // [OPTC_COLS]
+  const int col0 = blockIdx.x * OPTC_COLS;
+  const int tx = t % OPTC_TPR, ty = t / OPTC_TPR;      // update / Wb mapping: columns 4 tx .. 4 tx + 3, rows ty + 128 i
+  // the loads of the update first: they do not depend on the clip coefficient
+  f32x4 dn = {1.f, 1.f, 1.f, 1.f};
+  f32x4 g[OPTC_MAX_PASS], pv[OPTC_MAX_PASS], mv[OPTC_MAX_PASS], vv[OPTC_MAX_PASS];
+  if (!bias_block) {
+    if (norm_on_load) dn = *reinterpret_cast<const f32x4*>(cnorm + col0 + 4 * tx);
+#pragma unroll
+    for (int i = 0; i < OPTC_MAX_PASS; ++i)
+      if (i < npass) {
+        const int64_t o = (int64_t)(128 * i + ty) * n_p + col0 + 4 * tx;
+        g[i] = *reinterpret_cast<const f32x4*>(grad + o);
+        pv[i] = *reinterpret_cast<f32x4*>(p + o);
+        mv[i] = *reinterpret_cast<f32x4*>(m + o);
+        vv[i] = *reinterpret_cast<f32x4*>(v + o);
+      }
+  }
+  // clip coefficient (every workgroup sums the gradient-norm partials in the same order)
+  float coef;
+  {
+    double sg = 0;
+    for (int i = t; i < n_part; i += OPTC_THREADS) sg += gn_part[i];
+    sg = wave_sum_d(sg);
+    if ((t & 63) == 0) redd[t >> 6] = sg;
+    __syncthreads();
+    double tot = 0;
+#pragma unroll
+    for (int w = 0; w < OPTC_THREADS / 64; ++w) tot += redd[w];
+    const float total = sqrtf((float)tot);
+    if (blockIdx.x == 0 && t == 0) {
+      metrics[3] = total;
+      if (a.scale_metrics && a.grad_scale != 1.0f) {
+        metrics[0] *= a.grad_scale;
+        metrics[1] *= a.grad_scale;
+        metrics[2] *= a.grad_scale;
+        metrics[5] *= a.grad_scale;
+      }
+    }
+    coef = fminf(a.clip_thresh / (total + 1e-6f), 1.0f);
+  }
+  if (bias_block) {                       // the bias: 128 elements per block, threads 0..31
+    if (t < 32) {
+      const int64_t o = (int64_t)d_p * n_p + ((int)blockIdx.x - ncb) * 128 + 4 * t;
+      const f32x4 gb = *reinterpret_cast<const f32x4*>(grad + o);
+      f32x4 pb = *reinterpret_cast<f32x4*>(p + o), mb = *reinterpret_cast<f32x4*>(m + o), vb = *reinterpret_cast<f32x4*>(v + o);
+      adam_update4(gb, pb, mb, vb, a, coef);
+      *reinterpret_cast<f32x4*>(p + o) = pb;
+      *reinterpret_cast<f32x4*>(m + o) = mb;
+      *reinterpret_cast<f32x4*>(v + o) = vb;
+    }
+    return;
+  }
+  // ---- update
+#pragma unroll
+  for (int i = 0; i < OPTC_MAX_PASS; ++i)
+    if (i < npass) {
+      const int row = 128 * i + ty;
+      const int64_t o = (int64_t)row * n_p + col0 + 4 * tx;
+      if (norm_on_load) {                 // the in-place normalisation the last forward stands for (W / max(||col||, 1e-12))
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[i][q] = pv[i][q] / dn[q];
+      }
+      adam_update4(g[i], pv[i], mv[i], vv[i], a, coef);
+      *reinterpret_cast<f32x4*>(p + o) = pv[i];
+      *reinterpret_cast<f32x4*>(m + o) = mv[i];
+      *reinterpret_cast<f32x4*>(v + o) = vv[i];
+      *reinterpret_cast<f32x4*>(pn + row * OPTC_COLS + 4 * tx) = pv[i];
+    }
+  __syncthreads();
+  // ---- column norms, canonical order: a (slab, y8) pair -> rows y8, y8 + 8, y8 + 16, y8 + 24 of the slab, for column cc
+  {
+    const int cc = t % OPTC_COLS;
+    for (int pr = t / OPTC_COLS; pr < nslab * 8; pr += OPTC_THREADS / OPTC_COLS) {
+      const int i = pr >> 3, y8 = pr & 7;
+      float ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = pn[(32 * i + y8 + 8 * k) * OPTC_COLS + cc];
+        ss = __builtin_fmaf(w, w, ss);
+      }
+      red[pr * OPTC_COLS + cc] = ss;
+    }
+  }
+  __syncthreads();
+  if (t < OPTC_COLS) {
+    float tot = 0.f;
+    for (int i = 0; i < nslab; ++i) {
+      const float* r = red + i * 8 * OPTC_COLS + t;
+      tot += ((r[0] + r[OPTC_COLS]) + (r[2 * OPTC_COLS] + r[3 * OPTC_COLS])) + ((r[4 * OPTC_COLS] + r[5 * OPTC_COLS]) + (r[6 * OPTC_COLS] + r[7 * OPTC_COLS]));
+    }
+    const float dnm = fmaxf(sqrtf(tot), 1e-12f);
+    den[t] = dnm;
+    cnorm[col0 + t] = dnm;
+  }
+  __syncthreads();
+  // ---- bf16 copies of the normalised weights: Wb row-major (8 B per thread and row), Wt transposed (16-B pieces of a column)
+  {
+    const f32x4 dn = *reinterpret_cast<const f32x4*>(den + 4 * tx);
+#pragma unroll
+    for (int i = 0; i < OPTC_MAX_PASS; ++i)
+      if (i < npass) {
+        const int row = 128 * i + ty;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(pn + row * OPTC_COLS + 4 * tx);
+        *reinterpret_cast<bf16x4*>(Wb + (int64_t)row * n_p + col0 + 4 * tx) =
+            bf16x4{(bf16_t)(w[0] / dn[0]), (bf16_t)(w[1] / dn[1]), (bf16_t)(w[2] / dn[2]), (bf16_t)(w[3] / dn[3])};
+      }
+    const int cc = t % OPTC_COLS;                     // column cc, pieces t / OPTC_COLS + k OPTC_THREADS / OPTC_COLS (8 rows = 16 B each)
+    const float dc = den[cc];
+    for (int pc = t / OPTC_COLS; pc < d_p / 8; pc += OPTC_THREADS / OPTC_COLS) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(pn[(8 * pc + e) * OPTC_COLS + cc] / dc);
+      *reinterpret_cast<bf16x8*>(Wt + (int64_t)(col0 + cc) * d_p + 8 * pc) = o;
+    }
+  }
+}
+
+// W[r][c] /= cnorm[c]: the in-place normalisation a forward stands for, carried out for an observer of the fp32 master
+// (sae_get_params, a second forward without an update in between, sae_decode) -- the same division normalize_cast performs.
+__global__ __launch_bounds__(256) void normalize_inplace_kernel(float* __restrict__ W, const float* __restrict__ cnorm, int64_t n4, int n_p) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)((4 * i) % n_p);
+    f32x4 w = reinterpret_cast<f32x4*>(W)[i];
+    const f32x4 dn = *reinterpret_cast<const f32x4*>(cnorm + col);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = w[q] / dn[q];
+    reinterpret_cast<f32x4*>(W)[i] = w;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

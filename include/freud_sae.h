@@ -69,7 +69,9 @@ typedef struct sae_config {
                           /* paths that stay correct: 75 = no tile-driven TopK select, 76 = AuxK through the gather   */
                           /* kernels instead of the compacted dead-set GEMMs (tests compare both), 78 = the loss         */
                           /* finalisation as its own kernel between the fused forward and backward (round 2's order),   */
-                          /* 79 = the flat optimizer kernel + a separate column-norm pass for L1 (round 2's order)       */
+                          /* 79 = the flat optimizer kernel + a separate column-norm pass for L1 (round 2's order),      */
+                          /* 80 = L1 with d <= 384: the tiled update + normalize_cast in the next forward instead of the */
+                          /* update that also writes the next forward's weight copies (tests compare both to the bit)   */
   int32_t force_gemm128;  /* 1: 128x128 GEMM tiles even where the 256x256 kernel applies (A/B timing, tests)        */
   int32_t topk_dense_backward; /* TopK backward A/B (tests): 0 CSC sparse backward, 1 dense GEMMs + mask, 2 sparse d      */
                           /* pre-activations + dense weight-gradient GEMMs                                            */

@@ -289,7 +289,8 @@ def test_full_size_properties():
 def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
     """Round 3 changed HOW the fused d = 384 step is launched, not what it computes: the second forward decomposition
     (fwd_fused2.h; FREUD_FWD=1 selects the first), the loss finalisation folded into reduce_grads (debug_flags 78 = own kernel),
-    the optimizer that leaves the column-norm partials (debug_flags 79 = flat optimizer + separate pass).  Same arithmetic in
+    the optimizer that leaves the column-norm partials (debug_flags 79 = flat optimizer + separate pass) and then the one that
+    also writes the next forward's weight copies (debug_flags 80 = round-3-first-half order).  Same arithmetic in
     the same order: weights and optimizer moments after three steps must be BITWISE equal across all of them (the logged loss
     scalars agree to fp32 round-off: their partial sums are taken in another order)."""
     from freud_amd.engine import SaeEngine
@@ -302,7 +303,7 @@ def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
     x.view(-1)[::501] = -1.0
     xd = x.cuda()
     results = []
-    for fwd, dbg in (("2", 0), ("1", 0), ("2", 78), ("2", 79)):
+    for fwd, dbg in (("2", 0), ("1", 0), ("2", 78), ("2", 79), ("2", 80)):
         monkeypatch.setenv("FREUD_FWD", fwd)
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4, debug_flags=dbg)
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
@@ -312,7 +313,7 @@ def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
         results.append((eng.get_params(), m1, v1, eng.metrics().copy()))
         eng.close()
     ref = results[0]
-    names = ["fwd1", "dbg78", "dbg79"]
+    names = ["fwd1", "dbg78", "dbg79", "dbg80"]
     for name, other in zip(names, results[1:]):
         for k in ref[0]:
             dw = np.abs(ref[0][k] - other[0][k]).max()
@@ -320,3 +321,57 @@ def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
             assert np.array_equal(ref[1][k], other[1][k]) and np.array_equal(ref[2][k], other[2][k]), (name, k, "moments")
         # (the loss SCALARS are sums over per-workgroup partials taken in another order: equal to fp32 round-off, not bitwise)
         np.testing.assert_allclose(other[3], ref[3], rtol=2e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("d,n", [(384, 1024), (64, 256)])
+def test_folded_weight_preparation_keeps_the_reference_state_at_every_observation(d, n):
+    """L1 with d <= 384: the update also writes the next forward's bf16 weight copies and leaves the fp32 master un-normalised
+    (the reference's state after optimizer.step(), train_sae.py:450); the in-place normalisation of the next forward
+    (l1autoencoder.py:71-73) happens lazily.  Whatever is observed in between -- parameters right after a step, after an eval
+    forward, a second eval, decode, a resumed run -- must be BITWISE what the plain order (debug_flags 80: update, then column
+    norms + normalize_cast in the next forward) produces."""
+    from freud_amd.engine import SaeEngine
+    M = 512
+    g = torch.Generator().manual_seed(11)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    b = 0.01 * torch.randn(n, generator=g)
+    x = ((torch.relu(torch.randn(M, 16, generator=g)) * 0.1) @ torch.randn(16, d, generator=g)).to(torch.bfloat16).cuda()
+    lat = torch.relu(torch.randn(8, n, generator=g)).cuda()
+
+    def run(dbg):
+        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e4, debug_flags=dbg)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        seen = []
+        eng.step(x, 1e-3)
+        seen.append(eng.get_params()["decoder.weight"].copy())          # after an update: un-normalised
+        eng.step(x, 1e-3)
+        eng.step(x, 1e-3)
+        eng.eval(x)
+        seen.append(np.array(eng.metrics()[:2]))
+        seen.append(eng.get_params()["decoder.weight"].copy())          # after update + one forward: normalised once
+        eng.eval(x)                                                      # the reference normalises again
+        eng.step(x, 1e-3)
+        eng.eval(x)
+        eng.eval(x)
+        eng.step(x, 1e-3)
+        xh = torch.empty(8, d, device="cuda", dtype=torch.float32)
+        eng.decode(lat, xh)                                              # decode() reads the master as is
+        torch.cuda.synchronize()
+        seen.append(xh.cpu().numpy())
+        eng.step(x, 1e-3)
+        p = eng.get_params()
+        _, m1, v1 = eng.get_opt_state()
+        seen += [p["decoder.weight"], p["encoder_bias"], m1["decoder.weight"], v1["decoder.weight"]]
+        eng.close()
+        return seen
+
+    new, old = run(0), run(80)
+    for i, (a, o) in enumerate(zip(new, old)):
+        if i == 1:
+            np.testing.assert_allclose(a, o, rtol=2e-6)                  # loss scalars: partial sums in another order
+        else:
+            assert np.array_equal(a, o), (i, np.abs(a - o).max())
+    # and the column norms: un-normalised right after an update, 1 after update + forward
+    assert np.abs(np.linalg.norm(new[0], axis=0) - 1).max() > 1e-6
+    assert np.abs(np.linalg.norm(new[2], axis=0) - 1).max() < 1e-5
