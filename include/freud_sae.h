@@ -114,7 +114,11 @@ void sae_destroy(sae_ctx* ctx);
 
 /* Parameters, reference layouts (see top).  `is_device` selects host or device pointers.
  * For L1 pass (W, b, NULL, NULL); for TopK pass (We, be, Wd, bd).  Synchronising.
- * Replaces model.load_state_dict / model.state_dict (train_sae.py:232-251, 265-294). */
+ * Replaces model.load_state_dict / model.state_dict (train_sae.py:232-251, 265-294).
+ * sae_get_params returns what the reference's state_dict holds at the same point of the same call sequence: for L1 the
+ * decoder weight is UN-normalised right after an update (train_sae.py:450) and normalised once a forward has run
+ * (l1autoencoder.py:71-73 normalises in place on every forward) -- the engine may postpone that in-place division
+ * internally, never its visible effect. */
 int sae_set_params(sae_ctx* ctx, const float* p0, const float* p1, const float* p2, const float* p3, int is_device);
 int sae_get_params(sae_ctx* ctx, float* p0, float* p1, float* p2, float* p3, int is_device);
 
