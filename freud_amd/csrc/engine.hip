@@ -158,6 +158,10 @@ struct sae_ctx {
   const bf16_t* xb_cur = nullptr;   // bf16 GEMM copy of the current batch (== the caller's x when no copy is needed)
   unsigned int* masked = nullptr;
   int dw_splits = 1;
+  // plain (single-launch) weight-gradient GEMM of the generic L1 path: whole tiles written straight into the gradient, the tiles
+  // left over after whole rounds in K pieces through dw_tail (gemm_tail_plan); 0 = uniform split-K through the slabs
+  int dw_tail_tiles = 0, dw_tail_pieces = 0;
+  float* dw_tail = nullptr;
   int bwd_splits = 1;       // row ranges of the fused backward
   int bwd_range_splits = 1; // ... when it is launched in column-tile ranges (bwd_ranges > 1)
   bool use_fused_bwd = false;
@@ -464,7 +468,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part, c->dxh8,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
-                  c->aux_dbe_part, c->be_r, c->cnorm};
+                  c->aux_dbe_part, c->be_r, c->cnorm, c->dw_tail};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
@@ -547,6 +551,11 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   // with a gradient-ready hook the weight-gradient GEMM is issued in 512-row chunks (d_p >= 1024 only: smaller
   // models finish their gradient in one piece); the chunk's split-K factor keeps its launch rounds full
   c->dw_chunk_rows = c->d_p >= 1024 ? 512 : c->d_p;
+  if (!g_force_gemm128 && c->d_p % 256 == 0 && c->n_p % 256 == 0 && (c->d_p / 256) * (c->n_p / 256) >= 256 && !getenv("FREUD_DW_SPLITS") &&
+      c->cfg.debug_flags != 81) {
+    gemm_tail_plan((c->d_p / 256) * (c->n_p / 256), (int)(2 * Mp / 64), c->dw_tail_tiles, c->dw_tail_pieces);
+    if ((c->d_p / 256) * (c->n_p / 256) % 256 == 0) c->dw_tail_tiles = c->dw_tail_pieces = -1;     // whole rounds: one split, no tail
+  }
   c->dw_chunk_splits = choose_splits(c->dw_chunk_rows / 128, c->n_p / 128, 2 * Mp / 64);
   if (c->d_p >= 1024 && c->n_p % 256 == 0)
     for (int q = 4; q >= 2; --q)
@@ -603,6 +612,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->gn_part, 1024 * 8);
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
   ALLOC(c->cnorm, (int64_t)c->n_p * 4);
+  if (c->dw_tail_tiles > 0) ALLOC(c->dw_tail, (int64_t)c->dw_tail_tiles * c->dw_tail_pieces * 65536 * 4);
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
   c->stats_cap = DP_STATS_HEAD;
@@ -1210,11 +1220,13 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
     GemmArgs g2 = g;
     g2.nbm = g.nbm / 2;
     g2.nbn = g.nbn / 2;
-    const int grid_max = (g.dyn && g.grid_cover > 0) ? g.grid_cover : g2.nbm * g2.nbn * g2.splits;
+    const int grid_max = (g.dyn && g.grid_cover > 0) ? g.grid_cover
+                         : g2.tail_tiles > 0    ? g2.nbm * g2.nbn + g2.tail_tiles * (g2.tail_pieces - 1)
+                                                : g2.nbm * g2.nbn * g2.splits;
     const int grid_est = (((g.grid_hint + 3) / 4 + 7) / 8) * 8;          // 256x256 tiles, a multiple of 8
     // (the caller sets grid_hint only for a SMALL estimated extent: the persistent instantiation's tile loop costs the K loop
     // ~10 %, while the workgroups that start only to exit are cheap until they are the great majority)
-    if (G2_PERSIST_STATIC > 0 && !g.dyn && g2.splits == 1 && grid_max >= 4 * G2_PERSIST_STATIC) {
+    if (G2_PERSIST_STATIC > 0 && !g.dyn && g2.splits == 1 && g2.tail_tiles == 0 && grid_max >= 4 * G2_PERSIST_STATIC) {
       // big static launches (the K = d GEMMs: tens of thousands of tiles) as G2_PERSIST_STATIC resident workgroups that walk
       // the tiles: encoder / dpre -2 %, TopK encoder -2.5 % against one workgroup per tile (same box; 256 / 512 / 1024 measure alike)
       auto kernp = gemm256_bf16_kernel<AM, BM_, Epi, true>;
@@ -1519,6 +1531,10 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       const bool chunked = !col_chunked && (c->grad_ready != nullptr || (c->dist && c->dp_world > 0)) && c->dw_chunk_rows < d_p;
       const int chunk_rows = chunked ? c->dw_chunk_rows : d_p;
       if (chunked) splits = c->dw_chunk_splits;
+      // one launch, no exchange to feed: whole tiles go straight into the gradient buffer (no slabs, no reduction pass), the
+      // tiles left over after whole rounds of 256 workgroups in K pieces through the small overflow buffer
+      const bool direct = !col_chunked && !chunked && c->dw_tail_tiles != 0 && (int64_t)c->dw_tail_tiles * c->dw_tail_pieces <= 256 &&
+                          2 * Mp / 64 >= 16 * (c->dw_tail_pieces > 0 ? c->dw_tail_pieces : 1);
       if (!col_chunked) ev_begin(c, KID_DW, s);
       for (int r0 = 0; r0 < d_p && !col_chunked; r0 += chunk_rows) {
         const int rows = d_p - r0 < chunk_rows ? d_p - r0 : chunk_rows;
@@ -1529,8 +1545,17 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         g.splits = splits;
         EpiSlab e{};
         e.slab = c->slab + (int64_t)r0 * n_p; e.slab_stride = c->nW; e.ld = n_p;
+        if (direct) {
+          g.splits = 1;
+          g.tail_tiles = c->dw_tail_tiles > 0 ? c->dw_tail_tiles : 0;
+          g.tail_pieces = c->dw_tail_tiles > 0 ? c->dw_tail_pieces : 0;
+          e.slab = c->G; e.slab_stride = 0; e.tail = c->dw_tail;
+        }
         rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
         if (rc) return rc;
+        if (direct && g.tail_tiles > 0)
+          hipLaunchKernelGGL(reduce_tail_kernel, dim3(g.tail_tiles, 16), dim3(256), 0, s, c->dw_tail, c->G, n_p, d_p / 256, n_p / 256,
+                             g.tail_tiles, g.tail_pieces);
         if (chunked) {
           const int64_t off4 = (int64_t)r0 * n_p / 4, n4 = (int64_t)rows * n_p / 4;
           hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, c->slab + 4 * off4,
@@ -1540,7 +1565,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       if (!col_chunked) {
         ev_end(c, KID_DW, s);
-        dw_chunked = dw_chunked_any = chunked;
+        dw_chunked_any = chunked;
+        dw_chunked = chunked || direct;     // (direct: the gradient is already in place -- no slab reduction; nothing was announced)
       }
     }
     ev_begin(c, KID_REDUCE, s);

@@ -45,7 +45,22 @@ struct GemmArgs {
                          // tile count times `splits`)
   int grid_hint;         // dyn launches of the 256x256 kernel: an ESTIMATE of the 128x128 tiles of the dynamic extent (0 = none).
                          // Well below the static maximum it selects the PERSIST instantiation with a grid of that size.
+  // 256x256 kernel, static launches with splits == 1 (gemm_tail_plan): the LAST tail_tiles output tiles -- what is left of the
+  // tile count after whole rounds of one workgroup per CU -- are computed in tail_pieces K ranges each, so that the last
+  // round costs 1 / tail_pieces of a tile's time instead of a whole one.  The functor sees slab id 0 for the other tiles and
+  // 1 + piece * tail_tiles + (index of the tail tile) for the pieces; grid = nbm * nbn - tail_tiles + tail_tiles * tail_pieces.
+  int tail_tiles, tail_pieces;
 };
+
+// The plan for `tiles` 256x256 output tiles of `ktiles` K tiles on 256 CUs: tail tiles and pieces (0, 0: the tile count fills
+// whole rounds, or a piece would be shorter than 16 K tiles).
+__host__ __device__ __forceinline__ void gemm_tail_plan(int tiles, int ktiles, int& tail_tiles, int& tail_pieces) {
+  tail_tiles = tiles % 256;
+  tail_pieces = tail_tiles > 0 ? 256 / tail_tiles : 0;
+  if (tail_pieces > 16) tail_pieces = 16;
+  while (tail_pieces > 1 && ktiles / tail_pieces < 16) --tail_pieces;
+  if (tail_pieces < 2) tail_tiles = tail_pieces = 0;
+}
 enum { GEMM_DYN_NONE = 0, GEMM_DYN_M = 1, GEMM_DYN_N = 2, GEMM_DYN_K = 3 };
 
 // split-K factor for `tiles` output tiles (256 CUs, one workgroup each at a time): the factor in [1, smax] with at least 8 K

@@ -187,13 +187,32 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
                                              int ktiles, int splits) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   const int nblk = nbm * nbn * splits;
-  int id = xcd_remap(blk, nblk);
-  const int split = id / (nbm * nbn);
-  id -= split * (nbm * nbn);
+  int id, split, kt_begin, kt_end;
+  if (!PERSIST && g.tail_tiles > 0) {
+    // (splits == 1) whole tiles first, then the pieces of the tail tiles: piece-major, so that the workgroups of a round walk
+    // the same K range of the shared operand
+    const int main_tiles = nbm * nbn - g.tail_tiles;
+    if (blk < main_tiles) {
+      id = xcd_remap(blk, main_tiles);
+      split = 0;
+      kt_begin = 0;
+      kt_end = ktiles;
+    } else {
+      const int j = blk - main_tiles, piece = j / g.tail_tiles, tt = j - piece * g.tail_tiles;
+      id = main_tiles + tt;
+      split = 1 + piece * g.tail_tiles + tt;
+      kt_begin = (int)((int64_t)ktiles * piece / g.tail_pieces);
+      kt_end = (int)((int64_t)ktiles * (piece + 1) / g.tail_pieces);
+    }
+  } else {
+    id = xcd_remap(blk, nblk);
+    split = id / (nbm * nbn);
+    id -= split * (nbm * nbn);
+    kt_begin = (int)((int64_t)ktiles * split / splits);
+    kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
+  }
   int bm, bn;
   tile_coords(id, nbm, nbn, bm, bn);
-  const int kt_begin = (int)((int64_t)ktiles * split / splits);
-  const int kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
 
 #ifdef G2X_PHASE
   // experiment: half of the FIRST round's workgroups start late by G2X_PHASE x 8128 cycles, so that the CUs' epilogue bursts
@@ -457,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs g, Epi ep
   if constexpr (PERSIST) {
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) gemm256_tile<AMODE, BMODE, true>(g, epi, smem, blk, nbm, nbn, ktiles0, ktiles, splits);
   } else {
-    if ((int)blockIdx.x < nblk) gemm256_tile<AMODE, BMODE, false>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles, splits);
+    const int nlaunch = g.tail_tiles > 0 ? nbm * nbn + g.tail_tiles * (g.tail_pieces - 1) : nblk;
+    if ((int)blockIdx.x < nlaunch) gemm256_tile<AMODE, BMODE, false>(g, epi, smem, blockIdx.x, nbm, nbn, ktiles0, ktiles, splits);
   }
 }

@@ -304,13 +304,43 @@ struct EpiSlab {
   float* slab;          // [splits][rows][ld]
   int64_t slab_stride;  // rows*ld
   int ld;
+  // tail-split launches (GemmArgs::tail_tiles): slab id 0 is the output itself (`slab`, no reduction pass for whole tiles),
+  // id 1 + q the q-th piece tile of the compact overflow buffer tail[q][256][256]
+  float* tail;
   float* base;
-  __device__ void tile_begin(int, int, int split) { base = slab + slab_stride * split; }
+  int ld_cur;
+  __device__ void tile_begin(int row0, int col0, int split) {
+    if (tail != nullptr && split > 0) {
+      ld_cur = 256;
+      base = tail + (int64_t)(split - 1) * 65536 - ((int64_t)(row0 & ~255) * 256 + (col0 & ~255));
+    } else {
+      ld_cur = ld;
+      base = slab + slab_stride * split;
+    }
+  }
   struct Pre {};
   __device__ Pre prefetch(int, int) const { return Pre{}; }
-  __device__ void apply(int row, int col, f32x4 v, const Pre&) { *reinterpret_cast<f32x4*>(base + (int64_t)row * ld + col) = v; }
+  __device__ void apply(int row, int col, f32x4 v, const Pre&) { *reinterpret_cast<f32x4*>(base + (int64_t)row * ld_cur + col) = v; }
   __device__ void tile_end(float*) {}
 };
+
+// out[tail tile] = sum over its K pieces (fixed order) of the overflow buffer tail[piece * tail_tiles + t][256][256]; the tail
+// tiles are the last ones of the GEMM's tile walk (tile_coords).  grid (tail_tiles, 16), 256 threads: 16 rows of a tile each.
+__global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restrict__ tail, float* __restrict__ out, int ld, int nbm,
+                                                           int nbn, int tail_tiles, int tail_pieces) {
+  const int tt = blockIdx.x, id = nbm * nbn - tail_tiles + tt;
+  int bm, bn;
+  tile_coords(id, nbm, nbn, bm, bn);
+  const int t = threadIdx.x, c4 = (t & 63) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = blockIdx.y * 16 + (t >> 6) + 4 * i;
+    const float* src = tail + (int64_t)tt * 65536 + r * 256 + c4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int pc = 1; pc < tail_pieces; ++pc) a += *reinterpret_cast<const f32x4*>(src + (int64_t)pc * tail_tiles * 65536);
+    *reinterpret_cast<f32x4*>(out + (int64_t)(bm * 256 + r) * ld + bn * 256 + c4) = a;
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // gradient reduction, loss finalisation, clip + optimizer

@@ -71,7 +71,9 @@ typedef struct sae_config {
                           /* finalisation as its own kernel between the fused forward and backward (round 2's order),   */
                           /* 79 = the flat optimizer kernel + a separate column-norm pass for L1 (round 2's order),      */
                           /* 80 = L1 with d <= 384: the tiled update + normalize_cast in the next forward instead of the */
-                          /* update that also writes the next forward's weight copies (tests compare both to the bit)   */
+                          /* update that also writes the next forward's weight copies (tests compare both to the bit),  */
+                          /* 81 = uniform split-K through slabs for the plain weight-gradient GEMM of the generic L1     */
+                          /* path (instead of whole tiles straight into the gradient + the tail tiles in K pieces)       */
   int32_t force_gemm128;  /* 1: 128x128 GEMM tiles even where the 256x256 kernel applies (A/B timing, tests)        */
   int32_t topk_dense_backward; /* TopK backward A/B (tests): 0 CSC sparse backward, 1 dense GEMMs + mask, 2 sparse d      */
                           /* pre-activations + dense weight-gradient GEMMs                                            */
