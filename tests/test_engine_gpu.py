@@ -182,6 +182,32 @@ def test_gemm256_matches_gemm128():
     assert np.allclose(m256[:3], m128[:3], rtol=1e-5)
 
 
+@pytest.mark.parametrize("n", [13312, 16384])
+def test_weight_gradient_tail_split_matches_uniform_split_k(n):
+    """Generic L1 path, >= 256 output tiles of the weight gradient: whole tiles are written straight into the gradient buffer
+    and the tiles left over after whole rounds of 256 workgroups are computed in K pieces (n = 13 312: 260 tiles, 4 tail tiles
+    x 4 pieces; n = 16 384: 320 tiles, 64 tail tiles x 4 pieces).  debug_flags 81 = the uniform split-K through slabs: the
+    same sums in another association."""
+    d, M = 1280, 2048
+    g = torch.Generator().manual_seed(9)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    b = 0.01 * torch.randn(n, generator=g)
+    x = (torch.relu(torch.randn(M, 64, generator=g)) * 0.1 @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
+    res = []
+    for dbg in (0, 81):
+        eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e4, debug_flags=dbg)
+        eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        eng.forward_backward(x)
+        res.append(eng.debug_read(2, d * n + n))
+        eng.step(x, 1e-3)
+        res.append(eng.get_params()["decoder.weight"])
+        eng.close()
+    assert np.abs(res[0]).max() > 0
+    assert _rel(res[0], res[2]) < 1e-5                      # raw gradient
+    assert _rel(res[1], res[3]) < 1e-6                      # weights after a step
+
+
 @pytest.mark.parametrize("variant,d,n,M", [("l1", 384, 3072, 1024), ("l1", 1024, 2048, 512), ("topk", 256, 1024, 512)])
 def test_grad_ready_callback_ranges(variant, d, n, M):
     """sae_set_grad_ready_callback: the announced ranges are disjoint and cover the gradient buffer; the chunked
