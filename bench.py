@@ -259,9 +259,10 @@ def main():
         for i in range(args.warmup):
             one_step(i)
         torch.cuda.synchronize()
-        # the dominant kernel is bracketed with HIP events on a SAMPLE of the timed steps (an event pair costs ~6 us of idle GPU
-        # between dependent kernels): every 8th step of a long run, every 2nd of a short one (the driver's 20-step run: 10 samples)
-        eng.profile(1, period=8 if args.steps > 64 else 2)
+        # the dominant kernel is bracketed with HIP events: on every 8th step of a long run (an event pair costs a few us of idle
+        # GPU between dependent kernels), on EVERY step of a short one (the driver's 20-step run: 20 samples; three interleaved
+        # 20-step pairs on one box: 593.3 / 593.9 us sampled every step against 594.0 / 594.2 every second -- no measurable price)
+        eng.profile(1, period=8 if args.steps > 64 else 1)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -46,4 +46,4 @@ def test_default_bench_line_follows_the_contract():
 def test_driver_style_line_has_enough_kernel_samples():
     d = _line("r03_bench_default_driver_style.json")
     assert d["steps"] == 20 and d["warmup"] == 5
-    assert d["roofline"]["kernel_launches"] >= 10        # every 2nd step of a short run is bracketed
+    assert d["roofline"]["kernel_launches"] >= 10        # every step of a short run is bracketed
