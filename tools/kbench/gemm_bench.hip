@@ -13,6 +13,9 @@
 #include "../../freud_amd/csrc/l1_kernels.h"
 
 struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias / ReLU)
+#ifdef KB_BF16EPI
+  static constexpr bool ROUNDS_BF16_FIRST = true;      // the product's one-step bf16 epilogue (the default here is the fp32 two-pass one)
+#endif
 #ifdef KB_A3
   static constexpr bool DEEP_A_RING = true;      // three-deep A ring (the decoder's form)
 #endif
@@ -84,7 +87,7 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(KB_PERSIST), dim3(512), G2_LDS_BYTES, 0, g, e);
 #else
       auto kern = gemm256_bf16_kernel<OP_ROW, OP_ROW, EpiBf16>;
-      constexpr int lds = epi_deep_a_ring<EpiBf16>::value ? G2_A3_LDS_BYTES : G2_LDS_BYTES;
+      constexpr int lds = epi_deep_a_ring<EpiBf16>::value ? G2_A3_LDS_BYTES : (epi_rounds_first<EpiBf16>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES) ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), lds, 0, g, e);
 #endif
