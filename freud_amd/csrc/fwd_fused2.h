@@ -115,18 +115,36 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     return __builtin_bit_cast(bf16x8, v);
   };
   // staging image: byte offset of chunk (tile half hf, k-step s, this lane's h) in row `arow` of a 32-row block
+  // Chunk swizzle f(row) = (row & 7) ^ ((row >> 1) & 1) ^ ((row >> 4) & 1).  Round 3 used (row & 7): fine for the 16-byte writes
+  // (8 consecutive rows per LDS cycle), but a ds_read_b128 is served in groups of 16 lanes -- rows {0-3, 12-15, 20-27} and
+  // {4-11, 16-19, 28-31} -- where (row & 7) takes every value twice on rows of equal parity (the row pitch is half the banks):
+  // a 2-way conflict on every c^T fragment read, and the 8-byte drain reads (4 rows per 32 lanes) hit rows r and r + 2 on the
+  // same chunks.  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE read 0.18.  With f, the 16 rows of either group give 16
+  // distinct (row parity, chunk) pairs, 8 consecutive rows still give 8 distinct chunks, and rows r, r + 2 of a drain piece read
+  // chunks of different parity.  -DFF2_SWZ_V1 restores the old image for A/B runs.
+#ifdef FF2_SWZ_V1
+  auto swz = [](int row) { return row & 7; };
+#else
+  auto swz = [](int row) { return (row & 7) ^ ((row >> 1) & 1) ^ ((row >> 4) & 1); };
+#endif
   int boff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) boff[i] = arow * 128 + (((4 * (i >> 1) + 2 * (i & 1) + ah) ^ (arow & 7)) << 4);
+  for (int i = 0; i < 4; ++i) boff[i] = arow * 128 + (((4 * (i >> 1) + 2 * (i & 1) + ah) ^ swz(arow)) << 4);
   const int wrow = w * 4096;                                     // this wave's row block inside a pair buffer
   // drain: piece p = rows 8 p .. 8 p + 7 of the row block; lane -> row 8 p + lane / 8, 16 output bytes = columns 8 o .. 8 o + 7
   const int drow_l = lane >> 3, dch = lane & 7;
   int doff0, doff1;
   {
     const int tl = dch >> 2, s = (dch & 3) >> 1, u = dch & 1;
-    doff0 = drow_l * 128 + (((4 * tl + 2 * s + 0) ^ drow_l) << 4) + 8 * u;
-    doff1 = drow_l * 128 + (((4 * tl + 2 * s + 1) ^ drow_l) << 4) + 8 * u;
+    doff0 = drow_l * 128 + (((4 * tl + 2 * s + 0) ^ swz(drow_l)) << 4) + 8 * u;
+    doff1 = drow_l * 128 + (((4 * tl + 2 * s + 1) ^ swz(drow_l)) << 4) + 8 * u;
   }
+  // pieces 2 and 3 hold rows 16..31 of the row block: bit 4 of the row flips the chunk's low bit = bit 4 of the byte offset
+#ifdef FF2_SWZ_V1
+  auto dpiece = [](int off, int) { return off; };
+#else
+  auto dpiece = [](int off, int p) { return (p & 2) ? (off ^ 16) : off; };
+#endif
   bf16_t* cdrain = a.c + (m0 + drow_l) * a.n_p + dch * 8;
 
   float l1_acc = 0.f;
@@ -254,8 +272,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       // two full-line pieces of the finished pair per iteration: LDS reads in one gap, global store 8 gaps later
       if (i == 29 || i == 33) {
         const int p = 2 * (PH & 1) + (i == 33);
-        const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff0);
-        const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff1);
+        const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + dpiece(doff0, p));
+        const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + dpiece(doff1, p));
         dr[i == 33] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
       if (i == 37 || i == 42) {
@@ -309,8 +327,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     const char* cst_r = cst + (((a.ntiles >> 1) - 1) & 1) * 16384 + wrow;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff0);
-      const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + doff1);
+      const uint2 lo = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + dpiece(doff0, p));
+      const uint2 hi = *reinterpret_cast<const uint2*>(cst_r + p * 1024 + dpiece(doff1, p));
       __builtin_nontemporal_store(u32x4{lo.x, lo.y, hi.x, hi.y},
                                   reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)));
     }

@@ -494,9 +494,69 @@ struct StatsPush {
   int rank, world;
   unsigned long long epoch;
   unsigned long long timeout_ticks; // of s_memrealtime (100 MHz)
-  unsigned int* status;             // bit 0 set when a peer's triple did not arrive in time
+  unsigned int* status;             // sticky failure word of the peer exchange (p2p_exchange.h: P2P_ST_*)
+  unsigned int* status_host;        // its host-mapped mirror (may be null)
   double* gstats_out;               // [2]: global unmasked count, global rows
 };
+
+// The push itself: lane r (< world) of the calling wave writes (v0, v1, epoch) into rank r's inbox and waits for rank r's
+// triple in its own.  The inbox is uncached device memory and every access a system-scope atomic: no cache holds these words.
+// Order: the two payload words, a system-scope release fence + s_waitcnt vmcnt(0) (inline asm -- the compiler may drop the
+// wait, MI355X_MICROARCH.md "Compiler hazard"), then the epoch word.  Failure handling as in p2p_barrier (p2p_exchange.h): a
+// context whose status word is set pushes PUSH_POISON instead of its epoch and does not wait; a poll that times out or reads
+// a poisoned epoch sets the status word and poisons both parities of its slots in every peer's inbox.
+constexpr unsigned long long PUSH_POISON = 1ull << 63;
+__device__ __forceinline__ void stats_push_exchange(const StatsPush& push, double v0, double v1, double (*peer)[2]) {
+  if ((int)threadIdx.x < push.world) {
+    const int r = threadIdx.x;
+    const bool failed = __hip_atomic_load(push.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const int slot = (int)(push.epoch & 1) * 32;
+    unsigned long long* dst = push.inbox[r] + slot + push.rank * 4;
+    __hip_atomic_store(dst + 0, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(dst + 2, failed ? (push.epoch | PUSH_POISON) : push.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    peer[r][0] = v0;                // (placeholders of a failed exchange: finite numbers, the run is reported invalid anyway)
+    peer[r][1] = v1;
+    if (!failed) {
+      const unsigned long long* src = push.inbox[push.rank] + slot + r * 4;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long v;
+      unsigned int code = 0;
+      while ((v = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < push.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > push.timeout_ticks) {
+          code = 1u;                // P2P_ST_TIMEOUT
+          break;
+        }
+      }
+      if (!code && (v & PUSH_POISON)) code = 2u;      // P2P_ST_POISONED
+      if (code) {
+        atomicOr(push.status, code);
+        if (push.status_host) __hip_atomic_store(push.status_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(push.inbox[r] + push.rank * 4 + 2, push.epoch | PUSH_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(push.inbox[r] + 32 + push.rank * 4 + 2, push.epoch | PUSH_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        peer[r][0] = __longlong_as_double((long long)__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        peer[r][1] = __longlong_as_double((long long)__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      }
+    }
+  }
+}
+
+// self-test of the push (sae_p2p_init): rank r pushes (pattern, 2 pattern + 1); every rank checks all the triples it received
+__global__ void p2p_selftest_push_kernel(StatsPush push, int e, unsigned int* bad) {
+  __shared__ double peer[8][2];
+  auto val = [](int r, int e) { return (double)(1000 * (r + 1) + 37 * e); };
+  stats_push_exchange(push, val(push.rank, e), 2.0 * val(push.rank, e) + 1.0, peer);
+  __syncthreads();
+  if ((int)threadIdx.x < push.world) {
+    const int r = threadIdx.x;
+    if (peer[r][0] != val(r, e) || peer[r][1] != 2.0 * val(r, e) + 1.0) atomicAdd(bad, 1u);
+  }
+}
 
 __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_part, int n_l1, const float* sq_part,
                                                                 int n_sq, float* scal, float* metrics, int64_t M,
@@ -517,25 +577,7 @@ __global__ __launch_bounds__(1024) void finalize_losses_kernel(const float* l1_p
     for (int k = 0; k < 16; ++k) tot += redc[k];
     const double local = (double)M * d - tot;
     if (push.world > 0) {
-      if ((int)threadIdx.x < push.world) {
-        const int r = threadIdx.x;
-        const int slot = (int)(push.epoch & 1) * 32;
-        unsigned long long* dst = push.inbox[r] + slot + push.rank * 4;
-        __hip_atomic_store(dst + 0, (unsigned long long)__double_as_longlong(local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong((double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dst + 2, push.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long* src = push.inbox[push.rank] + slot + r * 4;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(src + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != push.epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > push.timeout_ticks) {
-            atomicOr(push.status, 1u);
-            break;
-          }
-        }
-        peer_stats[r][0] = __longlong_as_double((long long)__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-        peer_stats[r][1] = __longlong_as_double((long long)__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      }
+      stats_push_exchange(push, local, (double)M, peer_stats);
       __syncthreads();
       if (threadIdx.x == 0) {
         double gc = 0, gr = 0;

@@ -18,9 +18,24 @@
 //   barrier 2  nobody overwrites its buffer (next step's reduce_grads) while a peer still reads it.
 // (A world of one rank -- the single-GPU test hook -- has nothing to fetch and nobody to wait for after phase 1.)
 // Flags live in device memory allocated uncached (hipDeviceMallocUncached) on every rank; a rank writes its arrival into the
-// PEERS' flag blocks with a system-scope release store and polls its OWN block with system-scope acquire loads.  Flag values
-// are the call's epoch (monotonic, 64 bit): no resets, no ABA.  A poll that outlasts `timeout_ticks` of the 100 MHz
-// s_memrealtime clock sets the status word and gives up instead of hanging the GPU (a dead peer must not take the node down).
+// PEERS' flag blocks and polls its OWN block.  Flag values are the call's epoch (monotonic, 64 bit): no resets, no ABA.
+//
+// Visibility ("memory model"; tests/test_p2p_codeobj.py asserts these instructions in the built code
+// object).  G / Gb / stats are ordinary (coarse-grained) device memory: local lines live in this XCD's L2 (write-back), a
+// PEER's lines mapped through hipIpc are cached non-coherently (MTYPE NC) in the reader's L2.  Every barrier therefore is
+//   every storing wave: s_waitcnt vmcnt(0) -> workgroup barrier -> (the signalling lanes) system-scope RELEASE fence =
+//   `buffer_wbl2 sc0 sc1` (dirty L2 lines, i.e. the phase's sums, reach memory) + `s_waitcnt vmcnt(0)` (inline asm: hipcc drops
+//   the wait when it can prove its scoreboard empty, MI355X_MICROARCH.md "Compiler hazard") -> relaxed system-scope flag stores
+//   into the peers' blocks -> relaxed system-scope polls of the own block (uncached memory: every poll reaches memory) ->
+//   system-scope ACQUIRE fence = `buffer_inv sc0 sc1` (this CU's L1 and the NC lines of this XCD's L2 are dropped: the peers'
+//   lines read in an earlier step are re-fetched) + `s_waitcnt vmcnt(0)` (the invalidate completes asynchronously) ->
+//   workgroup barrier -> the phase's plain loads.
+//
+// Failure: a poll that outlasts `timeout_ticks` of the 100 MHz s_memrealtime clock gives up instead of hanging the GPU (a dead
+// peer must not take the node down), sets the status word AND poisons the protocol: the flags it owes the peers for this call
+// and for every later one carry P2P_POISON, a poller that reads a poisoned flag fails too (and poisons in turn), a failed
+// workgroup skips both phases (its buffer stays as it was), and the status word is sticky -- every later exchange of a failed
+// context starts failed.  So no rank can sail through on flags a peer published before it gave up.
 //
 // Payloads: P2P_F32 in place on fp32; P2P_F64 in place on doubles (statistics); P2P_BF16 reads the peers' bf16 COPY of the
 // segment (written by reduce_grads), sums in fp32, rounds ONCE, publishes the rounded sum through its own bf16 copy and writes
@@ -54,26 +69,62 @@ struct P2PArgs {
   int nseg, rank, world, channel;
   unsigned long long epoch;
   unsigned long long timeout_ticks;          // of s_memrealtime (100 MHz)
-  unsigned int* status;                      // device word: bit 0 = a barrier timed out
+  unsigned int* status;                      // device word, sticky: P2P_ST_TIMEOUT | P2P_ST_POISONED (| P2P_ST_SELFTEST by the self-test)
+  unsigned int* status_host;                 // the same word in host-mapped memory (may be null): the step loop polls it for free
   double* gn_part;                           // optional: per-workgroup sum of squares of the REDUCED values (clip norm)
+  int fault;                                 // test hook (FREUD_P2P_FAULT): 1 = skip the phase-2 copy of shard (rank + 1) % world
 };
 
-__device__ __forceinline__ void p2p_barrier(const P2PArgs& a, int slot) {
-  __syncthreads();                           // the workgroup's loads / stores of the phase are complete (vmcnt(0) + barrier)
-  if ((int)threadIdx.x < a.world) {
-    const int64_t base = (((int64_t)a.channel * 3 + slot) * P2P_MAX_BLOCKS + blockIdx.x) * P2P_MAX_WORLD;
-    __hip_atomic_store(a.sig[threadIdx.x] + base + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long* mine = a.sig[a.rank] + base + threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.epoch) {
-      __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-        atomicOr(a.status, 1u);
-        break;
+constexpr unsigned long long P2P_POISON = 1ull << 63;      // a flag value with this bit: the writer has left the protocol
+enum { P2P_ST_TIMEOUT = 1u, P2P_ST_POISONED = 2u, P2P_ST_SELFTEST = 4u };
+
+__device__ __forceinline__ void p2p_mark_failed(unsigned int* status, unsigned int* status_host, unsigned int code) {
+  atomicOr(status, code);
+  if (status_host) __hip_atomic_store(status_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One barrier of the exchange (see the header comment for the instruction sequence and why).  `fail_s`: the workgroup's
+// failure word in LDS (set at kernel start from the sticky status word).  Returns false when the protocol has failed.
+__device__ __forceinline__ bool p2p_barrier(const P2PArgs& a, int slot, volatile int* fail_s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its stores of the phase have left the wave
+  __syncthreads();
+  if ((int)threadIdx.x < a.world) {                      // (all in wave 0: world <= 8)
+    const bool failed = *fail_s != 0;
+    const int64_t blk = (int64_t)blockIdx.x * P2P_MAX_WORLD;
+    const int64_t base = ((int64_t)a.channel * 3 + slot) * P2P_MAX_BLOCKS * P2P_MAX_WORLD + blk;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: buffer_wbl2 sc0 sc1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... completed BEFORE the flag leaves
+    __hip_atomic_store(a.sig[threadIdx.x] + base + a.rank, failed ? (a.epoch | P2P_POISON) : a.epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!failed) {
+      const unsigned long long* mine = a.sig[a.rank] + base + threadIdx.x;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long v;
+      unsigned int code = 0;
+      while ((v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < a.epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+          code = P2P_ST_TIMEOUT;
+          break;
+        }
+      }
+      if (!code && (v & P2P_POISON)) code = P2P_ST_POISONED;
+      if (code) {
+        // leave the protocol for good and tell everybody: the flags this workgroup owes peer `threadIdx.x` for this call
+        // (all three barriers -- the peer may wait at any of them) carry the poison; later calls start failed (sticky status)
+        *fail_s = 1;
+        p2p_mark_failed(a.status, a.status_host, code);
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+          __hip_atomic_store(a.sig[threadIdx.x] + ((int64_t)a.channel * 3 + sl) * P2P_MAX_BLOCKS * P2P_MAX_WORLD + blk + a.rank,
+                             a.epoch | P2P_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // system scope: buffer_inv sc0 sc1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before the workgroup is released
   }
   __syncthreads();
+  return *fail_s == 0;
 }
 
 __device__ __forceinline__ double p2p_sq(const f32x4& o) {
@@ -106,10 +157,12 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
     return g.off + (int64_t)row * g.pitch + (int64_t)(v - row * vpr) * EPV;
   };
 
-  p2p_barrier(a, 0);
+  __shared__ int fail_s;
+  if (threadIdx.x == 0) fail_s = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky
+  bool ok = p2p_barrier(a, 0, &fail_s);     // (its first workgroup barrier publishes fail_s)
 
   // ---- phase 1: the owner's sum of slice (rank, b) over every rank's copy, in rank order
-  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+  for (int sgi = 0; ok && sgi < a.nseg; ++sgi) {
     const P2PSeg g = a.seg[sgi];
     unsigned v0, v1;
     slice_of(g, a.rank, v0, v1);
@@ -142,12 +195,13 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
   }
 
   if (a.world > 1) {
-    p2p_barrier(a, 1);
+    ok = p2p_barrier(a, 1, &fail_s);
 
     // ---- phase 2: fetch every other shard's slice b from its owner
 #pragma unroll
     for (int q = 0; q < P2P_MAX_WORLD; ++q) {
-      if (q >= a.world || q == a.rank) continue;
+      if (!ok || q >= a.world || q == a.rank) continue;
+      if (a.fault == 1 && q == (a.rank + 1) % a.world) continue;      // injected fault: this shard keeps the local partials
       for (int sgi = 0; sgi < a.nseg; ++sgi) {
         const P2PSeg g = a.seg[sgi];
         unsigned v0, v1;
@@ -173,7 +227,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
       }
     }
 
-    p2p_barrier(a, 2);
+    p2p_barrier(a, 2, &fail_s);
   }
 
   if (EPV == 4 && a.gn_part) {
@@ -244,19 +298,40 @@ __global__ __launch_bounds__(256) void reduce_slabs_range_kernel(const float* __
   }
 }
 
-// Self-test pattern of sae_p2p_init: element i of rank r = pattern(r, i); after the exchange every element must be the sum
-// over the ranks.  Small integers: exact in fp32 and in bf16 (|value| < 256).
-__global__ void p2p_selftest_fill_kernel(float* buf, bf16_t* bbuf, int64_t n, int rank) {
+// Self-test of sae_p2p_init (engine.hip: p2p_selftest).  Element i of rank r in exchange number e of payload kind k holds
+// pattern(i, r, e, k); after the exchange every element of the exchanged segment must be the sum over the ranks and every
+// element outside it must still hold this rank's own pattern.  The pattern CHANGES WITH e while the addresses do not: a peer
+// line that stayed in a cache from exchange e - 1 gives a wrong sum in exchange e (round 3 filled the same values twice, so a
+// stale line held the right value).  Small integers: exact in fp32, bf16 and fp64 (|value| <= 14, sums < 256).
+__device__ __forceinline__ int p2p_pattern(int64_t i, int rank, int e, int kind) {
+  return (int)((i * 7 + rank * 3 + e * 5 + kind * 11) % 29) - 14;
+}
+__global__ void p2p_selftest_fill_kernel(float* buf, bf16_t* bbuf, int64_t n, int rank, int e, int kind) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float v = (float)((i * 7 + rank * 3) % 29 - 14);
+    const float v = (float)p2p_pattern(i, rank, e, kind);
     buf[i] = v;
     if (bbuf) bbuf[i] = (bf16_t)v;
   }
 }
-__global__ void p2p_selftest_check_kernel(const float* buf, int64_t n, int world, unsigned int* bad) {
+__global__ void p2p_selftest_fill64_kernel(double* buf, int64_t n, int rank, int e, int kind) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    buf[i] = (double)p2p_pattern(i, rank, e, kind);
+}
+// seg: the exchanged block (rows x cols, pitch, off) of the buffer of n elements
+__global__ void p2p_selftest_check_kernel(const float* buf, int64_t n, P2PSeg seg, int rank, int world, int e, int kind, unsigned int* bad) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rel = i - seg.off;
+    const bool inside = rel >= 0 && rel / seg.pitch < seg.rows && rel % seg.pitch < seg.cols;
     float want = 0.f;
-    for (int r = 0; r < world; ++r) want += (float)((i * 7 + r * 3) % 29 - 14);
+    if (inside) for (int r = 0; r < world; ++r) want += (float)p2p_pattern(i, r, e, kind);
+    else want = (float)p2p_pattern(i, rank, e, kind);
+    if (buf[i] != want) atomicAdd(bad, 1u);
+  }
+}
+__global__ void p2p_selftest_check64_kernel(const double* buf, int64_t n, int world, int e, int kind, unsigned int* bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double want = 0;
+    for (int r = 0; r < world; ++r) want += (double)p2p_pattern(i, r, e, kind);
     if (buf[i] != want) atomicAdd(bad, 1u);
   }
 }
