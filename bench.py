@@ -221,6 +221,8 @@ def main():
         if use_dist:
             from freud_amd import dp
             mode = mode_override or ("host" if args.dp_host else (args.dp or dp.requested_mode()))
+            if mode_override == "rccl" and dist.get_backend() != "nccl":
+                mode = "host"
             dp_mode = dp.setup(eng, dist, rank, world, torch.device("cuda", local_rank), mode=mode, payload=args.dp_payload,
                                overlap=args.dp_overlap)
             args.dp_host = dp_mode == "host"
@@ -256,6 +258,24 @@ def main():
                     elapsed = float(te.item())
                 if elapsed >= args.spinup:
                     break
+        # Peer exchange with real peers: the first warm-up steps are AUDITED -- this rank's gradient contribution is snapshotted
+        # before the exchange, the snapshots are summed by torch.distributed (RCCL) and compared with what the engine's own
+        # exchange produced (freud_amd/dp.py: Auditor).  The verdict is collective; a mismatch sends every rank to in-engine RCCL.
+        audit_info = None
+        if dp_mode == "p2p" and world > 1 and os.environ.get("FREUD_DP_AUDIT", "1") != "0":
+            from freud_amd import dp
+            aud = dp.Auditor(eng, dist, rank, world, payload=args.dp_payload)
+            n_audit, worst = min(3, max(args.warmup, 1)), 0.0
+            try:
+                for i in range(n_audit):
+                    aud.arm()
+                    one_step(i)
+                    worst = max(worst, aud.verify(i + 1))
+                dp.check_replicas(eng, dist, rank, world, n_audit)
+                audit_info = {"audited_steps": n_audit, "max_rel_diff_vs_torch_distributed": worst, "replica_checksums": "identical"}
+            except dp.ExchangeError as e:
+                print(f"[rank {rank}] {e}", file=sys.stderr)
+                return eng, None, 0.0, dp_mode, False, {"failed": str(e)[:300]}
         for i in range(args.warmup):
             one_step(i)
         torch.cuda.synchronize()
@@ -288,19 +308,34 @@ def main():
             flag = torch.tensor([1 if healthy else 0], device="cuda", dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same decision
             healthy = int(flag.item()) == 1
-        return eng, one_step, dt, dp_mode, healthy
+            if healthy and world > 1:                        # replicas are bit-identical by construction: anything else is an exchange bug
+                from freud_amd import dp
+                try:
+                    dp.check_replicas(eng, dist, rank, world, args.warmup + args.steps)
+                    if audit_info is not None:
+                        audit_info["replica_checksums_after_run"] = "identical"
+                except dp.ExchangeError as e:
+                    print(f"[rank {rank}] {e}", file=sys.stderr)
+                    healthy = False
+                    audit_info = {"failed": str(e)[:300]}
+        return eng, one_step, dt, dp_mode, healthy, audit_info
 
     args.dp_host_flag = args.dp_host
-    eng, one_step, dt, dp_mode, healthy = attempt()
+    eng, one_step, dt, dp_mode, healthy, audit_info = attempt()
+    dp_fallback = None
     if not healthy:
-        # the peers could not be reached in the middle of the run (the exchange kernels time out instead of hanging): the
-        # measurement is repeated from scratch with the host-driven protocol, on a fresh context, and says so in config.dp
-        eng.close()
-        eng, one_step, dt, dp_mode, healthy = attempt("host")
-        dp_mode = "host"
-        dp_fallback = True
-    else:
-        dp_fallback = False
+        # the in-engine exchange failed (peers not reached in the middle of the run -- the exchange kernels time out instead of
+        # hanging --, an audit mismatch, diverged replicas): the measurement is repeated from scratch on a fresh context with the
+        # next carrier (peer exchange -> in-engine RCCL -> host-driven), and config.dp says so
+        first_failure = audit_info
+        for nxt in (["rccl", "host"] if dp_mode == "p2p" else ["host"]):
+            eng.close()
+            eng, one_step, dt, dp_mode, healthy, audit_info = attempt(nxt)
+            if healthy:
+                break
+        dp_fallback = first_failure or {"failed": "exchange failed during the first attempt"}
+        if not healthy:
+            raise SystemExit("bench.py: no data-parallel exchange completed the run")
     times = eng.kernel_times()
     metrics = eng.metrics()
     eng.profile(0)
@@ -320,6 +355,8 @@ def main():
     if args.variant == "topk":
         step_flops = (2.0 * d * n + 10.0 * args.k * d) * M   # 2 d n + 10 k d per activation
     fb_ms, fb_cnt = times["fwd_bwd_total"]
+    f8 = {"bf16": 0.0, "fp8": 0.4, "fp8bwd": 0.6}[args.precision] if args.variant == "l1" else 0.0
+    step_peak = 1.0 / (f8 / PEAK_FP8_TFLOPS + (1.0 - f8) / PEAK_BF16_TFLOPS)
 
     breakdown = None
     if args.breakdown or args.precision != "bf16":        # every rank runs the extra steps (they contain collectives); rank 0 reports
@@ -356,10 +393,10 @@ def main():
                       + (f", backward in {args.dp_overlap} column ranges" if fused and args.dp_overlap > 1 else ""),
                "rccl": f"in-engine RCCL, {eff_payload} gradients"}[dp_mode]
     if dp_fallback:
-        dp_desc += " (fallback: the in-engine exchange failed during a first attempt)"
+        dp_desc += " (fallback: the first choice failed: " + str(dp_fallback.get("failed", ""))[:160] + ")"
     model_name = {384: "tiny", 512: "base", 768: "small", 1024: "medium", 1280: "large"}.get(d, f"d={d}")
     out = {
-        "metric": "SAE train activations/sec (d=384 dict 8x)", "value": value, "unit": "activations/s",
+        "metric": f"SAE train activations/sec (d={d} dict {n // d}x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_s": args.spinup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
@@ -367,13 +404,16 @@ def main():
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM"
                                + (" (BASELINE configs[1])" if (d, n, M) == (384, 3072, 65536) else ""),
                    "rows_per_gpu": M, "d_model": d, "n_dict": n, "parallelism": f"dp{world}",
-                   "dp": dp_desc},
+                   "dp": dp_desc, "dp_guards": audit_info},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom,
                      "kernel_avg_ms": dom_avg_ms, "kernel_launches": dom_cnt,
                      "flops_per_launch": dom_flops, "peak_measured_bare_mfma_loop": MEASURED_MFMA_LOOP_TFLOPS,
                      "frac_of_measured": achieved / MEASURED_MFMA_LOOP_TFLOPS},
-        "step_mfma_frac": (step_flops * world / (ms_per_step * 1e-3) / 1e12) / (PEAK_BF16_TFLOPS * world),
+        # whole step against the MFMA roof; with fp8 GEMMs in the step the roof is FLOP-weighted (time at peak = fp8 FLOPs / fp8
+        # peak + bf16 FLOPs / bf16 peak): 4 of the 10 M d n FLOPs run on e4m3 with --precision fp8, 6 with fp8bwd
+        "step_mfma_frac": (step_flops / (ms_per_step * 1e-3) / 1e12) / step_peak,
+        "step_mfma_peak": step_peak,
         "fwd_bwd_ms": fb_ms / max(fb_cnt, 1),
         "loss": {"recon": float(metrics[0]), "l1": float(metrics[1]), "grad_norm": float(metrics[3])},
     }

@@ -82,3 +82,21 @@ __global__ __launch_bounds__(256) void dp_topk_tv_kernel(const double* __restric
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+
+// Order-independent 64-bit checksum of an fp32 buffer's BITS (sae_param_checksum): sum over i of mix(bits[i] ^ i * K1) -- integer
+// adds commute, so the atomics give the same word whatever the order.  Replicas of a data-parallel run hold bit-identical
+// parameters and optimizer moments by construction; train() compares these words across the ranks.
+__global__ __launch_bounds__(256) void checksum_kernel(const float* __restrict__ p, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    unsigned long long v = (unsigned long long)__float_as_uint(p[i]) ^ ((unsigned long long)i * 0x9E3779B97F4A7C15ull);
+    v ^= v >> 29;
+    v *= 0xD6E8FEB86659FD93ull;
+    v ^= v >> 32;
+    h += v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+

@@ -234,10 +234,19 @@ struct sae_ctx {
   void* p2p_opened[4 * P2P_MAX_WORLD] = {};      // peer mappings to close
   int p2p_nopened = 0;
   unsigned long long* sig = nullptr;             // this rank's flag block (uncached device memory)
-  unsigned int* p2p_status = nullptr;            // device word the exchange kernels set on a barrier timeout
+  unsigned int* p2p_status = nullptr;            // device words: [0] sticky failure bits the exchange kernels set (P2P_ST_*), [1] self-test mismatches
+  unsigned int* p2p_status_host = nullptr;       // host-mapped mirror of word 0 (hipHostMalloc): sae_dist_poll reads it without a sync
+  unsigned int* p2p_status_hostdev = nullptr;    // its device address
+  int p2p_fault_kind = 0, p2p_fault_rank = -1;   // FREUD_P2P_FAULT=skip_phase2:<rank>[:<after exchanges>] (tests: the guards must catch it)
+  unsigned long long p2p_fault_after = 0;
+  float* col_stage = nullptr;                    // in-engine RCCL, d >= 1024: contiguous staging of the dW column chunks ([d_p x n_p] floats)
+  float* audit_dst = nullptr;                    // sae_dist_audit: every gradient exchange first copies its segments here
+  bool finegrained = false;                      // FREUD_P2P_FINEGRAINED=1: G / Gb / stats in fine-grained device memory
   unsigned long long p2p_epoch[P2P_CHANNELS] = {};
   unsigned long long p2p_epoch_push = 0;         // epoch of the statistics push inside finalize_losses_kernel
-  unsigned long long p2p_timeout_ticks = 1000000000ull;    // 10 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS)
+  // 120 s of the 100 MHz clock (FREUD_P2P_TIMEOUT_MS): a LIVENESS bound, not a skew budget -- a rank may be late by a loader
+  // stall, a validation pass or a checkpoint write; a failed context fails fast afterwards (sticky status, poisoned flags)
+  unsigned long long p2p_timeout_ticks = 12000000000ull;
   bool gn_from_exchange = false;                 // gn_part holds the sum of squares of the EXCHANGED gradient
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
@@ -335,6 +344,12 @@ static int fused_bwd_splits(int ntiles, int steps, int cols) {
   return best;
 }
 
+// allocation of a buffer the peers of a data-parallel run map (G, Gb, stats)
+static hipError_t peer_visible_malloc(const sae_ctx* c, void** p, size_t bytes) {
+  if (c->finegrained) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+  return hipMalloc(p, bytes);
+}
+
 static int create_events(sae_ctx* c) {
   for (auto& r : c->ev)
     for (int i = 0; i < EV_RING; ++i) r.beg[i] = r.end[i] = nullptr;
@@ -365,7 +380,10 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->P, c->nparams * 4);
   TALLOC(c->Mom, c->nparams * 4);
   TALLOC(c->Var, c->nparams * 4);
-  TALLOC(c->G, (c->nparams + ntail) * 4);
+  {
+    hipError_t e_ = peer_visible_malloc(c, (void**)&c->G, (size_t)(c->nparams + ntail) * 4);
+    if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "allocation of the gradient buffer failed: %s", hipGetErrorString(e_));
+  }
   TALLOC(c->We_b, c->nW * 2);
   TALLOC(c->Wd_b, c->nW * 2);
   TALLOC(c->xs, Mp * c->d_p * 2);
@@ -396,7 +414,10 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->nfsf, (size_t)c->n_p * 8);
   TALLOC(c->dbe_fx, (size_t)c->n_p * 8);
   c->stats_cap = DP_STATS_HEAD + 2 * (int64_t)c->cfg.max_rows * c->d;     // column sums / sums of squares: at most one file
-  TALLOC(c->stats, c->stats_cap * 8);
+  {
+    hipError_t e_ = peer_visible_malloc(c, (void**)&c->stats, (size_t)c->stats_cap * 8);
+    if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "allocation of the statistics buffer failed: %s", hipGetErrorString(e_));
+  }
   // topk_dense_backward keeps the dense ddense GEMM (tests cover both)
   c->topk_sparse_da = (c->d_p == 384 || c->d_p == 768 || c->d_p == 1280) && c->cfg.topk_dense_backward != 1;
   TALLOC(c->dead, c->n_p);
@@ -475,6 +496,8 @@ extern "C" void sae_destroy(sae_ctx* c) {
   for (int i = 0; i < c->p2p_nopened; ++i) (void)hipIpcCloseMemHandle(c->p2p_opened[i]);
   if (c->sig) (void)hipFree(c->sig);
   if (c->p2p_status) (void)hipFree(c->p2p_status);
+  if (c->p2p_status_host) (void)hipHostFree(c->p2p_status_host);
+  if (c->col_stage) (void)hipFree(c->col_stage);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
@@ -532,6 +555,10 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   c->nW = (int64_t)c->d_p * c->n_p;
   c->nparams = c->nW + c->n_p;
   c->topk = cfg->variant == SAE_VARIANT_TOPK;
+  // FREUD_P2P_FINEGRAINED=1: the three buffers the peers read (G, Gb, stats) in fine-grained device memory -- never held
+  // non-coherently in a cache, so the peer exchange needs no cache maintenance to be correct.  The second in-engine option for a
+  // node where the start-up self-test of the default (coarse-grained + fences) fails; costs local bandwidth.
+  if (const char* fg = getenv("FREUD_P2P_FINEGRAINED")) c->finegrained = atoi(fg) == 1;
   const int64_t Mp = c->max_rows_p;
   if (c->topk) {
     int rc_tk = topk_create(c, Mp);
@@ -597,7 +624,17 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->P, c->nparams * 4);
   ALLOC(c->Mom, c->nparams * 4);
   ALLOC(c->Var, c->nparams * 4);
-  ALLOC(c->G, (c->nparams + SAE_NUM_METRICS) * 4);
+  if (c->finegrained) {
+    hipError_t e_ = peer_visible_malloc(c, (void**)&c->G, (size_t)(c->nparams + SAE_NUM_METRICS) * 4);
+    if (e_ == hipSuccess) e_ = peer_visible_malloc(c, (void**)&c->stats, (size_t)DP_STATS_HEAD * 8);
+    if (e_ != hipSuccess) {
+      int rc_ = fail(SAE_ERR_HIP, "fine-grained allocation of the gradient / statistics buffers failed: %s", hipGetErrorString(e_));
+      sae_destroy(c);
+      return rc_;
+    }
+  } else {
+    ALLOC(c->G, (c->nparams + SAE_NUM_METRICS) * 4);
+  }
   ALLOC(c->Wb, c->nW * 2);
   ALLOC(c->Wt, c->nW * 2);
   ALLOC(c->xb, Mp * c->d_p * 2);
@@ -616,7 +653,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
   c->stats_cap = DP_STATS_HEAD;
-  ALLOC(c->stats, c->stats_cap * 8);
+  if (!c->stats) ALLOC(c->stats, c->stats_cap * 8);
   ALLOC(c->stats_part, 1024 * 4);
   if (c->fp8) {
     ALLOC(c->x8, Mp * c->d_p);
@@ -823,7 +860,17 @@ static void p2p_launch(sae_ctx* c, int channel, const P2PSeg* segs, int nseg, in
   a.epoch = ++c->p2p_epoch[channel];
   a.timeout_ticks = c->p2p_timeout_ticks;
   a.status = c->p2p_status;
+  a.status_host = c->p2p_status_hostdev;
   a.gn_part = gn_part;
+  if (channel == 1 && c->p2p_fault_kind && c->p2p_fault_rank == c->p2p_rank && a.epoch > c->p2p_fault_after) a.fault = c->p2p_fault_kind;
+  if (channel == 1 && c->audit_dst) {        // sae_dist_audit: this rank's contribution as it stands before the exchange
+    for (int i = 0; i < nseg; ++i) {
+      const P2PSeg& g = segs[i];
+      if (hipMemcpy2DAsync(c->audit_dst + g.off, (size_t)g.pitch * 4, c->G + g.off, (size_t)g.pitch * 4, (size_t)g.cols * 4, (size_t)g.rows,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+        dist_fail(c, "exchange audit", "snapshot copy failed");
+    }
+  }
   if (channel == 0) hipLaunchKernelGGL(p2p_allreduce_kernel<2>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
   else hipLaunchKernelGGL(p2p_allreduce_kernel<4>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
   if (hipGetLastError() != hipSuccess) dist_fail(c, "peer exchange launch", "hipLaunchKernel failed");
@@ -878,6 +925,24 @@ static inline void exchange_block(sae_ctx* c, int64_t off, int rows, int cols, i
   P2PSeg g{};
   g.off = off; g.pitch = pitch; g.rows = rows; g.cols = cols; g.kind = P2P_F32; g.in_norm = 0;
   p2p_launch(c, 1, &g, 1, p2p_grid((int64_t)rows * (cols / 4)), nullptr, c->comm_stream);
+}
+
+// RCCL form of exchange_block: the block was summed into the contiguous `stage` ([rows x cols]); all-reduce it there and copy
+// the sums into their strided place of the gradient buffer, both on the communication stream
+static inline void exchange_staged(sae_ctx* c, float* stage, int64_t off, int rows, int cols, int64_t pitch, hipStream_t s) {
+  hipEvent_t ev = c->ev_range[c->ev_range_i++ & 15];
+  if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(c->comm_stream, ev, 0) != hipSuccess) {
+    dist_fail(c, "gradient block hand-over", "event record / wait failed");
+    return;
+  }
+  const ncclResult_t r = ncclAllReduce(stage, stage, (size_t)rows * cols, ncclFloat, ncclSum, c->comm, c->comm_stream);
+  if (r != ncclSuccess) {
+    dist_fail(c, "ncclAllReduce of a staged gradient block", ncclGetErrorString(r));
+    return;
+  }
+  if (hipMemcpy2DAsync(c->G + off, (size_t)pitch * 4, stage, (size_t)cols * 4, (size_t)cols * 4, (size_t)rows, hipMemcpyDeviceToDevice,
+                       c->comm_stream) != hipSuccess)
+    dist_fail(c, "staged gradient block", "copy back failed");
 }
 
 // Fused d = 384 backward, data parallel: column range [c0, c0 + cols) of dW and of db is final on stream s (`last`: with it
@@ -1049,7 +1114,7 @@ extern "C" int sae_dist_set_payload(sae_ctx* c, int dtype) {
   if (!c) return fail(SAE_ERR_INVALID, "null argument");
   if (dtype != SAE_DTYPE_F32 && dtype != SAE_DTYPE_BF16) return fail(SAE_ERR_INVALID, "payload must be SAE_DTYPE_F32 or SAE_DTYPE_BF16");
   USE_DEVICE(c);
-  if (dtype == SAE_DTYPE_BF16 && !c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
+  if (dtype == SAE_DTYPE_BF16 && !c->Gb) HIP_TRY(peer_visible_malloc(c, (void**)&c->Gb, (size_t)c->nparams * 2));
   c->payload = dtype;
   return SAE_OK;
 }
@@ -1070,7 +1135,7 @@ extern "C" int sae_p2p_export(sae_ctx* c, void* out, int64_t capacity) {
   if (capacity < (int64_t)sizeof(P2PBlob)) return fail(SAE_ERR_INVALID, "need %d bytes", (int)sizeof(P2PBlob));
   if (c->dist) return fail(SAE_ERR_STATE, "the context already runs a data-parallel protocol");
   USE_DEVICE(c);
-  if (!c->Gb) HIP_TRY(hipMalloc((void**)&c->Gb, (size_t)c->nparams * 2));
+  if (!c->Gb) HIP_TRY(peer_visible_malloc(c, (void**)&c->Gb, (size_t)c->nparams * 2));
   if (!c->sig) {
     // flags the PEERS write and this rank polls: uncached device memory, so that a poll always reaches memory
     // [barrier flags of the exchange kernels | inbox of the statistics push: 2 parities x 8 sources x 4 words]
@@ -1078,6 +1143,15 @@ extern "C" int sae_p2p_export(sae_ctx* c, void* out, int64_t capacity) {
     HIP_TRY(hipMemset(c->sig, 0, (size_t)(P2P_SIG_WORDS + 64) * 8));
     HIP_TRY(hipMalloc((void**)&c->p2p_status, 64));
     HIP_TRY(hipMemset(c->p2p_status, 0, 64));
+    // a mirror of the failure word the host can read without touching the stream (sae_dist_poll); best effort: without it
+    // the failure still shows at the next sae_dist_check
+    if (hipHostMalloc((void**)&c->p2p_status_host, 64, hipHostMallocMapped) == hipSuccess) {
+      memset(c->p2p_status_host, 0, 64);
+      if (hipHostGetDevicePointer((void**)&c->p2p_status_hostdev, c->p2p_status_host, 0) != hipSuccess) c->p2p_status_hostdev = nullptr;
+    } else {
+      c->p2p_status_host = nullptr;
+      (void)hipGetLastError();
+    }
     HIP_TRY(hipDeviceSynchronize());
   }
   P2PBlob b{};
@@ -1095,6 +1169,18 @@ extern "C" int sae_p2p_export(sae_ctx* c, void* out, int64_t capacity) {
 }
 
 static int p2p_selftest(sae_ctx* c);
+static void p2p_leave(sae_ctx* c) {
+  c->p2p = false;
+  c->dist = false;
+  c->dp_world = 0;
+  c->audit_dst = nullptr;
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < c->p2p_nopened; ++i) (void)hipIpcCloseMemHandle(c->p2p_opened[i]);
+  c->p2p_nopened = 0;
+  if (c->p2p_status) (void)hipMemset(c->p2p_status, 0, 64);
+  if (c->p2p_status_host) c->p2p_status_host[0] = 0;
+  // (the flag block keeps its epochs: a later sae_p2p_init continues the counters, never reuses a value)
+}
 
 extern "C" int sae_p2p_init(sae_ctx* c, const void* blobs, int64_t bytes_per_rank, int rank, int world) {
   if (!c || !blobs) return fail(SAE_ERR_INVALID, "null argument");
@@ -1133,48 +1219,109 @@ extern "C" int sae_p2p_init(sae_ctx* c, const void* blobs, int64_t bytes_per_ran
     const long ms = atol(t);
     if (ms > 0) c->p2p_timeout_ticks = (unsigned long long)ms * 100000ull;
   }
+  if (const char* f = getenv("FREUD_P2P_FAULT")) {     // test hook: "skip_phase2:<rank>[:<after this many gradient exchanges>]"
+    int fr = -1;
+    long long after = 0;
+    if (sscanf(f, "skip_phase2:%d:%lld", &fr, &after) >= 1) {
+      c->p2p_fault_kind = 1;
+      c->p2p_fault_rank = fr;
+      c->p2p_fault_after = (unsigned long long)after;
+    }
+  }
   c->p2p = true;
   c->p2p_rank = rank;
   c->dist = true;
   c->dp_world = world;
   rc = p2p_selftest(c);
-  if (rc) {          // leave the protocol again: the caller may fall back to a host-driven exchange with this context
-    c->p2p = false;
-    c->dist = false;
-    c->dp_world = 0;
-    (void)hipDeviceSynchronize();
-    for (int i = 0; i < c->p2p_nopened; ++i) (void)hipIpcCloseMemHandle(c->p2p_opened[i]);
-    c->p2p_nopened = 0;
-    (void)hipMemset(c->p2p_status, 0, 64);
-  }
+  if (rc) p2p_leave(c);     // the caller may fall back to another exchange with this context
   return rc;
 }
 
-// every rank fills its gradient buffer (and the bf16 copy) with a rank-dependent pattern, exchanges, and checks the sums:
-// proves mappings, flags and both payloads before the first training step; a rank that cannot reach its peers times out here
-// (status word) instead of corrupting a run.  Collective: every rank runs it inside sae_p2p_init.
+// Leave the peer exchange again (a peer's self-test failed although this rank's passed: every rank must fall back together).
+extern "C" int sae_p2p_leave(sae_ctx* c) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (!c->p2p) return SAE_OK;
+  USE_DEVICE(c);
+  p2p_leave(c);
+  return SAE_OK;
+}
+
+// Start-up self-test of the peer exchange (collective: every rank runs it inside sae_p2p_init).  P2P_SELFTEST_EPOCHS exchanges
+// of EACH payload form over the SAME addresses, every one with a different rank-dependent pattern (p2p_exchange.h), checked on
+// the device after every exchange:
+//   kind 0  fp32, the whole parameter gradient as one contiguous segment (the fused d = 384 path)
+//   kind 1  bf16 payload of the same segment (bf16 copies read from the peers, fp32 results)
+//   kind 2  fp32, a 2-D strided block (rows x cols at an offset, pitch n_p: the column chunks of the d >= 1024 path); the
+//           elements OUTSIDE the block must keep this rank's own values
+//   kind 3  fp64 on the statistics channel (its own flags and epochs)
+//   kind 4  the statistics push through the inbox (finalize_losses_kernel's StatsPush)
+// A peer line that survives in a cache from one exchange to the next, a flag that overtakes its data, a mapping to the wrong
+// buffer: each gives wrong sums here, before the first training step.  A rank that cannot reach its peers times out (status
+// word) instead of corrupting a run.  FREUD_P2P_FAULT=skip_phase2:<rank> is caught here (tests/test_dp_gpu.py).
+constexpr int P2P_SELFTEST_EPOCHS = 4;
 static int p2p_selftest(sae_ctx* c) {
   hipStream_t s = c->comm_stream;
   const int64_t n = c->nparams;
+  const int64_t ns = c->stats_cap < 4096 ? c->stats_cap : 4096;        // doubles of the statistics buffer exercised (>= DP_STATS_HEAD)
   std::vector<float> keep((size_t)n);
+  std::vector<double> keep_stats((size_t)ns);
   HIP_TRY(hipMemcpy(keep.data(), c->G, (size_t)n * 4, hipMemcpyDeviceToHost));
-  unsigned int bad_total = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    hipLaunchKernelGGL(p2p_selftest_fill_kernel, dim3(256), dim3(256), 0, s, c->G, c->Gb, n, c->p2p_rank);
-    P2PSeg g{};
-    g.off = 0; g.pitch = n; g.rows = 1; g.cols = (int)n; g.kind = pass == 0 ? P2P_F32 : P2P_BF16; g.in_norm = 1;
-    p2p_launch(c, 1, &g, 1, p2p_grid(n / 4), c->gn_part, s);
-    HIP_TRY(hipMemsetAsync(c->p2p_status + 1, 0, 4, s));
-    hipLaunchKernelGGL(p2p_selftest_check_kernel, dim3(256), dim3(256), 0, s, c->G, n, c->dp_world, c->p2p_status + 1);
+  HIP_TRY(hipMemcpy(keep_stats.data(), c->stats, (size_t)ns * 8, hipMemcpyDeviceToHost));
+  unsigned int bad_total = 0, bad_kind[5] = {};
+  auto collect = [&](int kind) -> int {
     unsigned int st[2] = {};
     HIP_TRY(hipMemcpyAsync(st, c->p2p_status, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (st[0] & 1u) return fail(SAE_ERR_HIP, "peer exchange self-test: a peer did not arrive within %.1f s", c->p2p_timeout_ticks / 1e8);
+    if (st[0] & P2P_ST_TIMEOUT) return fail(SAE_ERR_HIP, "peer exchange self-test: a peer did not arrive within %.1f s", c->p2p_timeout_ticks / 1e8);
+    if (st[0] & P2P_ST_POISONED) return fail(SAE_ERR_HIP, "peer exchange self-test: a peer left the protocol (its self-test failed or timed out)");
     bad_total += st[1];
+    bad_kind[kind] += st[1];
+    return SAE_OK;
+  };
+  // the 2-D block: the second quarter of the columns of every W row (L1: [d_p x n_p]; TopK: the first [d_p rows] of the flat buffer
+  // read with pitch n_p -- the exchange kernel does not care what the floats mean)
+  P2PSeg blk{};
+  blk.pitch = c->n_p; blk.rows = (int)((n / c->n_p) < c->d_p ? (n / c->n_p) : c->d_p); blk.cols = (c->n_p / 4) & ~3; blk.off = blk.cols;
+  blk.kind = P2P_F32; blk.in_norm = 0;
+  for (int e = 0; e < P2P_SELFTEST_EPOCHS; ++e) {
+    for (int kind = 0; kind < 5; ++kind) {
+      HIP_TRY(hipMemsetAsync(c->p2p_status + 1, 0, 4, s));
+      if (kind <= 2) {
+        hipLaunchKernelGGL(p2p_selftest_fill_kernel, dim3(256), dim3(256), 0, s, c->G, c->Gb, n, c->p2p_rank, e, kind);
+        P2PSeg g{};
+        g.off = 0; g.pitch = n; g.rows = 1; g.cols = (int)n; g.kind = kind == 1 ? P2P_BF16 : P2P_F32; g.in_norm = 1;
+        if (kind == 2) g = blk;
+        if (kind == 2 && (blk.cols < 4 || blk.rows < 1)) continue;
+        p2p_launch(c, 1, &g, 1, p2p_grid((int64_t)g.rows * (g.cols / 4)), kind == 2 ? nullptr : c->gn_part, s);
+        hipLaunchKernelGGL(p2p_selftest_check_kernel, dim3(256), dim3(256), 0, s, c->G, n, g, c->p2p_rank, c->dp_world, e, kind, c->p2p_status + 1);
+      } else if (kind == 3) {
+        hipLaunchKernelGGL(p2p_selftest_fill64_kernel, dim3(16), dim3(256), 0, s, c->stats, ns, c->p2p_rank, e, kind);
+        P2PSeg g{};
+        g.off = 0; g.pitch = ns; g.rows = 1; g.cols = (int)(ns & ~1ll); g.kind = P2P_F64;
+        p2p_launch(c, 0, &g, 1, p2p_grid(g.cols / 2), nullptr, s);
+        hipLaunchKernelGGL(p2p_selftest_check64_kernel, dim3(16), dim3(256), 0, s, c->stats, (int64_t)g.cols, c->dp_world, e, kind, c->p2p_status + 1);
+      } else {
+        StatsPush push{};
+        for (int r = 0; r < c->dp_world; ++r) push.inbox[r] = c->p2p_sig[r] + P2P_SIG_WORDS;
+        push.rank = c->p2p_rank; push.world = c->dp_world; push.epoch = ++c->p2p_epoch_push;
+        push.timeout_ticks = c->p2p_timeout_ticks; push.status = c->p2p_status; push.status_host = c->p2p_status_hostdev; push.gstats_out = nullptr;
+        hipLaunchKernelGGL(p2p_selftest_push_kernel, dim3(1), dim3(64), 0, s, push, e, c->p2p_status + 1);
+      }
+      HIP_TRY(hipGetLastError());
+      const int rc = collect(kind);
+      if (rc) return rc;
+    }
   }
   HIP_TRY(hipMemcpy(c->G, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->stats, keep_stats.data(), (size_t)ns * 8, hipMemcpyHostToDevice));
   if (c->dist_error) return fail(SAE_ERR_HIP, "peer exchange self-test: %s", c->dist_errmsg);
-  if (bad_total) return fail(SAE_ERR_HIP, "peer exchange self-test: %u wrong sums", bad_total);
+  if (bad_total) {
+    // tell the peers: a rank whose own sums were right must not go on with one whose sums were wrong
+    unsigned int code = P2P_ST_SELFTEST;
+    (void)hipMemcpy(c->p2p_status, &code, 4, hipMemcpyHostToDevice);
+    return fail(SAE_ERR_HIP, "peer exchange self-test: %u wrong values (fp32 %u, bf16 payload %u, strided block %u, fp64 statistics %u, statistics push %u) "
+                             "in %d exchanges per payload form", bad_total, bad_kind[0], bad_kind[1], bad_kind[2], bad_kind[3], bad_kind[4], P2P_SELFTEST_EPOCHS);
+  }
   return SAE_OK;
 }
 
@@ -1190,6 +1337,14 @@ extern "C" int sae_dist_set_overlap(sae_ctx* c, int nranges) {
   return SAE_OK;
 }
 
+static int p2p_status_error(sae_ctx* c, unsigned int st) {
+  if (st & P2P_ST_TIMEOUT)
+    return fail(SAE_ERR_HIP, "peer exchange: a peer did not arrive within %.1f s (the replicas are out of step: results after the last "
+                             "successful check are invalid)", c->p2p_timeout_ticks / 1e8);
+  if (st & P2P_ST_POISONED) return fail(SAE_ERR_HIP, "peer exchange: a peer left the protocol (timed out or failed); results after the last successful check are invalid");
+  return fail(SAE_ERR_HIP, "peer exchange: failure word %u", st);
+}
+
 // Synchronises the context's streams and reports a failure of the in-engine exchange (a peer that never arrived: the
 // exchange kernels give up after the timeout instead of hanging the GPU).
 extern "C" int sae_dist_check(sae_ctx* c) {
@@ -1200,9 +1355,61 @@ extern "C" int sae_dist_check(sae_ctx* c) {
   if (c->p2p) {
     unsigned int st = 0;
     HIP_TRY(hipMemcpy(&st, c->p2p_status, 4, hipMemcpyDeviceToHost));
-    if (st & 1u) return fail(SAE_ERR_HIP, "peer exchange: a peer did not arrive within %.1f s (results of this run are invalid)", c->p2p_timeout_ticks / 1e8);
+    if (st) return p2p_status_error(c, st);
   }
   if (c->dist_error) return fail(SAE_ERR_HIP, "%s", c->dist_errmsg);
+  return SAE_OK;
+}
+
+// layout of the gradient buffer: out[0] floats of parameter gradients, out[1] loss scalars behind them (SAE_NUM_METRICS; some
+// are written AFTER the exchange, e.g. the clipped gradient norm), out[2] did_fire flags behind those (TopK)
+extern "C" int sae_grad_layout(sae_ctx* c, int64_t out[3]) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  out[0] = c->nparams;
+  out[1] = SAE_NUM_METRICS;
+  out[2] = c->topk ? c->n_p : 0;
+  return SAE_OK;
+}
+
+extern "C" int sae_dist_audit(sae_ctx* c, float* snapshot_dev) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (snapshot_dev && !c->p2p) return fail(SAE_ERR_STATE, "the audit snapshots the peer exchange's inputs: call sae_p2p_init first");
+  c->audit_dst = snapshot_dev;
+  return SAE_OK;
+}
+
+extern "C" int sae_param_checksum(sae_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return fail(SAE_ERR_INVALID, "null argument");
+  USE_DEVICE(c);
+  HIP_TRY(hipDeviceSynchronize());
+  // (the raw buffers as they stand: with the folded weight preparation of the L1 path the master holds the un-normalised update
+  // on EVERY replica alike -- nothing is settled here, the call does not change what the next step launches)
+  unsigned long long* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, 32));
+  hipError_t e = hipMemset(dev, 0, 32);
+  const float* bufs[3] = {c->P, c->Mom, c->Var};
+  for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+    hipLaunchKernelGGL(checksum_kernel, dim3(512), dim3(256), 0, nullptr, bufs[i], c->nparams, dev + i);
+    e = hipGetLastError();
+  }
+  unsigned long long h[4] = {};
+  if (e == hipSuccess) e = hipMemcpy(h, dev, 24, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(SAE_ERR_HIP, "parameter checksum failed: %s", hipGetErrorString(e));
+  h[3] = (unsigned long long)c->step;
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
+  return SAE_OK;
+}
+
+// The same check WITHOUT synchronising: reads the host-mapped mirror of the failure word (the exchange kernels store it there
+// when they give up).  Free to call after every step; a failure it does not see yet shows at the next sae_dist_check.
+extern "C" int sae_dist_poll(sae_ctx* c) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (c->dist_error) return fail(SAE_ERR_HIP, "%s", c->dist_errmsg);
+  if (c->p2p && c->p2p_status_host) {
+    const unsigned int st = *(volatile unsigned int*)c->p2p_status_host;
+    if (st) return p2p_status_error(c, st);
+  }
   return SAE_OK;
 }
 
@@ -1427,7 +1634,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     if (gs && inline_stats(c)) {       // peer exchange: the statistics travel inside this kernel (no pass over x, no second stream)
       for (int r = 0; r < c->dp_world; ++r) push.inbox[r] = c->p2p_sig[r] + P2P_SIG_WORDS;
       push.rank = c->p2p_rank; push.world = c->dp_world; push.epoch = ++c->p2p_epoch_push;
-      push.timeout_ticks = c->p2p_timeout_ticks; push.status = c->p2p_status; push.gstats_out = c->stats;
+      push.timeout_ticks = c->p2p_timeout_ticks; push.status = c->p2p_status; push.status_host = c->p2p_status_hostdev; push.gstats_out = c->stats;
     } else if (gs && c->dist) {
       HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));      // the summed statistics have arrived
     }
@@ -1508,7 +1715,16 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       // kernel takes as it is): every chunk reads only its own columns of the latent / dpre streams, so chunking costs no
       // extra HBM traffic -- row chunks (the contiguous ranges RCCL and the host callback need) re-read both 5.4 GB streams
       // once per chunk: +1.5 ms of the 30 ms C4 step on one rank.
-      const bool col_chunked = c->dist && c->dp_world > 0 && c->p2p && c->dw_col_chunks > 1;
+      // In-engine RCCL (round 4): the same column chunks, each summed over its split-K slabs into a CONTIGUOUS staging block,
+      // all-reduced there and copied back into its strided place on the communication stream (two passes over 52 MB per chunk
+      // at C4 against re-reading two 5.4 GB streams per row chunk).  Host-driven exchange: row chunks (the callback's contract
+      // is a contiguous range of the gradient buffer).
+      const bool col_staged = c->dist && c->dp_world > 0 && !c->p2p && c->dw_col_chunks > 1 && c->cfg.debug_flags != 82;
+      if (col_staged && !c->col_stage) {
+        hipError_t e_ = hipMalloc((void**)&c->col_stage, (size_t)c->nW * 4);
+        if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "staging buffer of the column chunks: %s", hipGetErrorString(e_));
+      }
+      const bool col_chunked = c->dist && c->dp_world > 0 && (c->p2p || col_staged) && c->dw_col_chunks > 1;
       if (col_chunked) {
         const int cols = n_p / c->dw_col_chunks;
         ev_begin(c, KID_DW, s);
@@ -1522,8 +1738,16 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           e.slab = c->slab + col0; e.slab_stride = c->nW; e.ld = n_p;
           rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
           if (rc) return rc;
-          hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3(512), dim3(256), 0, s, c->slab, c->nW, g.splits, n_p, d_p, col0, cols, c->G);
-          exchange_block(c, col0, d_p, cols, n_p, s);
+          if (c->p2p) {
+            hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3(512), dim3(256), 0, s, c->slab, c->nW, g.splits, n_p, d_p, col0, cols, c->G,
+                               (int64_t)n_p, col0);
+            exchange_block(c, col0, d_p, cols, n_p, s);
+          } else {
+            float* stage = c->col_stage + (int64_t)q * d_p * cols;
+            hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3(512), dim3(256), 0, s, c->slab, c->nW, g.splits, n_p, d_p, col0, cols, stage,
+                               (int64_t)cols, 0);
+            exchange_staged(c, stage, col0, d_p, cols, n_p, s);
+          }
         }
         ev_end(c, KID_DW, s);
         dw_chunked = dw_chunked_any = true;

@@ -501,8 +501,10 @@ struct StatsPush {
 
 // The push itself: lane r (< world) of the calling wave writes (v0, v1, epoch) into rank r's inbox and waits for rank r's
 // triple in its own.  The inbox is uncached device memory and every access a system-scope atomic: no cache holds these words.
-// Order: the two payload words, a system-scope release fence + s_waitcnt vmcnt(0) (inline asm -- the compiler may drop the
-// wait, MI355X_MICROARCH.md "Compiler hazard"), then the epoch word.  Failure handling as in p2p_barrier (p2p_exchange.h): a
+// Nothing of the triple is ever held in a cache (uncached allocation, `sc0 sc1` accesses on both sides), so no write-back or
+// invalidate is involved -- what is needed is ORDER: the two payload words, `s_waitcnt vmcnt(0)` (their write acknowledgements;
+// inline asm so that the compiler cannot drop or move it), then the epoch word; on the reading side the payload loads are
+// issued only after the epoch load has returned the expected value (tests/test_p2p_codeobj.py asserts both in the code object).  Failure handling as in p2p_barrier (p2p_exchange.h): a
 // context whose status word is set pushes PUSH_POISON instead of its epoch and does not wait; a poll that times out or reads
 // a poisoned epoch sets the status word and poisons both parities of its slots in every peer's inbox.
 constexpr unsigned long long PUSH_POISON = 1ull << 63;
@@ -514,8 +516,7 @@ __device__ __forceinline__ void stats_push_exchange(const StatsPush& push, doubl
     unsigned long long* dst = push.inbox[r] + slot + push.rank * 4;
     __hip_atomic_store(dst + 0, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // both payload words acknowledged before the epoch word leaves
     __hip_atomic_store(dst + 2, failed ? (push.epoch | PUSH_POISON) : push.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     peer[r][0] = v0;                // (placeholders of a failed exchange: finite numbers, the run is reported invalid anyway)
     peer[r][1] = v1;
@@ -538,7 +539,7 @@ __device__ __forceinline__ void stats_push_exchange(const StatsPush& push, doubl
         __hip_atomic_store(push.inbox[r] + push.rank * 4 + 2, push.epoch | PUSH_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(push.inbox[r] + 32 + push.rank * 4 + 2, push.epoch | PUSH_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the epoch was seen: the payload loads are issued after it returned)
         peer[r][0] = __longlong_as_double((long long)__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         peer[r][1] = __longlong_as_double((long long)__hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
       }

@@ -85,6 +85,9 @@ __device__ __forceinline__ void p2p_mark_failed(unsigned int* status, unsigned i
 
 // One barrier of the exchange (see the header comment for the instruction sequence and why).  `fail_s`: the workgroup's
 // failure word in LDS (set at kernel start from the sticky status word).  Returns false when the protocol has failed.
+// FENCES = false (barrier 2): nothing was written for the peers since barrier 1 and nothing of theirs is read afterwards -- the
+// barrier only says "I have finished reading your buffer" -- so neither the write-back nor the invalidate is needed.
+template <bool FENCES = true>
 __device__ __forceinline__ bool p2p_barrier(const P2PArgs& a, int slot, volatile int* fail_s) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its stores of the phase have left the wave
   __syncthreads();
@@ -92,8 +95,10 @@ __device__ __forceinline__ bool p2p_barrier(const P2PArgs& a, int slot, volatile
     const bool failed = *fail_s != 0;
     const int64_t blk = (int64_t)blockIdx.x * P2P_MAX_WORLD;
     const int64_t base = ((int64_t)a.channel * 3 + slot) * P2P_MAX_BLOCKS * P2P_MAX_WORLD + blk;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: buffer_wbl2 sc0 sc1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... completed BEFORE the flag leaves
+    if (FENCES) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: buffer_wbl2 sc0 sc1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... completed BEFORE the flag leaves
+    }
     __hip_atomic_store(a.sig[threadIdx.x] + base + a.rank, failed ? (a.epoch | P2P_POISON) : a.epoch, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     if (!failed) {
@@ -120,8 +125,10 @@ __device__ __forceinline__ bool p2p_barrier(const P2PArgs& a, int slot, volatile
                              a.epoch | P2P_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // system scope: buffer_inv sc0 sc1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before the workgroup is released
+    if (FENCES) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: buffer_inv sc0 sc1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed before the workgroup is released
+    }
   }
   __syncthreads();
   return *fail_s == 0;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
 
   __shared__ int fail_s;
   if (threadIdx.x == 0) fail_s = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky
-  bool ok = p2p_barrier(a, 0, &fail_s);     // (its first workgroup barrier publishes fail_s)
+  bool ok = p2p_barrier<true>(a, 0, &fail_s);     // (its first workgroup barrier publishes fail_s)
 
   // ---- phase 1: the owner's sum of slice (rank, b) over every rank's copy, in rank order
   for (int sgi = 0; ok && sgi < a.nseg; ++sgi) {
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
   }
 
   if (a.world > 1) {
-    ok = p2p_barrier(a, 1, &fail_s);
+    ok = p2p_barrier<true>(a, 1, &fail_s);
 
     // ---- phase 2: fetch every other shard's slice b from its owner
 #pragma unroll
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
       }
     }
 
-    p2p_barrier(a, 2, &fail_s);
+    p2p_barrier<false>(a, 2, &fail_s);
   }
 
   if (EPV == 4 && a.gn_part) {
@@ -285,16 +292,19 @@ __global__ __launch_bounds__(256) void reduce_grads_range_kernel(const float* __
 
 // dW rows [0, d_p) x columns [c0, c0 + cols) of the generic weight-gradient GEMM's split-K slabs -> gradient buffer (the
 // column chunks of the d >= 1024 path under the peer exchange)
+// `out` / `out_pitch` / `out_c0`: where the summed block goes -- the gradient buffer itself (pitch n_p, column c0: the peer exchange
+// takes the strided block as it is) or a CONTIGUOUS staging block (pitch cols, column 0: what RCCL can sum in one call)
 __global__ __launch_bounds__(256) void reduce_slabs_range_kernel(const float* __restrict__ slab, int64_t slab_stride, int splits, int n_p,
-                                                                  int d_p, int c0, int cols, float* __restrict__ grad) {
+                                                                  int d_p, int c0, int cols, float* __restrict__ out, int64_t out_pitch,
+                                                                  int out_c0) {
   const int vpr = cols / 4;
   const int64_t nv = (int64_t)d_p * vpr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / vpr;
-    const int64_t o = row * n_p + c0 + (i - row * vpr) * 4;
+    const int64_t row = i / vpr, cv = (i - row * vpr) * 4;
+    const int64_t o = row * n_p + c0 + cv;
     f32x4 a = *reinterpret_cast<const f32x4*>(slab + o);
     for (int k = 1; k < splits; ++k) a += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * slab_stride + o);
-    *reinterpret_cast<f32x4*>(grad + o) = a;
+    *reinterpret_cast<f32x4*>(out + row * out_pitch + out_c0 + cv) = a;
   }
 }
 

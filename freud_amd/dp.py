@@ -12,8 +12,20 @@ forms of the same exact protocol (include/freud_sae.h, "data-parallel exactness"
   "host"  torch.distributed from Python (RCCL under the "nccl" backend, gloo on CPU): statistics all-reduce, forward_backward,
           gradient ranges all-reduced as the engine announces them, optimizer_step.
 
-FREUD_DP = auto (default) | p2p | rccl | host.  auto: p2p where every rank can map its peers and the start-up self-test
-exchange passes, else host.  (FREUD_DP_HOST=1 is the older spelling of FREUD_DP=host.)
+FREUD_DP = auto (default) | p2p | rccl | host.  auto: p2p where every rank can map its peers AND the start-up self-test passes
+(four exchanges of every payload form over the same addresses with changing patterns: a stale cached peer line gives wrong
+sums there), else the in-engine RCCL form, else host.  (FREUD_DP_HOST=1 is the older spelling of FREUD_DP=host.)
+
+Why p2p may be the default although no two-GPU box has ever been available to this build: its failure is made LOUD,
+not silent, at three levels, all of which run on whatever hardware the job lands on --
+  1. the self-test above (sae_p2p_init), on every rank, before the first step;
+  2. audit(): real gradients -- this rank's contribution is snapshotted before an exchange, the snapshots are summed by an
+     INDEPENDENT carrier (torch.distributed: RCCL / gloo) and compared with what the peer exchange produced.  A wrong sum that
+     is identical on every rank, which no replica comparison can see, shows here.  Runs on the first FREUD_DP_AUDIT_STEPS (3)
+     steps and at every logging step of train(), and in bench.py's warm-up (result in the JSON line);
+  3. check_replicas(): 64-bit checksums of parameters and optimizer moments compared across the ranks at every logging step and
+     before every checkpoint write: replicas are bit-identical by construction, any difference is an exchange bug.
+A failed audit or replica check raises ExchangeError naming rank and step; train() then writes nothing and exits non-zero.
 """
 from __future__ import annotations
 
@@ -28,6 +40,11 @@ def requested_mode() -> str:
     if mode not in ("auto", "p2p", "rccl", "host"):
         raise ValueError(f"FREUD_DP={mode!r}: must be auto, p2p, rccl or host")
     return mode
+
+
+class ExchangeError(RuntimeError):
+    """The data-parallel exchange produced (or would produce) wrong numbers: replicas diverged, an audit mismatch, a peer that
+    left the protocol.  train() turns it into a non-zero exit that names the last good checkpoint."""
 
 
 def _all_agree(dist, ok: bool, device) -> bool:
@@ -48,6 +65,8 @@ def setup(eng, dist, rank: int, world: int, device, mode: str = "auto", payload:
     if not nccl:
         device = "cpu"                               # the hand-shake tensors travel over the host backend
     chosen = "host"
+    if mode == "p2p" and world > 8:
+        raise RuntimeError(f"FREUD_DP=p2p serves up to 8 ranks of one node (world = {world}); use FREUD_DP=rccl or host")
     # the peer exchange only uses the process group as a host channel for the handles: any backend will do
     if hip_engine and mode in ("auto", "p2p") and world <= 8:
         ok, err = True, None
@@ -72,9 +91,10 @@ def setup(eng, dist, rank: int, world: int, device, mode: str = "auto", payload:
             if mode == "p2p":
                 raise RuntimeError("FREUD_DP=p2p: the peer exchange could not be set up on every rank")
             if ok:
-                # this rank holds working mappings but a peer does not: a context cannot leave the protocol again
-                raise RuntimeError("peer exchange came up on some ranks only; restart with FREUD_DP=host")
-    elif mode == "rccl":
+                eng.p2p_leave()             # this rank's self-test passed, a peer's did not: fall back TOGETHER
+    if chosen == "host" and hip_engine and nccl and (mode == "rccl" or mode == "auto"):
+        # in-engine RCCL: the explicit choice, and auto's second option (nodes above 8 ranks, peers that cannot be mapped,
+        # a failed self-test) before the Python-driven protocol
         ids = [eng.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ok = True
@@ -83,9 +103,12 @@ def setup(eng, dist, rank: int, world: int, device, mode: str = "auto", payload:
         except Exception as e:              # noqa: BLE001
             print(f"[rank {rank}] in-engine RCCL unavailable ({e})", file=sys.stderr)
             ok = False
-        if not _all_agree(dist, ok, device):
+        if _all_agree(dist, ok, device):
+            chosen = "rccl"
+        elif mode == "rccl":
             raise RuntimeError("FREUD_DP=rccl: the engine's communicator could not be created on every rank")
-        chosen = "rccl"
+        elif ok:
+            raise RuntimeError("in-engine RCCL came up on some ranks only; restart with FREUD_DP=host")
     if chosen in ("p2p", "rccl"):
         if payload == "bfloat16":
             eng.dist_set_payload("bfloat16")
@@ -96,3 +119,99 @@ def setup(eng, dist, rank: int, world: int, device, mode: str = "auto", payload:
     else:
         eng.set_dp_world(world)
     return chosen
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# run-time guards of the in-engine exchange (module docstring, levels 2 and 3)
+# ------------------------------------------------------------------------------------------------------------------------
+class Auditor:
+    """Sum check of the peer exchange against an independent carrier.
+
+        aud = Auditor(eng, dist, rank, world)       # allocates the snapshot buffer (same size as the gradient buffer)
+        aud.arm(); eng.step(x, lr); aud.verify(step)    # one audited step
+
+    arm() makes every gradient exchange of the next step copy the segments it is about to sum into the snapshot; verify()
+    all-reduces the snapshot over `dist` (nccl: on the device; gloo: through host memory) and compares with the gradient
+    buffer the engine holds after the step.  Only the exchanged segments are compared (the snapshot is NaN elsewhere).
+    fp32 payload: the two sums differ by summation order only -> rel. error <= 1e-5; bf16 payload: one bf16 rounding of
+    the inputs and one of the sum -> <= 2e-2."""
+
+    def __init__(self, eng, dist, rank: int, world: int, payload: str = "float32"):
+        import torch
+        self.eng, self.dist, self.rank, self.world = eng, dist, rank, world
+        self.grads = eng.grad_tensor()
+        self.snap = torch.empty_like(self.grads)
+        # the loss scalars ride in the exchanged buffer, but some of them are written AFTER the exchange (the optimizer leaves the
+        # clipped gradient norm there): the comparison covers the parameter gradients and the did_fire flags
+        n_par, n_met, _ = eng.grad_layout()
+        self.cmp = torch.ones(self.grads.numel(), dtype=torch.bool, device=self.grads.device)
+        self.cmp[n_par:n_par + n_met] = False
+        self.tol = 2e-2 if payload == "bfloat16" else 1e-5
+        self.armed = False
+        self.passed = 0
+
+    def arm(self) -> None:
+        self.snap.fill_(float("nan"))
+        self.eng.dist_audit(self.snap)
+        self.armed = True
+
+    def verify(self, step: int) -> float:
+        import torch
+        assert self.armed
+        self.eng.dist_audit(None)
+        self.armed = False
+        torch.cuda.synchronize()
+        mask = ~torch.isnan(self.snap) & self.cmp
+        ref = torch.where(mask, self.snap, torch.zeros_like(self.snap))
+        if self.dist.get_backend() == "nccl":
+            self.dist.all_reduce(ref)
+        else:
+            host = ref.cpu()
+            self.dist.all_reduce(host)
+            ref = host.to(ref.device)
+        got = torch.where(mask, self.grads, torch.zeros_like(self.grads))
+        n_cmp = int(mask.sum().item())
+        if n_cmp == 0:
+            raise ExchangeError(f"[rank {self.rank}] step {step}: exchange audit saw no exchanged segment (is the peer exchange in force?)")
+        err = float((got - ref).abs().max().item())
+        scale = float(ref.abs().max().item())
+        rel = err / max(scale, 1e-30)
+        mine_bad = not (rel <= self.tol)
+        # the verdict is COLLECTIVE: a rank whose own sums are right must stop together with the one whose sums are wrong
+        flags = torch.zeros(self.world, dtype=torch.int32)
+        flags[self.rank] = 1 if mine_bad else 0
+        if self.dist.get_backend() == "nccl":
+            flags = flags.cuda()
+        self.dist.all_reduce(flags)
+        failed = [r for r in range(self.world) if int(flags[r].item()) != 0]
+        if failed:
+            detail = ""
+            if mine_bad:
+                bad = int(((got - ref).abs() > self.tol * max(scale, 1e-30)).sum().item())
+                detail = (f": max |diff| {err:.3e} at scale {scale:.3e} (rel {rel:.2e} > {self.tol:.0e}), {bad} of {n_cmp} elements here")
+            raise ExchangeError(f"[rank {self.rank}] step {step}: the peer exchange's sum differs from the {self.dist.get_backend()} "
+                                f"all-reduce of the same inputs on rank(s) {failed}{detail} -- stale or misdirected peer reads; "
+                                "restart with FREUD_DP=rccl or host")
+        self.passed += 1
+        return rel
+
+
+def check_replicas(eng, dist, rank: int, world: int, step: int) -> None:
+    """Raise ExchangeError unless every rank holds bit-identical parameters and optimizer moments (64-bit checksums over the
+    host channel).  Collective.  Cheap: three passes over the parameters on the device + one small all-gather."""
+    import torch
+    mine = eng.param_checksum()
+    # int64 carries the 64 checksum bits (two's complement): gloo and nccl both move int64
+    t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in mine], dtype=torch.int64)
+    nccl = dist.get_backend() == "nccl"
+    if nccl:
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    rows = [tuple(int(v) for v in o.cpu().tolist()) for o in out]
+    if any(r != rows[0] for r in rows):
+        names = ("parameters", "exp_avg", "exp_avg_sq", "step count")
+        diff = [(r, [names[k] for k in range(4) if rows[r][k] != rows[0][k]]) for r in range(1, world) if rows[r] != rows[0]]
+        raise ExchangeError(f"[rank {rank}] step {step}: replicas diverged (bit-identical by construction, so this is an exchange bug): "
+                            + "; ".join(f"rank {r} differs from rank 0 in {', '.join(w)}" for r, w in diff))
+

@@ -94,8 +94,13 @@ def load() -> C.CDLL:
         "sae_p2p_blob_bytes": (C.c_int, []),
         "sae_p2p_export": (C.c_int, [vp, vp, i64]),
         "sae_p2p_init": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
+        "sae_p2p_leave": (C.c_int, [vp]),
         "sae_dist_set_overlap": (C.c_int, [vp, C.c_int]),
         "sae_dist_check": (C.c_int, [vp]),
+        "sae_dist_poll": (C.c_int, [vp]),
+        "sae_dist_audit": (C.c_int, [vp, vp]),
+        "sae_grad_layout": (C.c_int, [vp, C.POINTER(i64)]),
+        "sae_param_checksum": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "sae_set_grad_ready_callback": (C.c_int, [vp, GRAD_READY_FN, vp]),
         "sae_get_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
         "sae_set_topk_state": (C.c_int, [vp, C.POINTER(C.c_int64), i64]),
@@ -128,8 +133,8 @@ EXPORTED_SYMBOLS = [
     "sae_last_error", "sae_version", "sae_create", "sae_destroy", "sae_set_params", "sae_get_params",
     "sae_set_opt_state", "sae_get_opt_state", "sae_forward_backward", "sae_grad_buffer", "sae_optimizer_step",
     "sae_set_grad_ready_callback", "sae_batch_stats", "sae_stats_buffer", "sae_set_dp_world", "sae_dist_unique_id",
-    "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_p2p_blob_bytes", "sae_p2p_export", "sae_p2p_init",
-    "sae_dist_set_overlap", "sae_dist_check", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
+    "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_p2p_blob_bytes", "sae_p2p_export", "sae_p2p_init", "sae_p2p_leave",
+    "sae_dist_set_overlap", "sae_dist_check", "sae_dist_poll", "sae_dist_audit", "sae_grad_layout", "sae_param_checksum", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
     "sae_step", "sae_eval", "sae_eval_into", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
@@ -344,6 +349,10 @@ class SaeEngine:
         buf = C.create_string_buffer(joined, len(joined))
         _check(self._lib.sae_p2p_init(self._ctx, buf, len(blobs[0]), int(rank), int(world)))
 
+    def p2p_leave(self) -> None:
+        """Undo p2p_init (a peer's self-test failed although this rank's passed: the ranks fall back together)."""
+        _check(self._lib.sae_p2p_leave(self._ctx))
+
     def dist_set_overlap(self, nranges: int) -> None:
         """Fused d=384 backward in `nranges` column-tile ranges, each exchanged under the next one's backward."""
         _check(self._lib.sae_dist_set_overlap(self._ctx, int(nranges)))
@@ -351,6 +360,33 @@ class SaeEngine:
     def dist_check(self) -> None:
         """Synchronise and raise if an in-engine exchange failed (a peer never arrived)."""
         _check(self._lib.sae_dist_check(self._ctx))
+
+    def dist_poll(self) -> None:
+        """The same report without synchronising (host-mapped failure word): free after every step."""
+        _check(self._lib.sae_dist_poll(self._ctx))
+
+    def dist_audit(self, snapshot) -> None:
+        """snapshot: a float32 CUDA tensor shaped like grad_tensor() (kept alive by the caller) -- every gradient exchange
+        first copies the segments it is about to sum into it; None switches the snapshots off (freud_amd/dp.py: audit)."""
+        if snapshot is None:
+            _check(self._lib.sae_dist_audit(self._ctx, None))
+            return
+        g = self.grad_tensor()
+        assert snapshot.is_cuda and snapshot.dtype == g.dtype and snapshot.numel() == g.numel() and snapshot.is_contiguous()
+        _check(self._lib.sae_dist_audit(self._ctx, C.c_void_p(snapshot.data_ptr())))
+
+    def grad_layout(self) -> tuple:
+        """(parameter-gradient floats, loss scalars, did_fire flags) of grad_tensor(), in that order."""
+        out = (C.c_int64 * 3)()
+        _check(self._lib.sae_grad_layout(self._ctx, out))
+        return tuple(int(v) for v in out)
+
+    def param_checksum(self) -> tuple:
+        """(parameters, first moments, second moments, step): order-independent 64-bit checksums of the fp32 bits.  Replicas
+        of a data-parallel run must agree on all four (train() compares them over the host channel).  Synchronises."""
+        out = (C.c_uint64 * 4)()
+        _check(self._lib.sae_param_checksum(self._ctx, out))
+        return tuple(int(v) for v in out)
 
     def optimizer_step(self, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         _check(self._lib.sae_optimizer_step(self._ctx, float(lr), float(grad_scale), self._stream(stream)))

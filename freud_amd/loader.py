@@ -51,6 +51,11 @@ def _host_lib():
         lib.freud_gather_f32_to_bf16.restype = None
         lib.freud_f32_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.freud_f32_to_bf16.restype = None
+        lib.freud_f32_to_bf16_portable.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.freud_f32_to_bf16_portable.restype = None
+        lib.freud_convert_piece.argtypes = [C.c_void_p, C.c_int64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        lib.freud_convert_piece.restype = None
+        lib.freud_host_impl.restype = C.c_int
         _HOST_LIB = lib
     return _HOST_LIB
 
@@ -143,7 +148,13 @@ class MemoryMappedActivationDataLoader:
         small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= limit
         if self.device.type == "cuda" and not self._convert and (mode == "1" or (mode not in ("0",) and small)):
             self._try_register()
-        self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else min(8, max(1, (os.cpu_count() or 1) // 4))
+        # gather pool: a conversion thread moves ~8-11 GB/s of fp32 (AVX2; more with the AVX-512 streaming-store form), a
+        # 60 000-row tiny batch is 92 MB of fp32 per 0.6 ms train step -- round 3's 8 threads were the limit of the loader-fed
+        # rate on the driver's box (30.5 GB/s delivered).  A quarter of the host's hardware threads, between
+        # 1 and 24, per rank (a node's 8 ranks share the host: LOCAL_WORLD_SIZE divides the budget)
+        lw = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
+        auto = min(24, max(1, (os.cpu_count() or 1) // (4 * min(lw, 2))))
+        self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else auto
         self._pool = None
         self.skip_next = 0          # resume (train_sae f4): the next iterator drops this many leading batches unread
 
@@ -209,13 +220,20 @@ class MemoryMappedActivationDataLoader:
             idx64 = np.ascontiguousarray(np.asarray(idxs, dtype=np.int64))
             out16 = out.view(np.uint16) if out.dtype != np.uint16 else out
 
-            def conv(t):
-                sel = idx64[t::nthreads]
-                for q, j in enumerate(range(t, len(idx64), nthreads)):
-                    lib.freud_gather_f32_to_bf16(mm.ctypes.data, sel[q:q + 1].ctypes.data, 1, row, out16[j].ctypes.data)
-            if nthreads <= 1 or len(idxs) < 2 * nthreads:
+            if nthreads <= 1 or len(idx64) == 0:
                 lib.freud_gather_f32_to_bf16(mm.ctypes.data, idx64.ctypes.data, len(idx64), row, out16.ctypes.data)
                 return
+            # work items = pieces of rows (a multiple of 32 elements, so that every piece starts on a 64-byte line of the
+            # destination row): `per` pieces per row give every thread the same number of bytes whatever the batch size
+            per = max(1, -(-2 * nthreads // len(idx64)))
+            piece = ((row + per - 1) // per + 31) // 32 * 32
+            items = [(j, e0, min(e0 + piece, row)) for j in range(len(idx64)) for e0 in range(0, row, piece)]
+            base, dst0, stride = mm.ctypes.data, out16.ctypes.data, out16.strides[0]
+            rows_i = [int(v) for v in idx64]
+
+            def conv(t):
+                for j, e0, e1 in items[t::nthreads]:
+                    lib.freud_convert_piece(base, rows_i[j], row, e0, e1, dst0 + j * stride)
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="shard-gather")

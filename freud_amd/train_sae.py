@@ -23,6 +23,7 @@ import json
 import math
 import os
 import random
+import sys
 import time
 from typing import Callable, Dict, Optional
 
@@ -31,6 +32,8 @@ import torch
 
 from freud_amd.config import L1AutoEncoderConfig, TopKAutoEncoderConfig, get_n_dict_components
 from freud_amd.loader import MemoryMappedActivationDataLoader
+
+EXIT_EXCHANGE_FAILED = 3      # main(): the data-parallel exchange failed mid-run; restart fresh processes from the last good checkpoint
 
 
 # ------------------------------------------------------------------------------------------------
@@ -299,7 +302,9 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
             os.environ.setdefault("WORLD_SIZE", str(world))
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug_%h_%p.log")   # RCCL logs to stdout otherwise
             os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")           # gradient buffer = engine memory
-            backend = dist_backend or ("nccl" if device.type == "cuda" else "gloo")
+            # (FREUD_DIST_BACKEND=gloo: host channel only -- the peer exchange needs nothing else, and two RCCL ranks cannot
+            # share one GPU: how tests/test_dp_gpu.py runs the CLI with two processes on a 1-GPU box)
+            backend = dist_backend or os.environ.get("FREUD_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
             kw = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend, **kw)
 
@@ -390,6 +395,20 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
     # same protocol through torch.distributed: statistics all-reduce, forward_backward, gradient all-reduce (ranges as
     # the engine announces them when it can), optimizer.
     grads, works, overlap, in_engine = None, [], False, False
+    auditor, audit_first, last_good = None, 0, start_checkpoint
+
+    def guard(what):
+        """Before anything is persisted or reported: the in-engine exchange has not failed (local, synchronising) and -- with
+        more than one rank -- the replicas are bit-identical (collective).  Raises dp.ExchangeError; ADVICE r3: a rank that
+        sailed on after a peer gave up must never reach save_checkpoint."""
+        if in_engine:
+            try:
+                eng.dist_check()
+            except Exception as e:          # noqa: BLE001 -- EngineError text -> one exception type for the caller
+                raise dp.ExchangeError(f"[rank {rank}] step {state['step']} ({what}): {e}") from e
+        if use_dist and world > 1 and hasattr(eng, "param_checksum"):
+            dp.check_replicas(eng, dist, rank, world, state["step"])
+
     if use_dist:
         from freud_amd import dp
         dp_mode = dp.setup(eng, dist, rank, world, device, mode=dp.requested_mode(),
@@ -398,6 +417,11 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         in_engine = dp_mode in ("p2p", "rccl")
         if is_main:
             print(f"data parallel: {world} ranks, exchange = {dp_mode}")
+        if dp_mode == "p2p" and world > 1 and os.environ.get("FREUD_DP_AUDIT", "1") != "0":
+            # sum check of the peer exchange against torch.distributed on real gradients (freud_amd/dp.py, level 2): the first
+            # FREUD_DP_AUDIT_STEPS steps and every logging step
+            auditor = dp.Auditor(eng, dist, rank, world, payload=os.environ.get("FREUD_DP_PAYLOAD", "float32"))
+            audit_first = int(os.environ.get("FREUD_DP_AUDIT_STEPS", "3"))
         if not in_engine:
             grads = eng.grad_tensor()
             overlap = hasattr(eng, "set_grad_ready_callback") and dist.get_backend() == "nccl"
@@ -429,13 +453,22 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                     dist.all_reduce(grads)                  # sum of [grads | loss shares (| did_fire)] over ranks
                 eng.optimizer_step(step_lr, 1.0)            # the summed gradient IS the whole batch's: no 1/R
             else:
+                audit_now = auditor is not None and (state["step"] < audit_first or (state["step"] + 1) % log_tb_every == 0)
+                if audit_now:
+                    auditor.arm()
                 eng.step(activations, step_lr)
+                if audit_now:
+                    auditor.verify(state["step"] + 1)       # raises dp.ExchangeError on a wrong sum
+                elif in_engine and hasattr(eng, "dist_poll"):
+                    try:
+                        eng.dist_poll()                     # host-mapped failure word: no sync, no launch
+                    except Exception as e:                  # noqa: BLE001
+                        raise dp.ExchangeError(f"[rank {rank}] step {state['step'] + 1}: {e}") from e
             state["step"] += 1
             rows_done += activations.shape[0] * activations.shape[1] * world
 
             if state["step"] % log_tb_every == 0:           # the only device->host sync of the loop
-                if in_engine:
-                    eng.dist_check()                        # a peer that never arrived: stop, the replicas are out of step
+                guard("logging")                            # a peer that never arrived / diverged replicas: stop here
                 m = eng.metrics()
                 if autoencoder_variant == "l1":
                     logger.add_scalar("train/loss", float(m[0]) + float(m[1]), state["step"])
@@ -453,12 +486,16 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                 logger.add_scalar("train/activations_per_sec", rows_done / max(time.time() - t_start, 1e-9), state["step"])
 
             if state["step"] % save_every == 0:
+                guard("checkpoint")                         # nothing is written from a failed or diverged run
                 if is_main:
                     save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
+                last_good = checkpoint_out_dir + "/step" + str(state["step"]) + ".pth"
+                state["last_good_checkpoint"] = last_good
                 if use_dist:
                     dist.barrier()      # rank 0 wrote for a while: re-align before the next step's in-engine exchange (it times out)
 
             if state["step"] % val_every == 0:
+                guard("validation")
                 if is_main:
                     print("Validating...")
                 losses_dict, mag_max, mag_std = validate(eng, val_folder, device, whisper_config["layer_name"],
@@ -501,15 +538,19 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
                 break
         if n_batches == 0:
             raise RuntimeError(f"train loader yields no batches: {dset_len} files, batch_size {batch_size}, world {world}")
+        guard("epoch end")
         if is_main:    # epoch-end checkpoint (train_sae.py:600-602)
             save_checkpoint(state, checkpoint_out_dir + "/step" + str(state["step"]) + ".pth")
+        last_good = checkpoint_out_dir + "/step" + str(state["step"]) + ".pth"
+        state["last_good_checkpoint"] = last_good
         if use_dist:
             dist.barrier()
     logger.close()
     if use_dist:
-        if in_engine:
-            eng.dist_check()
+        guard("end of run")
         dist.barrier()
+    if auditor is not None:
+        state["exchange_audits_passed"] = auditor.passed
     return state
 
 
@@ -520,7 +561,25 @@ def main(argv=None):
     with open(args.config, "r") as f:
         config = json.load(f)
     config["device"] = torch.device(config["device"])
-    train(**config)
+    try:
+        train(**config)
+    except Exception as e:
+        from freud_amd import dp
+        if not isinstance(e, dp.ExchangeError):
+            raise
+        # Mid-run failure of the data-parallel exchange (a peer died or timed out, replicas diverged, an audit mismatch): nothing
+        # was written after the failure (every write is behind guard()).  This process has touched the GPU and must not re-exec
+        # itself: exit non-zero and let the launcher start FRESH processes from the last good checkpoint with another carrier.
+        run_dir = config.get("run_dir", "")
+        ckpts = []
+        if os.path.isdir(os.path.join(run_dir, "checkpoints")):
+            ckpts = sorted((f for f in os.listdir(os.path.join(run_dir, "checkpoints")) if f.startswith("step") and f.endswith(".pth")),
+                           key=lambda f: int(f[4:-4]))
+        last = os.path.join(run_dir, "checkpoints", ckpts[-1]) if ckpts else config.get("start_checkpoint")
+        print(f"FATAL: data-parallel exchange failed: {e}\n"
+              f"last good checkpoint: {last}\n"
+              f"restart fresh processes with FREUD_DP=host (or rccl) and \"start_checkpoint\": {json.dumps(last)}", file=sys.stderr)
+        sys.exit(EXIT_EXCHANGE_FAILED)
 
 
 if __name__ == "__main__":

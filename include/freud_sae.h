@@ -198,19 +198,40 @@ int sae_dist_set_payload(sae_ctx* ctx, int dtype);
  *   sae_p2p_export      allocates the exchange state and writes this rank's blob (hipIpc handles of the gradient buffer, its
  *                       bf16 copy, the statistics buffer and the flag block) to host memory;
  *   sae_p2p_init        takes the blobs of ALL ranks (rank order, gathered over any host channel), maps the peers and runs a
- *                       self-test exchange (collective: every rank must call it; a peer that cannot be reached makes it FAIL
- *                       after FREUD_P2P_TIMEOUT_MS, default 10000, instead of hanging).  Afterwards sae_forward_backward /
- *                       sae_step run the data-parallel protocol through the peer exchange; sae_dist_world() == world.
+ *                       self-test (collective: every rank must call it): four exchanges of every payload form -- fp32, bf16
+ *                       payload, a strided 2-D block, fp64 statistics, the statistics push -- over the SAME addresses with a
+ *                       different rank-dependent pattern each time, checked on the device, so that a stale cached peer line, a
+ *                       flag overtaking its data or a wrong mapping shows as wrong sums BEFORE the first step; a peer that
+ *                       cannot be reached makes it FAIL after FREUD_P2P_TIMEOUT_MS (default 120000: a liveness bound)
+ *                       instead of hanging.  Afterwards sae_forward_backward / sae_step run the data-parallel protocol
+ *                       through the peer exchange; sae_dist_world() == world.  FREUD_P2P_FINEGRAINED=1 (read by sae_create)
+ *                       puts the three peer-read buffers in fine-grained memory (no cache maintenance needed; slower).
  *   sae_dist_set_overlap  fused d = 384 path: launch the backward in `nranges` column-tile ranges; each range's gradient is
  *                       exchanged on the communication stream under the next range's backward (needs the peer exchange:
  *                       RCCL sums contiguous buffers only).  1 (default) = one launch, exchanged in line.
  *   sae_dist_check      synchronises and reports a failed exchange (a peer that never arrived: the exchange kernels give up
- *                       after the timeout -- the replicas are then out of step and the run must stop). */
+ *                       after the timeout, POISON the flags they owe their peers so that no rank sails on, and the failure is
+ *                       sticky -- the replicas are out of step and the run must stop);
+ *   sae_dist_poll       the same report without synchronising (host-mapped mirror of the failure word): free after every step;
+ *   sae_dist_audit      snapshot_dev != NULL: from now on every gradient exchange first copies the segments it is about to sum
+ *                       (this rank's own contribution) into snapshot_dev (device, same layout and size as sae_grad_buffer).
+ *                       The host sums the snapshots over the ranks with an INDEPENDENT carrier (torch.distributed) and
+ *                       compares with the exchanged gradient: a wrong-but-identical sum, which no replica comparison can
+ *                       see, shows here (freud_amd/dp.py: audit_step).  NULL switches it off.
+ *   sae_param_checksum  out_host[4] = order-independent 64-bit checksums of {parameters, first moments, second moments} and the
+ *                       step count.  Replicas are bit-identical by construction, so ANY difference between ranks is an
+ *                       exchange bug; train() compares them over the host channel at every logging step and before every
+ *                       checkpoint (no reference counterpart: train_sae.py:448-450 is single-device).  Synchronises. */
 int sae_p2p_blob_bytes(void);
 int sae_p2p_export(sae_ctx* ctx, void* blob_out_host, int64_t capacity_bytes);
 int sae_p2p_init(sae_ctx* ctx, const void* all_blobs_host, int64_t bytes_per_rank, int rank, int world);
+int sae_p2p_leave(sae_ctx* ctx);     /* undo sae_p2p_init (a PEER's self-test failed: every rank falls back together); no-op otherwise */
 int sae_dist_set_overlap(sae_ctx* ctx, int nranges);
 int sae_dist_check(sae_ctx* ctx);
+int sae_dist_poll(sae_ctx* ctx);
+int sae_dist_audit(sae_ctx* ctx, float* snapshot_dev);
+int sae_grad_layout(sae_ctx* ctx, int64_t out_host[3]);   /* floats of sae_grad_buffer: {parameter gradients, loss scalars, did_fire flags} */
+int sae_param_checksum(sae_ctx* ctx, uint64_t out_host[4]);
 
 /* clip_grad_norm_ + Adam/RAdam update with learning rate `lr` (train_sae.py:449-450).
  * grad_scale multiplies every gradient (and the loss scalars) first.  Asynchronous. */

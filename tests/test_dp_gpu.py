@@ -134,11 +134,11 @@ from freud_amd.engine import SaeEngine
 variant = sys.argv[1]
 torch.cuda.set_device(0)
 g = torch.Generator().manual_seed(1)
-d, n, M = (384, 1024, 2048) if variant == "l1" else (768, 2048, 1024)
+d, n, M = {"l1": (384, 1024, 2048), "l1_d1280": (1280, 1024, 1024), "topk": (768, 2048, 1024)}[variant]
 x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
 outs = []
 for dist_mode in (False, True):
-    if variant == "l1":
+    if variant.startswith("l1"):
         eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4)
         W = torch.empty(d, n); torch.nn.init.orthogonal_(W, generator=torch.Generator().manual_seed(2))
         eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)})
@@ -163,11 +163,13 @@ print(json.dumps({"rel": rel, "m0": outs[0][1].tolist(), "m1": outs[1][1].tolist
 """
 
 
-@pytest.mark.parametrize("variant", ["l1", "topk"])
+@pytest.mark.parametrize("variant", ["l1", "l1_d1280", "topk"])
 def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant):
     """sae_dist_init with a communicator of ONE rank: statistics all-reduce on the communication stream, gradient ranges
     all-reduced as they become final, stream joins -- the whole in-engine protocol -- must reproduce the plain step
-    (global statistics == local ones).  Child process: the communicator must not leak into the other tests."""
+    (global statistics == local ones).  Child process: the communicator must not leak into the other tests.
+    l1_d1280: the generic three-GEMM path, whose weight gradient travels as COLUMN chunks through a contiguous staging buffer
+    (summed there by RCCL, copied back into the strided block of the gradient buffer)."""
     import json
     import os
     import subprocess
@@ -193,6 +195,7 @@ from freud_amd.train_sae import train
 cfg = json.load(open(sys.argv[1]))
 world = int(os.environ.get("WORLD_SIZE", "1"))
 state = train(**cfg, dist_backend="gloo" if world > 1 else None)     # gloo: host channel only (two NCCL ranks cannot share a GPU)
+print("AUDITS_PASSED", state.get("exchange_audits_passed", -1), flush=True)
 if world > 1:
     import torch.distributed as dist
     dist.destroy_process_group()
@@ -293,6 +296,10 @@ def _ranks_vs_single_process(tmp_path, case, payload, overlap, world):
     env = {"FREUD_DP": "p2p", "FREUD_DP_PAYLOAD": payload, "FREUD_DP_OVERLAP": str(overlap), "FREUD_P2P_TIMEOUT_MS": "20000"}
     outs = _run_children(script, os.path.join(str(tmp_path), "cfg2.json"), world, env)
     assert "exchange = p2p" in outs[0][0], outs[0][0][-1000:]
+    # every step of these runs is a logging step: each one's exchanged gradient was checked against a gloo all-reduce of the
+    # ranks' own contributions (dp.Auditor), and the replicas' checksums were compared before every checkpoint
+    for so, _ in outs:
+        assert f"AUDITS_PASSED {steps}" in so, so[-500:]
     _run_children(script, os.path.join(str(tmp_path), "cfg1.json"), 1, {})
     a = torch.load(os.path.join(cfg2["run_dir"], "checkpoints", f"step{steps}.pth"), map_location="cpu")
     b = torch.load(os.path.join(cfg1["run_dir"], "checkpoints", f"step{steps}.pth"), map_location="cpu")
@@ -367,3 +374,181 @@ def test_absent_peer_times_out_instead_of_hanging(tmp_path):
     line = [l for l in outs[0][0].splitlines() if l.startswith(("ERROR_AFTER", "NO_ERROR"))][-1]
     assert line.startswith("ERROR_AFTER") and "did not arrive" in line, line
     assert time.time() - t0 < 120
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: the guards of the peer exchange must CATCH a wrong exchange
+# ------------------------------------------------------------------------------------------------------------------
+def _small_l1_config(tmp_path, steps=4, **over):
+    import json
+    import os
+    from freud_amd.loader import write_shards
+    d, n, T, n_files = 384, 1024, 64, 16
+    g = torch.Generator().manual_seed(3)
+    rows = ((torch.relu(torch.randn(n_files * T, 16, generator=g)) * 0.2) @ torch.randn(16, d, generator=g)).reshape(n_files, T * d)
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, "enc", rows.numpy(), [T, d])
+    cfg = {
+        "whisper_config": {"model": "tiny", "layer_name": "enc"}, "seed": 0, "train_folder": folder, "val_folder": folder,
+        "device": "cuda", "lr": 1e-3, "weight_decay": 0.0, "steps": steps, "clip_thresh": 1.0, "dl_max_workers": 0,
+        "log_tb_every": 2, "save_every": 2, "val_every": 1000, "scheduler_params": {}, "start_checkpoint": None, "from_disk": True,
+        "autoencoder_variant": "l1", "optimizer": "radam", "scheduler": "cosine",
+        "autoencoder_config": {"n_dict_components": n, "recon_alpha": 100.0}, "batch_size": 2,
+        "run_dir": os.path.join(str(tmp_path), "run"),
+    }
+    cfg.update(over)
+    path = os.path.join(str(tmp_path), "cfg.json")
+    json.dump(cfg, open(path, "w"))
+    return cfg, path
+
+
+def _run_cli(cfg_path, world, extra_env, timeout=600):
+    """python -m freud_amd.train_sae --config ... as `world` processes on GPU 0 (gloo host channel).  Returns [(rc, out, err)]."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), FREUD_DIST_BACKEND="gloo",
+                   RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-m", "freud_amd.train_sae", "--config", cfg_path], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for pr in procs:
+            so, se = pr.communicate(timeout=timeout)
+            res.append((pr.returncode, so, se))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return res
+
+
+def test_injected_fault_is_caught_by_the_startup_selftest(tmp_path):
+    """FREUD_P2P_FAULT=skip_phase2:1 -- rank 1 never copies one shard from its owner, i.e. it keeps what a stale read would give.
+    The start-up self-test (patterns that change between exchanges over the same addresses) must see wrong sums on rank 1:
+    FREUD_DP=p2p then refuses to start on EVERY rank, FREUD_DP=auto falls back together (host protocol over gloo here) and
+    trains."""
+    cfg, path = _small_l1_config(tmp_path)
+    env = {"FREUD_P2P_FAULT": "skip_phase2:1", "FREUD_P2P_TIMEOUT_MS": "20000"}
+    res = _run_cli(path, 2, dict(env, FREUD_DP="p2p"))
+    assert all(rc != 0 for rc, _, _ in res), [r[0] for r in res]
+    assert "self-test" in res[1][2] and "wrong values" in res[1][2], res[1][2][-2000:]
+    assert "could not be set up on every rank" in res[0][2], res[0][2][-2000:]
+    res = _run_cli(path, 2, dict(env, FREUD_DP="auto"))
+    assert all(rc == 0 for rc, _, _ in res), [r[2][-1500:] for r in res]
+    assert "exchange = host" in res[0][1], res[0][1][-500:]
+
+
+@pytest.mark.parametrize("audit", ["1", "0"])
+def test_injected_fault_after_selftest_stops_the_run_before_anything_is_written(tmp_path, audit):
+    """The same fault switched on AFTER the self-test (its 12 gradient-channel exchanges): the run starts, rank 1's first exchange
+    is wrong.  With the audit (default) the first step's sum check against the gloo all-reduce of the same inputs fails on rank
+    1 and every rank stops; without it (FREUD_DP_AUDIT=0) the replica checksums differ at the first logging step.  Either way:
+    exit code 3 on every rank, the last good checkpoint named, and NO checkpoint of the diverged run on disk."""
+    import os
+    cfg, path = _small_l1_config(tmp_path)
+    env = {"FREUD_P2P_FAULT": "skip_phase2:1:12", "FREUD_P2P_TIMEOUT_MS": "20000", "FREUD_DP": "p2p", "FREUD_DP_AUDIT": audit}
+    res = _run_cli(path, 2, env)
+    for rc, so, se in res:
+        assert rc == 3, (rc, se[-2000:])
+        assert "FATAL: data-parallel exchange failed" in se and "last good checkpoint" in se, se[-2000:]
+    assert ("differs from the gloo all-reduce" if audit == "1" else "replicas diverged") in res[0][2], res[0][2][-2000:]
+    ck = os.path.join(cfg["run_dir"], "checkpoints")
+    assert not os.path.isdir(ck) or not [f for f in os.listdir(ck) if f.endswith(".pth")], os.listdir(ck)
+
+
+_LATE_PEER_CHILD = r"""
+import os, sys, time
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["FREUD_ROOT"])
+from freud_amd.engine import SaeEngine, EngineError
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+d, n, M = 384, 1024, 512
+eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e2)
+W = torch.empty(d, n); torch.nn.init.orthogonal_(W, generator=torch.Generator().manual_seed(0))
+eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)})
+blobs = [None, None]
+dist.all_gather_object(blobs, eng.p2p_export())
+eng.p2p_init(blobs, rank, 2)
+dist.barrier()
+x = torch.randn(M, d, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+if rank == 1:
+    time.sleep(4.0)                               # far beyond rank 0's timeout: rank 0 has given up when rank 1 arrives
+eng.step(x, 1e-3)
+polled = "clean"
+torch.cuda.synchronize()
+try:
+    eng.dist_poll()
+except EngineError as e:
+    polled = "poll:" + str(e)
+try:
+    eng.dist_check()
+    print("NO_ERROR", polled, flush=True)
+except EngineError as e:
+    print("ERROR: %s | %s" % (e, polled), flush=True)
+dist.barrier()
+os._exit(0)
+"""
+
+
+def test_late_peer_is_poisoned_not_served(tmp_path):
+    """rank 0 times out waiting for rank 1 AFTER having published its own arrival flags.  When rank 1 arrives, those
+    flags must not let it through: rank 0 has overwritten them with the poison value, rank 1's polls read it, rank 1 fails too
+    (and says why), and both ranks' host-mapped failure words show it without a synchronisation."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "late.py")
+    open(script, "w").write(_LATE_PEER_CHILD)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, FREUD_ROOT=root, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FREUD_P2P_TIMEOUT_MS="500")
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        outs = [pr.communicate(timeout=180) for pr in procs]
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    lines = []
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, se[-3000:]
+        lines.append([l for l in so.splitlines() if l.startswith(("ERROR", "NO_ERROR"))][-1])
+    assert lines[0].startswith("ERROR") and "did not arrive" in lines[0], lines
+    assert lines[1].startswith("ERROR") and "left the protocol" in lines[1], lines
+    assert "poll:" in lines[0] and "poll:" in lines[1], lines
+
+
+def test_param_checksum_is_deterministic_and_sensitive():
+    """sae_param_checksum: the same state gives the same words (order-independent sum), one flipped bit changes them."""
+    from freud_amd.engine import SaeEngine
+    d, n, M = 384, 1024, 512
+    g = torch.Generator().manual_seed(0)
+    W = torch.empty(d, n)
+    torch.nn.init.orthogonal_(W, generator=g)
+    x = torch.randn(M, d, generator=g).to(torch.bfloat16).cuda()
+    sums = []
+    for flip in (False, False, True):
+        eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e2)
+        Wn = W.numpy().copy()
+        if flip:
+            Wn.view(np.uint32)[7, 11] ^= 1
+        eng.set_params({"decoder.weight": Wn, "encoder_bias": np.zeros(n, np.float32)})
+        for _ in range(2):
+            eng.step(x, 1e-3)
+        sums.append(eng.param_checksum())
+        assert eng.param_checksum() == sums[-1]
+        eng.close()
+    assert sums[0] == sums[1] and sums[0][3] == 2
+    assert sums[2][0] != sums[0][0]
+

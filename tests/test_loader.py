@@ -102,3 +102,52 @@ def test_bf16_delivery_of_fp32_shards(tmp_path):
     write_shards(folder16, "L", rows.numpy().astype(np.float16), [T, d])
     x16, _ = next(iter(MemoryMappedActivationDataLoader(folder16, "L", 2, deliver_dtype="bfloat16")))
     assert x16.dtype == torch.float16
+
+
+def test_host_converter_forms_are_bit_identical():
+    """libfreud_host.so: the AVX-512 streaming-store form (taken at run time where the CPU has it) against the portable loop --
+    every special value (NaNs of both signs, infinities, denormals, the -1.0 neighbours, round-to-even ties), unaligned
+    destinations and lengths that leave heads and tails around the 64-byte lines."""
+    import ctypes as C
+    import numpy as np
+    from freud_amd.loader import _host_lib
+    lib = _host_lib()
+    rng = np.random.default_rng(0)
+    special = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFF800001, 0x7F800000, 0xFF800000, 0x00000001, 0x80000001, 0x007FFFFF,
+                        0xBF800000, 0xBF800001, 0xBF7FFFFF, 0xBF808000, 0xBF7F8000, 0xBF807FFF, 0xBF7F8001, 0x3F808000, 0x3F818000,
+                        0x7F7FFFFF, 0xFF7FFFFF, 0x00000000, 0x80000000], dtype=np.uint32)
+    bits = np.concatenate([special, rng.integers(0, 2 ** 32, size=70001, dtype=np.uint64).astype(np.uint32),
+                           (rng.standard_normal(5000).astype(np.float32) * 3).view(np.uint32)])
+    src = bits.view(np.float32)
+    for off, n in ((0, len(src)), (1, 4097), (3, 33), (5, 31), (7, 64), (31, 1000), (0, 0)):
+        a = np.zeros(n + 64, np.uint16)
+        b = np.zeros(n + 64, np.uint16)
+        s = np.ascontiguousarray(src[:n])
+        lib.freud_f32_to_bf16(s.ctypes.data, a[off:].ctypes.data, n)
+        lib.freud_f32_to_bf16_portable(s.ctypes.data, b[off:].ctypes.data, n)
+        assert np.array_equal(a, b), (off, n, int(lib.freud_host_impl()))
+    # the -1.0 guard and NaN rule themselves
+    out = np.zeros(len(special), np.uint16)
+    lib.freud_f32_to_bf16(np.ascontiguousarray(special.view(np.float32)).ctypes.data, out.ctypes.data, len(special))
+    assert out[9] == 0xBF80 and 0xBF80 not in (out[10], out[11], out[12], out[13], out[14], out[15])
+    assert all((int(v) & 0x7F80) == 0x7F80 and (int(v) & 0x7F) != 0 for v in out[:4])      # NaNs stay NaNs
+
+
+def test_gather_pool_splits_rows_into_pieces(tmp_path):
+    """A batch of few large rows over many gather threads (dl_max_workers=12: more threads than rows): pieces of rows, every
+    element converted exactly once, same bytes as the single-thread gather."""
+    import numpy as np
+    import torch
+    from freud_amd.loader import MemoryMappedActivationDataLoader, write_shards
+    T, d, n_files = 37, 24, 6
+    rows = (torch.randn(n_files, T * d, generator=torch.Generator().manual_seed(2)) * 2).numpy().astype(np.float32)
+    folder = str(tmp_path / "f32")
+    write_shards(folder, "L", rows, [T, d])
+    got = {}
+    for workers in (1, 12):
+        torch.manual_seed(3)
+        dl = MemoryMappedActivationDataLoader(folder, "L", 3, workers, None, {"shuffle": True, "drop_last": True}, deliver_dtype="bfloat16")
+        got[workers] = [x.clone() for x, _ in dl]
+    assert len(got[1]) == 2
+    for a, b in zip(got[1], got[12]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
