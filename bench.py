@@ -169,6 +169,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = world > 1 or args.force_dist
+    if world > 1:
+        os.environ.setdefault("FREUD_P2P_FINEGRAINED", "1")      # (freud_amd/train_sae.py: peer-read buffers in fine-grained memory)
     if use_dist:
         import torch.distributed as dist
         # RCCL writes its NCCL_DEBUG output (version banner, warnings) to STDOUT: send it to a file instead so that

@@ -59,6 +59,15 @@ struct BwdFusedArgs {
   int tile0;           // first column tile of the launch (column-range launches; 0 otherwise)
   int splits;
   int steps_total;     // M_p / 32
+  // Balanced form (round 4; bal_m > 0): the work is cut into QUANTA -- (column tile, 1/32 of the rows) -- linearised tile-major,
+  // and workgroup k takes quanta [k bal_m, (k + 1) bal_m): every CU gets the same number of rows whatever ntiles is (24 tiles
+  // x 10 row ranges left 16 of 256 CUs idle at C2), at the price of workgroups that finish one tile's rows and go on with the
+  // next tile's (a "segment" each: own W^T fragments, own slab piece).  A quantum is bal_q steps (ceil(steps_total / 32)), so
+  // workgroups start at only 32 / gcd(bal_m, 32) distinct row phases and those of equal phase walk the same dx_hat / x rows in
+  // lockstep; wg_map places them on one XCD.  Tile j's rows arrive as pieces k - (32 j) / bal_m of the workgroups k that touch
+  // it: slab / db_part are indexed [piece][...] and reduce_grads_kernel adds bal_pieces(j, bal_m) of them.
+  int bal_m, bal_q;
+  const short* wg_map; // blockIdx.x -> k (null: identity)
   unsigned long long* clk;   // diagnostic (bench.py --dbg 66), normally null: [wg][4] = s_memtime / s_memrealtime around the loop
 };
 
@@ -93,15 +102,17 @@ constexpr int BF_DMA_A = BF_DMA_A_, BF_DMA_B = BF_DMA_B_;
 __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int nblk = a.ntiles * a.splits;
-  const int id = xcd_remap(blockIdx.x, nblk);
-  const int split = id / a.ntiles, ntile = a.tile0 + id - split * a.ntiles;
-  const int step_begin = (int)((int64_t)a.steps_total * split / a.splits);
-  const int step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
+  // the workgroup's segments: one (column tile, step range, slab piece) in the uniform form; in the balanced form one per column
+  // tile its quanta touch (usually one, two for the workgroups that straddle a tile boundary)
+  int qa = 0, qe = 1, wgk = 0;
+  if (a.bal_m > 0) {
+    wgk = __builtin_amdgcn_readfirstlane(a.wg_map ? (int)a.wg_map[blockIdx.x] : (int)blockIdx.x);
+    qa = wgk * a.bal_m;
+    qe = qa + a.bal_m < 32 * a.ntiles ? qa + a.bal_m : 32 * a.ntiles;
+  }
   unsigned long long clk_k0 = 0;
   if (a.clk) clk_k0 = __builtin_amdgcn_s_memtime();
-  const int n0 = ntile * BF_BN;           // first dictionary column of the workgroup
-  const int nw = n0 + 32 * w;             // first column of this wave
+  int n0 = 0, nw = 0;                     // first dictionary column of the workgroup / of this wave (per segment)
   // With an unscaled dx_hat everything is computed in units of 1/scale: dpre' = dc' + (1/M)/scale, and the
   // epilogue multiplies the dW slab and db by scale = alpha/count.
   float scal1, scal2;
@@ -122,21 +133,6 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   }
   const float scale = a.unscaled ? scal1 : 1.0f;
   const float inv_m = a.unscaled ? scal2 / scal1 : scal2;
-
-  // W^T fragments of this wave: B[k = d][col = n] -> lane (n = lane & 31, h) holds Wt[nw + n][16 kk + 8 h ..+8]
-  bf16x8 wfrag[24];
-  {
-    const bf16_t* wp = a.Wt + (int64_t)(nw + (lane & 31)) * BF_D + 8 * (lane >> 5);
-#pragma unroll
-    for (int kk = 0; kk < 24; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wp + 16 * kk);
-  }
-
-  f32x16 acc[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  float db_acc = 0.f;
 
   // ---- staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land contiguously at a wave-uniform LDS
   // address).  One instruction fills 4 rows x 256 B of a [32][256 B] sub-tile image; the dual-use swizzle is
@@ -176,17 +172,6 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       glds16_x2_nt(gc, gc, voff_c[0], voff_c[1], buf + loff_c[0], buf + loff_c[1]);
     }
   };
-
-  if (step_begin < step_end) {
-#pragma unroll
-    for (int p = 0; p < 7; ++p) dma_pair(p, (int64_t)step_begin * BF_BM, 0);
-  }
-  // make hipcc retire the W^T fragment loads HERE: otherwise it places its vmcnt waits for them inside the loop,
-  // where they would also wait for the (untracked) LDS-DMA of the next step and serialise copy and compute
-#pragma unroll
-  for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(wfrag[kk]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   // ---- loop-invariant per-lane LDS read offsets (everything else folds into instruction immediates)
   //   row read of chunk 2*(kk&7)+h of row (lane&31):         roff[kk & 7]
@@ -247,13 +232,66 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) cinit[r] = inv_m;
 
+  unsigned long long clk_t0 = 0, clk_r0 = 0, clk_loop = 0, clk_real = 0, clk_steps = 0;
+#pragma unroll 1
+  for (bool first_seg = true; qa < qe; first_seg = false) {
+  // ---- this segment: column tile, step range, slab piece
+  bf16x8 wfrag[24];
+  f32x16 acc[12];
+  float db_acc = 0.f;
   bf16x8 ring[RING], cf[2], pf[2];
+  int ntile, step_begin, step_end, split;
+  if (a.bal_m > 0) {
+    const int j = qa >> 5, qb = qe < 32 * (j + 1) ? qe : 32 * (j + 1);
+    ntile = a.tile0 + j;
+    step_begin = (qa - 32 * j) * a.bal_q;
+    step_end = (qb - 32 * j) * a.bal_q;
+    if (step_begin > a.steps_total) step_begin = a.steps_total;
+    if (step_end > a.steps_total) step_end = a.steps_total;
+    split = wgk - bal_first_wg(j, a.bal_m);
+    qa = qb;
+  } else {
+    const int nblk = a.ntiles * a.splits;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    split = id / a.ntiles;
+    ntile = a.tile0 + id - split * a.ntiles;
+    step_begin = (int)((int64_t)a.steps_total * split / a.splits);
+    step_end = (int)((int64_t)a.steps_total * (split + 1) / a.splits);
+    qa = qe;
+  }
+  ntile = __builtin_amdgcn_readfirstlane(ntile); step_begin = __builtin_amdgcn_readfirstlane(step_begin);
+  step_end = __builtin_amdgcn_readfirstlane(step_end); split = __builtin_amdgcn_readfirstlane(split);
+  n0 = ntile * BF_BN;
+  nw = n0 + 32 * w;
+  if (!first_seg) {      // the previous segment's last (redundant) DMA pieces have landed and every wave has left its loop
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // W^T fragments of this wave: B[k = d][col = n] -> lane (n = lane & 31, h) holds Wt[nw + n][16 kk + 8 h ..+8]
+  {
+    const bf16_t* wp = a.Wt + (int64_t)(nw + (lane & 31)) * BF_D + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wp + 16 * kk);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  db_acc = 0.f;
+  if (step_begin < step_end) {
+#pragma unroll
+    for (int p = 0; p < 7; ++p) dma_pair(p, (int64_t)step_begin * BF_BM, 0);
+  }
+  // make hipcc retire the W^T fragment loads HERE: otherwise it places its vmcnt waits for them inside the loop,
+  // where they would also wait for the (untracked) LDS-DMA of the next step and serialise copy and compute
+#pragma unroll
+  for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(wfrag[kk]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i <= DIST; ++i) ring[i] = load_frag(smem, i);     // includes gap 0 of the first step
   cf[0] = tr_pair(smem + 2 * BF_DXH_BYTES + coff0, smem + 2 * BF_DXH_BYTES + coff1);
   cf[1] = tr_pair(smem + 2 * BF_DXH_BYTES + 4096 + coff0, smem + 2 * BF_DXH_BYTES + 4096 + coff1);
-
-  unsigned long long clk_t0 = 0, clk_r0 = 0;
   if (a.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
@@ -300,26 +338,32 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     cur ^= 1;
   }
   if (a.clk) {
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) {
-      unsigned long long* o = a.clk + (int64_t)blockIdx.x * 4;
-      o[0] = t1 - clk_t0; o[1] = r1 - clk_r0; o[2] = (unsigned long long)(step_end - step_begin); o[3] = clk_t0 - clk_k0;
-    }
+    clk_loop += __builtin_amdgcn_s_memtime() - clk_t0;
+    clk_real += __builtin_amdgcn_s_memrealtime() - clk_r0;
+    clk_steps += (unsigned long long)(step_end - step_begin);
   }
 
   // ---- epilogue: dW slab of this row range (rows d = 32 dt + (r&3) + 8 (r>>2) + 4 h, column nw + lane&31)
   {
-    float* out = a.slab + (int64_t)split * BF_D * a.n_p + nw + (lane & 31);
+    float* out = a.slab + (int64_t)split * BF_D * a.n_p;
     const int h = lane >> 5;
+    const unsigned off0 = (unsigned)(nw + (lane & 31)) + (unsigned)(4 * h) * (unsigned)a.n_p;
 #pragma unroll
-    for (int dt = 0; dt < 12; ++dt)
+    for (int dt = 0; dt < 12; ++dt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int drow = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        out[(int64_t)drow * a.n_p] = acc[dt][r] * scale;
+        const unsigned drow = 32 * dt + (r & 3) + 8 * (r >> 2);
+        out[off0 + drow * (unsigned)a.n_p] = acc[dt][r] * scale;
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     db_acc += __shfl_xor(db_acc, 32, 64);
     if (lane < 32) a.db_part[(int64_t)split * a.n_p + nw + lane] = db_acc * scale;
+  }
+  }   // segments
+  if (a.clk && threadIdx.x == 0) {
+    unsigned long long* o = a.clk + (int64_t)blockIdx.x * 4;
+    o[0] = clk_loop; o[1] = clk_real; o[2] = clk_steps; o[3] = 0;
   }
   if (a.clk && threadIdx.x == 0) {   // whole-kernel cycles of this workgroup in the upper half of the stamp buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

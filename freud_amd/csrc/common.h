@@ -117,3 +117,9 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
 }
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// Balanced form of the fused d = 384 backward (bwd_fused.h): workgroup k takes quanta [k m, (k + 1) m) of the tile-major list of
+// (column tile, 1/32 of the rows) quanta.  The pieces of column tile j = the workgroups whose quanta meet [32 j, 32 j + 32).
+__host__ __device__ __forceinline__ int bal_first_wg(int j, int m) { return (32 * j) / m; }
+__host__ __device__ __forceinline__ int bal_pieces(int j, int m) { return (32 * j + 31) / m - (32 * j) / m + 1; }
+

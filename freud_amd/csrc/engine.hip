@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -248,6 +249,9 @@ struct sae_ctx {
   // stall, a validation pass or a checkpoint write; a failed context fails fast afterwards (sticky status, poisoned flags)
   unsigned long long p2p_timeout_ticks = 12000000000ull;
   bool gn_from_exchange = false;                 // gn_part holds the sum of squares of the EXCHANGED gradient
+  int bal_m = 0;                // balanced fused backward (bwd_fused.h): quanta per workgroup (0 = uniform row ranges), workgroups,
+  int bal_grid = 0;             //   and the blockIdx -> workgroup table (XCD-aware)
+  short* bal_map = nullptr;
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
   int64_t step = 0;
@@ -498,6 +502,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
   if (c->p2p_status) (void)hipFree(c->p2p_status);
   if (c->p2p_status_host) (void)hipHostFree(c->p2p_status_host);
   if (c->col_stage) (void)hipFree(c->col_stage);
+  if (c->bal_map) (void)hipFree(c->bal_map);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
@@ -605,6 +610,43 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
       if (sp > c->bwd_range_splits) c->bwd_range_splits = sp;
     }
   int slab_splits = c->use_fused_bwd ? (c->bwd_range_splits > c->dw_splits ? c->bwd_range_splits : c->dw_splits) : c->dw_splits;
+  if (c->use_fused_bwd && c->cfg.debug_flags != 83 && !getenv("FREUD_BWD_UNIFORM")) {     // (both: A/B switches for the uniform row ranges)
+    // balanced form: 32 quanta per column tile, m per workgroup so that at most one workgroup per CU is needed
+    const int ntiles = c->n_p / BF_BN, cus = 256;
+    const int m = (32 * ntiles + cus - 1) / cus, grid = (32 * ntiles + m - 1) / m;
+    int pmax = 1;
+    for (int j = 0; j < ntiles; ++j) pmax = bal_pieces(j, m) > pmax ? bal_pieces(j, m) : pmax;
+    // cost in 32-row steps at the largest batch, as in fused_bwd_splits: rows per workgroup + prologue / epilogue (+ one more of
+    // each for a workgroup that changes tiles) + the slab pieces written and read back
+    const int steps = (int)(Mp / BF_BM), q = (steps + 31) / 32;
+    const double slab_steps = (double)c->n_p * BF_D * 8.0 / 4.0e12 / 1.43e-6;
+    const double cost_bal = (double)m * q + 5.0 + (32 % m ? 3.5 : 0.0) + (32.0 / m + (32 % m ? 1.0 : 0.0)) * slab_steps;
+    const int sp = c->bwd_splits, rounds = (ntiles * sp + 255) / 256;
+    const double cost_uni = rounds * ((double)((steps + sp - 1) / sp) + 5.0) + sp * slab_steps;
+    if (cost_bal < cost_uni * 0.995 && pmax <= 64 && grid <= 4096) {
+      c->bal_m = m;
+      c->bal_grid = grid;
+      if (pmax > slab_splits) slab_splits = pmax;
+      // blockIdx -> workgroup: workgroups of equal start phase (k m mod 32) walk the same rows at the same time; sorted by phase
+      // and dealt to the XCDs in contiguous runs (blocks b and b + 8 share an XCD), an XCD streams as few row ranges as possible
+      std::vector<int> order(grid);
+      for (int k = 0; k < grid; ++k) order[k] = k;
+      std::stable_sort(order.begin(), order.end(), [m](int a_, int b_) { return (a_ * m) % 32 < (b_ * m) % 32; });
+      std::vector<short> map(grid);
+      int pos = 0;
+      for (int x = 0; x < 8; ++x) {
+        const int len = grid / 8 + (x < grid % 8 ? 1 : 0);
+        for (int i = 0; i < len; ++i) map[8 * i + x] = (short)order[pos++];
+      }
+      hipError_t e_ = hipMalloc((void**)&c->bal_map, (size_t)grid * 2);
+      if (e_ == hipSuccess) e_ = hipMemcpy(c->bal_map, map.data(), (size_t)grid * 2, hipMemcpyHostToDevice);
+      if (e_ != hipSuccess) {
+        int rc_ = fail(SAE_ERR_HIP, "balanced backward: workgroup table: %s", hipGetErrorString(e_));
+        sae_destroy(c);
+        return rc_;
+      }
+    }
+  }
   {   // a chunk launch writes splits x (chunk rows x n_p) floats at the chunk's row offset of each slab
     const int64_t need = (int64_t)(c->dw_chunk_splits > c->dw_col_splits ? c->dw_chunk_splits : c->dw_col_splits);
     if (need > slab_splits) slab_splits = (int)need;
@@ -1605,6 +1647,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     GemmArgs g{};
     g.A0 = c->c; g.B0 = c->Wb; g.lda = n_p; g.ldb = n_p;
     g.nbm = (int)(Mp / 128); g.nbn = d_p / 128; g.ktiles0 = g.ktiles = n_p / 64; g.splits = 1;
+    g.group_m = 4;       // (gemm.h: GemmArgs::group_m)
     EpiDec<T> e{};
     e.x = x; e.dxh = c->dxh; e.scal = c->scal; e.sq_part = c->sq_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = g.nbn;
     ev_begin(c, KID_DEC_FWD, s);
@@ -1663,13 +1706,19 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       if (splits > a.steps_total) splits = a.steps_total;
       a.ntiles = rtiles; a.splits = splits;
       db_rows = splits;
+      const bool balanced = nranges == 1 && c->bal_m > 0 && a.steps_total >= 64;
+      if (balanced) {
+        a.bal_m = c->bal_m;
+        a.bal_q = (a.steps_total + 31) / 32;
+        a.wg_map = c->bal_map;
+      }
       const bool dp_now = c->dist && c->dp_world > 0;
       bf16_t* gb = (dp_now && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr;
       ev_begin(c, KID_BWD_FUSED, s);
       LDS_ATTR(bwd_fused_d384_kernel, BF_LDS_BYTES, g_device);
       for (int r = 0; r < nranges; ++r) {
         a.tile0 = r * rtiles;
-        hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(bwd_fused_d384_kernel, dim3(balanced ? c->bal_grid : a.ntiles * a.splits), dim3(256), BF_LDS_BYTES, s, a);
         if (nranges > 1) {
           const int c0 = a.tile0 * BF_BN, cols = rtiles * BF_BN;
           hipLaunchKernelGGL(reduce_grads_range_kernel, dim3(256), dim3(256), 0, s, c->slab, c->nW, splits, c->db_part, db_rows, n_p,
@@ -1808,7 +1857,8 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       hipLaunchKernelGGL(reduce_grads_kernel, dim3(blocks), dim3(256), 0, s, c->slab, nW4, splits, c->db_part, db_rows, n_p,
                          c->G, nW4, n4, c->gn_part,
-                         (c->dist && c->dp_world > 0 && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr, fin);
+                         (c->dist && c->dp_world > 0 && c->payload == SAE_DTYPE_BF16) ? c->Gb : (bf16_t*)nullptr, fin,
+                         (c->bwd_ranges == 1 && c->bal_m > 0 && (int)(Mp / BF_BM) >= 64) ? c->bal_m : 0);
       c->gn_blocks = blocks;
       c->gn_valid = true;
     } else {

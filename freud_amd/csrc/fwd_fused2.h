@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   // rows (for its d-slice), so the whole [128 x 384] x block is staged in the (now idle) rings, transformed in place into
   // dx_hat by the four waves, and leaves as coalesced 16-byte stores.
   float sq = 0.f, plain = 0.f, nmask = 0.f;
+  float msq = 0.f;               // lean epilogue: squared error of the MASKED entries (masked MSE numerator = plain - msq)
   typedef __attribute__((ext_vector_type(4))) T Tx4;
   const bool vec_ok = (a.d == FF_D) && ((reinterpret_cast<uintptr_t>(a.x) & (sizeof(T) * 4 - 1)) == 0);
   constexpr int FF_DXH_PITCH = FF_D * 2 + 16;                    // 784 B
@@ -377,6 +378,43 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           xv[k] = X_VIA_LDS ? *reinterpret_cast<const Tx4*>(srow + (dbase + 8 * k) * 2) : *reinterpret_cast<const Tx4*>(xrow + dbase + 8 * k);
+#ifndef FF2_EPI_V1
+        if (!PAD) {
+          // Round 4: the lean form.  Masked entries (x == -1.0 exactly) are rare, so the 16 elements are first run WITHOUT the
+          // mask -- e = bf16(x_hat) - x, plain += e e (one fma), dx_hat = bf16(2 e) -- and the wave looks once (a ballot) whether
+          // any lane met a -1.0; only then the masked elements are taken out again.  Per element 7 vector instructions instead
+          // of 13 (keep / rmask selects, the count and the second squared-error sum are gone from the common path); with no
+          // masked entry the sums are the same additions in the same order, with some they differ by fp32 round-off
+          // (-DFF2_EPI_V1 = round 3's form).
+          bool any_m = false;
+          bf16x4 o[4];
+          float e[16];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float xf = (float)xv[k][q];
+              e[4 * k + q] = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
+              plain = __builtin_fmaf(e[4 * k + q], e[4 * k + q], plain);
+              any_m |= (xf == -1.0f);
+              o[k][q] = (bf16_t)(e[4 * k + q] + e[4 * k + q]);
+            }
+          if (__builtin_amdgcn_ballot_w64(any_m) != 0ull) {        // wave-uniform, almost never taken
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if ((float)xv[k][q] == -1.0f) {
+                  nmask += 1.0f;
+                  msq = __builtin_fmaf(e[4 * k + q], e[4 * k + q], msq);
+                  o[k][q] = (bf16_t)0.0f;
+                }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(srow + (dbase + 8 * k) * 2) = o[k];
+          continue;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           bf16x4 o;
@@ -427,6 +465,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
   const float l1s = block_sum_256(l1_acc, red);
+#ifndef FF2_EPI_V1
+  if (!PAD && vec_ok) sq = plain - msq;          // (vec_ok is block-uniform)
+#endif
   const float sqs = block_sum_256(sq, red + 8);
   const float pls = block_sum_256(plain, red + 16);
   const float nms = block_sum_256(nmask, red + 24);

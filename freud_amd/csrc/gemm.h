@@ -50,6 +50,8 @@ struct GemmArgs {
   // round costs 1 / tail_pieces of a tile's time instead of a whole one.  The functor sees slab id 0 for the other tiles and
   // 1 + piece * tail_tiles + (index of the tail tile) for the pieces; grid = nbm * nbn - tail_tiles + tail_tiles * tail_pieces.
   int tail_tiles, tail_pieces;
+  int group_m;           // tile-walk patch height (tile_coords); 0 = GEMM_GROUP_M.  The long-K decoder takes 4 (round 4, same-box A/B
+                         // at C4: 4.63-4.68 against 4.80-4.91 ms with 8, the other GEMMs within noise -- profiles/r04_ab_group_m_c4.txt)
 };
 
 // The plan for `tiles` 256x256 output tiles of `ktiles` K tiles on 256 CUs: tail tiles and pieces (0, 0: the tile count fills
@@ -119,12 +121,12 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 #define GEMM_GROUP_M_ 8      // tools/build_variant.sh can sweep it (4 x 8 / 8 x 4 / 16 x 2 patches per XCD)
 #endif
 constexpr int GEMM_GROUP_M = GEMM_GROUP_M_;
-__device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& bm, int& bn) {
-  const int per_group = GEMM_GROUP_M * nbn;
+__device__ __forceinline__ void tile_coords(int id, int nbm, int nbn, int& bm, int& bn, int group_m = GEMM_GROUP_M) {
+  const int per_group = group_m * nbn;
   const int grp = id / per_group, r = id - grp * per_group;
-  const int rows = nbm - grp * GEMM_GROUP_M < GEMM_GROUP_M ? nbm - grp * GEMM_GROUP_M : GEMM_GROUP_M;
+  const int rows = nbm - grp * group_m < group_m ? nbm - grp * group_m : group_m;
   bn = r / rows;
-  bm = grp * GEMM_GROUP_M + (r - bn * rows);
+  bm = grp * group_m + (r - bn * rows);
 }
 
 template <int MODE>
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, Epi epi) 
   const int split = id / (nbm * nbn);
   id -= split * (nbm * nbn);
   int bm, bn;
-  tile_coords(id, nbm, nbn, bm, bn);
+  tile_coords(id, nbm, nbn, bm, bn, g.group_m > 0 ? g.group_m : GEMM_GROUP_M);
   const int kt_begin = (int)((int64_t)ktiles * split / splits);
   const int kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
 

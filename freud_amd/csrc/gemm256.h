@@ -212,7 +212,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     kt_end = (int)((int64_t)ktiles * (split + 1) / splits);
   }
   int bm, bn;
-  tile_coords(id, nbm, nbn, bm, bn);
+  tile_coords(id, nbm, nbn, bm, bn, g.group_m > 0 ? g.group_m : GEMM_GROUP_M);
 
 #ifdef G2X_PHASE
   // experiment: half of the FIRST round's workgroups start late by G2X_PHASE x 8128 cycles, so that the CUs' epilogue bursts

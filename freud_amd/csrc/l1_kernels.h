@@ -409,21 +409,26 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restri
                                                             const float* __restrict__ db_part, int db_rows, int n_p,
                                                             float* __restrict__ grad, int64_t nW4, int64_t n4,
                                                             double* __restrict__ gn_part, bf16_t* __restrict__ grad_bf16,
-                                                            LossFinalize fin) {
+                                                            LossFinalize fin, int bal_m) {
+  // bal_m > 0 (balanced fused backward, bwd_fused.h): column tile j of 128 arrives in bal_pieces(j, bal_m) pieces instead of
+  // `splits` / `db_rows` everywhere; pieces are added in piece order (deterministic)
   __shared__ double red[4];
   if (fin.cnt_part && blockIdx.x == gridDim.x - 1) finalize_losses_block256(fin);
   double ss = 0;
+  const int n4p = n_p / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 a;
     if (i < nW4) {
       const f32x4* s = reinterpret_cast<const f32x4*>(slab);
       a = s[i];
-      for (int k = 1; k < splits; ++k) a += s[i + k * stride4];
+      const int cnt = bal_m > 0 ? bal_pieces((int)(i % n4p) >> 5, bal_m) : splits;
+      for (int k = 1; k < cnt; ++k) a += s[i + k * stride4];
     } else {
       const int64_t j4 = i - nW4;
       const f32x4* s = reinterpret_cast<const f32x4*>(db_part);
       a = s[j4];
-      for (int k = 1; k < db_rows; ++k) a += s[j4 + (int64_t)k * (n_p / 4)];
+      const int cnt = bal_m > 0 ? bal_pieces((int)j4 >> 5, bal_m) : db_rows;
+      for (int k = 1; k < cnt; ++k) a += s[j4 + (int64_t)k * n4p];
     }
     reinterpret_cast<f32x4*>(grad)[i] = a;
     if (grad_bf16) reinterpret_cast<bf16x4*>(grad_bf16)[i] = bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};

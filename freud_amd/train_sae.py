@@ -293,6 +293,12 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         torch.cuda.set_device(device)
         engine_factory = _default_engine_factory
     dist = None
+    if world > 1:
+        # the buffers the peers of the in-engine exchange read (gradient, its bf16 copy, statistics) in FINE-GRAINED device
+        # memory: a peer then never holds their lines non-coherently in its L2, so the exchange does not depend on cache
+        # maintenance for correctness (it keeps its fences all the same).  Free on one GPU (C2 and C4 measured,
+        # profiles/r04_ab_finegrained_*.txt); read by sae_create, hence set before the engine exists.
+        os.environ.setdefault("FREUD_P2P_FINEGRAINED", "1")
     if use_dist:
         import torch.distributed as dist
         if not dist.is_initialized():

@@ -255,7 +255,13 @@ def test_four_processes_one_gpu_train_like_one_process(tmp_path):
     _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=4)
 
 
-def _ranks_vs_single_process(tmp_path, case, payload, overlap, world):
+def test_two_processes_coarse_grained_buffers(tmp_path):
+    """Multi-rank runs put the peer-read buffers in fine-grained memory by default (train_sae.py); FREUD_P2P_FINEGRAINED=0 keeps
+    them coarse-grained -- the form whose cross-device visibility rests on the fences alone -- and must train the same."""
+    _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=2, extra_env={"FREUD_P2P_FINEGRAINED": "0"})
+
+
+def _ranks_vs_single_process(tmp_path, case, payload, overlap, world, extra_env=None):
     """R x B == 1 x RB on REAL kernels with the REAL exchange: two freshly spawned processes (ranks 0 and 1, both on GPU 0)
     run train() with the in-engine protocol over hipIpc peer mappings -- handles through a gloo group, batch statistics
     summed before the backward, every gradient range summed by the engine's exchange kernels, self-test at start-up -- and
@@ -294,6 +300,7 @@ def _ranks_vs_single_process(tmp_path, case, payload, overlap, world):
     for name, cfg in (("cfg2.json", cfg2), ("cfg1.json", cfg1)):
         json.dump(cfg, open(os.path.join(str(tmp_path), name), "w"))
     env = {"FREUD_DP": "p2p", "FREUD_DP_PAYLOAD": payload, "FREUD_DP_OVERLAP": str(overlap), "FREUD_P2P_TIMEOUT_MS": "20000"}
+    env.update(extra_env or {})
     outs = _run_children(script, os.path.join(str(tmp_path), "cfg2.json"), world, env)
     assert "exchange = p2p" in outs[0][0], outs[0][0][-1000:]
     # every step of these runs is a logging step: each one's exchanged gradient was checked against a gloo all-reduce of the

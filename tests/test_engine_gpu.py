@@ -312,6 +312,64 @@ def test_full_size_properties():
     eng.close()
 
 
+def test_c4_full_size_properties():
+    """BASELINE configs[3] at its REAL shape on one GPU (d=1280, n=40 960, M=65 536 rows -- VERDICT r3: the one hot shape that
+    had no asserted property at size; the oracle case of this shape is M = 512, where the weight-gradient GEMM's K loop is two
+    tiles long instead of 2048).  Size-independent properties: (i) a batch whose second half is entirely -1.0 has the unmasked
+    count and masked MSE of the first half alone; (ii) the loss goes down on a learnable batch; (iii) two runs are BITWISE
+    equal (tail-split weight gradient, k-half ring, persistent K = d GEMMs: nothing may depend on timing); (iv) the tail-split
+    weight gradient (whole tiles straight into the gradient + 32 x 8 K pieces) equals the uniform split-K form (debug_flags 81)
+    to summation order (5e-5: K = 131 072 fp32 additions in two different orders)."""
+    d, n, M = 1280, 40960, 65536
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(d, n, generator=g)
+    W /= W.norm(dim=0, keepdim=True)
+    x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
+    params = {"decoder.weight": W.numpy(), "encoder_bias": np.zeros(n, np.float32)}
+
+    def run(steps, **kw):
+        eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e4, **kw)
+        eng.set_params(params)
+        losses = []
+        for _ in range(steps):
+            eng.step(x, 1e-4)
+            m = eng.metrics()
+            losses.append(float(m[0] + m[1]))
+        return eng, losses
+
+    eng, _ = run(0)
+    eng.eval(x)
+    full = eng.metrics().copy()
+    x2 = x.clone()
+    x2[M // 2:] = -1.0
+    eng.eval(x2)
+    half = eng.metrics().copy()
+    eng.eval(x[: M // 2].contiguous())
+    first = eng.metrics().copy()
+    del x2
+    assert half[4] == pytest.approx(first[4], rel=1e-6)
+    assert half[0] == pytest.approx(first[0], rel=1e-4)
+    assert full[4] == pytest.approx(float((x != -1.0).sum().item()), rel=1e-6)
+    eng.forward_backward(x)                                   # raw gradient of step 1, tail-split form
+    torch.cuda.synchronize()
+    g_tail = eng.grad_tensor()[: d * n].clone()
+    eng.close()
+    outs = []
+    for _ in range(2):
+        eng, losses = run(4)
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+        outs.append(eng.get_params()["decoder.weight"].copy())
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+    eng, _ = run(0, debug_flags=81)                           # uniform split-K through slabs
+    eng.forward_backward(x)
+    torch.cuda.synchronize()
+    g_uni = eng.grad_tensor()[: d * n]
+    rel = float((g_tail - g_uni).norm() / g_uni.norm())
+    eng.close()
+    assert rel < 5e-5, rel       # K = 2 M = 131 072 products per element, fp32 accumulators, two summation orders (measured 1.0e-5)
+
+
 def test_alternative_launch_forms_are_bitwise_identical(monkeypatch):
     """Round 3 changed HOW the fused d = 384 step is launched, not what it computes: the second forward decomposition
     (fwd_fused2.h; FREUD_FWD=1 selects the first), the loss finalisation folded into reduce_grads (debug_flags 78 = own kernel),
