@@ -442,11 +442,20 @@ def main():
               (np.median(st[:, 6]), np.median(st[:, 4]), np.median(st[:, 7] - st[:, 6] - st[:, 4]), np.median(st[:, 7])),
               file=sys.stderr)
     if args.dbg == 66 and rank == 0:     # clock stamps of the fused backward
-        nt = n // 128 + (1 if n % 128 else 0)
-        st = eng.debug_read(6, nt * 80).reshape(-1, 4)[: nt * 10]      # [workgroup][4] loop stamps (second half: whole-kernel cycles)
-        st = st[st[:, 2] > 0]
-        print("bwd in-kernel clock %.0f MHz (median), loop cycles/step %.0f (ideal 72 MFMA x 32 = 2304)" %
-              (np.median(st[:, 0] / st[:, 1]) * 100.0, np.median(st[:, 0] / st[:, 2])), file=sys.stderr)
+        full = None
+        for grid in ((n // 128 + (1 if n % 128 else 0)) * 10, 256):      # uniform at C2: 24 x 10 (too small a buffer for the balanced form: refused); balanced: 256
+            try:
+                full = eng.debug_read(6, grid * 8).reshape(2, grid, 4)
+                break
+            except Exception:
+                continue
+        st, whole = full[0], full[1][:, 0]
+        ok = st[:, 2] > 0
+        st, whole = st[ok], whole[ok]
+        print("bwd in-kernel clock %.0f MHz (median), loop cycles/step %.0f (ideal 72 MFMA x 32 = 2304); %d workgroups, steps per "
+              "workgroup %.0f-%.0f, whole-kernel cycles per workgroup: median %.0f, max %.0f, outside the loop (median) %.0f" %
+              (np.median(st[:, 0] / st[:, 1]) * 100.0, np.median(st[:, 0] / st[:, 2]), len(st), st[:, 2].min(), st[:, 2].max(),
+               np.median(whole), whole.max(), np.median(whole - st[:, 0])), file=sys.stderr)
     if args.variant == "topk":
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "

@@ -2508,7 +2508,9 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     return SAE_OK;
   }
   if (which == 6) {   // clock stamps of the fused backward (debug_flags == 66): [wg][4] as floats
-    const int64_t nq = (int64_t)(c->n_p / 128) * 10 * 4 * 2;   // [0]: loop stamps per workgroup, [1]: whole-kernel cycles
+    // [0 .. grid): loop stamps per workgroup {loop cycles, loop time in 10 ns ticks, steps, 0}; [grid .. 2 grid): whole-kernel cycles
+    const int64_t grid = (c->bal_m > 0 && c->bwd_ranges == 1) ? c->bal_grid : (int64_t)(c->n_p / 128) * c->bwd_splits;
+    const int64_t nq = grid * 4 * 2;
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");
     std::vector<unsigned long long> tmp((size_t)nq);
     HIP_TRY(hipMemcpy(tmp.data(), reinterpret_cast<unsigned long long*>(c->dpre) + (1 << 16), tmp.size() * 8, hipMemcpyDeviceToHost));

@@ -413,11 +413,16 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   // ---- load + candidate filter.  keys[v][q] packs columns 8 g + 2 q (low half) and 8 g + 2 q + 1 (high half)
   u32x4 keys[MAXV];
   unsigned cand[MAXV];                             // 8 candidate bits per vector
-  unsigned cbits[MAXV];
-  if (COMPACT) {                                       // the dead bits of each vector's 8 columns, one byte (dead implies col < n)
+  // the dead bits of each vector's 8 columns, one byte (dead implies col < n).  MAXV <= 12: fetched up front, so that the row's
+  // loads do not wait for them one by one; larger rows read them in the load loop -- a third per-vector array on top of keys and
+  // cand (264 dwords at MAXV = 44) made hipcc leave all three on the stack (1072 bytes of scratch per lane)
+  constexpr bool CBITS_AHEAD = COMPACT && MAXV <= 12;
+  unsigned cbits[CBITS_AHEAD ? MAXV : 1];
+  if (CBITS_AHEAD) {
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) cbits[v] = (v * 256 + t < nvec) ? (unsigned)vec_bits[v * 256 + t] : 0u;
   }
+  auto cbits_of = [&](int v, int g) -> unsigned { return CBITS_AHEAD ? cbits[CBITS_AHEAD ? v : 0] : (g < nvec ? (unsigned)vec_bits[g] : 0u); };
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int g = v * 256 + t;
@@ -426,12 +431,13 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     if (g < nvec) {
       // read exactly once (3.2 GB at C3): keep it out of the caches' way.  COMPACT: vectors without a dead column are not
       // read at all (with few dead latents that is most of the row)
-      if (!COMPACT || cbits[v] != 0u) w = __builtin_nontemporal_load(src + g);
+      const unsigned cbv = COMPACT ? cbits_of(v, g) : 0u;
+      if (!COMPACT || cbv != 0u) w = __builtin_nontemporal_load(src + g);
       if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
         cb = 0xFFu;
       } else {
         if (COMPACT) {
-          cb = cbits[v];
+          cb = cbv;
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -570,6 +576,62 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
             mine[u] = cand_pk[sg * TOPK_SEG_CAP + li];
           }
         }
+#ifndef SEL_BINSEARCH
+        // Round 4: the k-th largest candidate by ONE histogram instead of a binary search over the 32-bit word (up to 32 probes,
+        // a block barrier each: the search was the larger part of this kernel at k_aux = 384, C ~ 450-600).  Candidates are
+        // >= L, and bf16 keys within two octaves of L differ from it by < 256: bin = min(255, key - L), an LDS add per
+        // candidate, a suffix scan over the 256 bins (one block scan) finds the bin B that holds the k-th largest and how many of
+        // its members are needed.  Bins above B are selected whole; bin B is ONE key value (unless it is the overflow bin), so its
+        // members tie on the value and the rule "lowest column first" ranks them: they go to a short list and count the
+        // members above them.  The overflow bin with more members than needed, or a bin B with > 256 members, falls back to the
+        // binary search below (block-uniform).
+        __shared__ int hist[256];
+        __shared__ int sel_bin, sel_need, tie_n;
+        __shared__ unsigned int tie_list[256];
+        hist[t] = 0;
+        if (t == 0) tie_n = 0;
+        __syncthreads();
+        int mybin[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          mybin[u] = -1;
+          if (mine[u] != 0u) {
+            const unsigned int dk = (mine[u] >> 17) - L;
+            mybin[u] = dk < 255u ? (int)dk : 255;
+            atomicAdd(&hist[mybin[u]], 1);
+          }
+        }
+        __syncthreads();
+        {
+          const int hr = hist[255 - t];                       // reversed: the prefix over t is the suffix over the bins
+          int tot;
+          const int excl = block_excl_scan_256(hr, sc, &tot);
+          if (excl < k && k <= excl + hr) {                   // exactly one thread (C >= k, hr > 0 there)
+            sel_bin = 255 - t;
+            sel_need = k - excl;
+          }
+        }
+        __syncthreads();
+        const int B = sel_bin, need = sel_need, inB = hist[B];
+        const bool take_all = need == inB;
+        if (take_all || (B < 255 && inB <= 256)) {            // block-uniform
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (!take_all && mybin[u] == B) tie_list[atomicAdd(&tie_n, 1)] = mine[u];
+          if (!take_all) __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            bool sel = mybin[u] > B || (take_all && mybin[u] == B);
+            if (!take_all && mybin[u] == B) {
+              int above = 0;
+              for (int i = 0; i < inB; ++i) above += tie_list[i] > mine[u] ? 1 : 0;
+              sel = above < need;
+            }
+            if (sel) crow[cpos((int)(0x1FFFFu - (mine[u] & 0x1FFFFu)))] = (unsigned short)(mine[u] >> 17);
+          }
+          return;
+        }
+#endif
         unsigned int lo = 1u, hi = 0xFFFFFFFFu;             // largest T with #(candidates >= T) >= k; C >= k, candidates > 0
         int probe = 0;
         while (lo < hi) {
