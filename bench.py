@@ -111,10 +111,31 @@ def pcie_inclusive_sample(d, n, files=320, batch_files=40, T=1500, epochs=6):
             if epoch >= 2 and t0 is not None and steps > skip:
                 per_epoch.append((time.perf_counter() - t0) / (steps - skip))
         eng.close()
+        nthreads, impl = dl._gather_threads, None
+        try:
+            from freud_amd.loader import _host_lib
+            impl = {0: "portable (AVX2 auto-vectorised)", 1: "AVX-512, streaming stores"}.get(int(_host_lib().freud_host_impl()))
+        except Exception:       # noqa: BLE001
+            pass
         del dl
         dt = sorted(per_epoch)[len(per_epoch) // 2]          # median epoch
+        # the host -> HBM link of THIS box, measured the plain way (pinned buffer, one stream, 256 MB copies): the loader cannot
+        # deliver more than this; boxes of the pool differ (Gen5 x16 boxes copy ~55 GB/s, others ~31)
+        pin = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+        dev = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        link = 8 * (256 << 20) / (time.perf_counter() - t0) / 1e9
+        del pin, dev
+        delivered = batch_files * T * d * 2 / dt / 1e9
         return {"value": batch_files * T / dt, "unit": "activations/s", "ms_per_step": dt * 1e3,
                 "rows_per_step": batch_files * T, "steps": (steps - skip) * len(per_epoch),
+                "delivered_GBps": delivered, "link_h2d_GBps_measured": link, "frac_of_link": delivered / link,
+                "gather_threads": nthreads, "converter": impl,
                 "sample": f"{shard_gb:.2f} GB fp32 shard ({files} files x {T} x {d}) in the page cache, delivered as bf16 by the "
                           f"gather threads (bit-identical training: the engine rounds x to bf16 first), loader + engine step"}
     finally:

@@ -304,6 +304,33 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
 #pragma unroll
     for (int i = 0; i < 72; ++i) {
       const bf16x8 fa = ring[i % RING];
+#ifdef BF_PROXY16
+      // TIMING PROXY ONLY (tools/build_variant.sh proxy16 -DBF_PROXY16; results are WRONG): every 32x32x16 MFMA replaced by two
+      // 16x16x32 MFMAs on the same operand registers and a quarter each of the same accumulator -- the same FLOPs, the same LDS
+      // and register traffic, the other MFMA shape: what clock / time would a 16x16x32 backward get under the chip's power limit?
+      typedef __attribute__((ext_vector_type(4))) float f32x4_;
+#define BF_TWO16(C, A, Bv, ODD)                                                                                   \
+  do {                                                                                                             \
+    f32x4_ q0_ = (ODD) ? __builtin_shufflevector(C, C, 4, 5, 6, 7) : __builtin_shufflevector(C, C, 0, 1, 2, 3);      \
+    f32x4_ q1_ = (ODD) ? __builtin_shufflevector(C, C, 12, 13, 14, 15) : __builtin_shufflevector(C, C, 8, 9, 10, 11); \
+    q0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, q0_, 0, 0, 0);                                            \
+    q1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, q1_, 0, 0, 0);                                            \
+    if (ODD) { C[4] = q0_[0]; C[5] = q0_[1]; C[6] = q0_[2]; C[7] = q0_[3]; C[12] = q1_[0]; C[13] = q1_[1]; C[14] = q1_[2]; C[15] = q1_[3]; } \
+    else { C[0] = q0_[0]; C[1] = q0_[1]; C[2] = q0_[2]; C[3] = q0_[3]; C[8] = q1_[0]; C[9] = q1_[1]; C[10] = q1_[2]; C[11] = q1_[3]; }       \
+  } while (0)
+      if (i == 0) {
+        dc = cinit;
+#pragma unroll
+        for (int z = 8; z < 16; ++z) dc[z] = cinit[z] * (1.0f + 1e-6f * (float)z);      // (keeps the two half-chains distinct: no CSE)
+        BF_TWO16(dc, fa, wfrag[0], false);
+      } else if (i < 24) {
+        BF_TWO16(dc, fa, wfrag[i], (i & 1) != 0);
+      } else if (i < 48) {
+        BF_TWO16(acc[(i - 24) >> 1], fa, cf[i & 1], (i & 1) != 0);
+      } else {
+        BF_TWO16(acc[(i - 48) >> 1], fa, pf[i & 1], (i & 1) != 0);
+      }
+#else
       if (i == 0) {
         asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(dc) : "v"(fa), "v"(wfrag[0]), "v"(cinit));
       } else if (i < 24) {
@@ -313,6 +340,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       } else {
         acc[(i - 48) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[i & 1], acc[(i - 48) >> 1], 0, 0, 0);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // ---- gap g = i + 1 (issues while MFMA i occupies the matrix pipe); gap 72 is gap 0 of the next step
       const int g = i + 1;

@@ -13,6 +13,7 @@
 // Chosen at run time (__builtin_cpu_supports); the portable loop (auto-vectorised for AVX2) stays as the fallback and as the
 // reference of the test.  (vcvtne2ps2bf16 is deliberately NOT used: it flushes fp32 denormals to zero, the device does not.)
 #include <immintrin.h>
+#include <pthread.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -94,5 +95,112 @@ void freud_convert_piece(const float* base, int64_t idx, size_t row_elems, size_
   freud_f32_to_bf16(base + (size_t)idx * row_elems + e0, dst_row + e0, e1 - e0);
 }
 
+// ---- a small persistent thread pool (pthreads; no OpenMP: the process already hosts torch's OpenMP runtime, and a second one
+// in a helper library is a known source of oversubscription and fork trouble).  One job at a time (the loader's gather worker is
+// the only caller); workers sleep on a condition variable between jobs; work items are handed out by an atomic counter; the
+// calling thread works too.
+#define POOL_MAX 64
+typedef void (*item_fn)(long item, void* arg);
+static struct {
+  pthread_t th[POOL_MAX];
+  int nth;                         // workers started
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+  unsigned long gen;               // job generation (under mu)
+  item_fn fn;
+  void* arg;
+  long items;
+  int use;                         // workers that may join this job
+  volatile long next;              // next item (atomic)
+  volatile int active;             // workers still inside the job (atomic)
+  int shutdown;
+} g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER, .cv_done = PTHREAD_COND_INITIALIZER};
+
+static void pool_run_items(void) {
+  for (;;) {
+    const long it = __atomic_fetch_add(&g_pool.next, 1, __ATOMIC_RELAXED);
+    if (it >= g_pool.items) break;
+    g_pool.fn(it, g_pool.arg);
+  }
+}
+
+static void* pool_worker(void* idp) {
+  const int id = (int)(intptr_t)idp;
+  unsigned long seen = 0;
+  pthread_mutex_lock(&g_pool.mu);
+  for (;;) {
+    while (!g_pool.shutdown && (g_pool.gen == seen || id >= g_pool.use)) {
+      if (g_pool.gen != seen && id >= g_pool.use) seen = g_pool.gen;      // a job this worker is not part of
+      pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+    }
+    if (g_pool.shutdown) break;
+    seen = g_pool.gen;
+    pthread_mutex_unlock(&g_pool.mu);
+    pool_run_items();
+    pthread_mutex_lock(&g_pool.mu);
+    if (__atomic_sub_fetch(&g_pool.active, 1, __ATOMIC_ACQ_REL) == 0) pthread_cond_signal(&g_pool.cv_done);
+  }
+  pthread_mutex_unlock(&g_pool.mu);
+  return NULL;
+}
+
+static void pool_parallel_for(long items, int nthreads, item_fn fn, void* arg) {
+  if (nthreads > POOL_MAX + 1) nthreads = POOL_MAX + 1;
+  if (nthreads <= 1 || items <= 1) {
+    for (long it = 0; it < items; ++it) fn(it, arg);
+    return;
+  }
+  pthread_mutex_lock(&g_pool.mu);
+  while (g_pool.nth < nthreads - 1) {              // the caller is the last "thread" of the job
+    if (pthread_create(&g_pool.th[g_pool.nth], NULL, pool_worker, (void*)(intptr_t)g_pool.nth) != 0) break;
+    g_pool.nth++;
+  }
+  const int use = g_pool.nth < nthreads - 1 ? g_pool.nth : nthreads - 1;
+  g_pool.fn = fn; g_pool.arg = arg; g_pool.items = items; g_pool.use = use;
+  __atomic_store_n(&g_pool.next, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&g_pool.active, use, __ATOMIC_RELEASE);
+  g_pool.gen++;
+  pthread_cond_broadcast(&g_pool.cv_work);
+  pthread_mutex_unlock(&g_pool.mu);
+  pool_run_items();
+  pthread_mutex_lock(&g_pool.mu);
+  while (__atomic_load_n(&g_pool.active, __ATOMIC_ACQUIRE) != 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+  pthread_mutex_unlock(&g_pool.mu);
+}
+
+// A whole batch in ONE call (round 4): rows idx[0..count) -> consecutive rows of dst, cut into pieces and spread over `nthreads`
+// threads of the pool above.  The loader's Python thread pool spent more time handing pieces to threads (GIL hand-offs: 24 Python
+// threads delivered HALF of what 8 did on a 256-thread host, profiles/r04_loader_*.json) than converting them; here the
+// interpreter is out of the loop and the call releases the GIL for its whole duration.
+typedef struct {
+  const char* base; const int64_t* idx; size_t row_elems, per, piece, dst_pitch; char* dst; int convert;
+} gather_job;
+
+static void gather_item(long it, void* argp) {
+  const gather_job* g = (const gather_job*)argp;
+  const size_t j = (size_t)it / g->per, e0 = ((size_t)it % g->per) * g->piece;
+  const size_t e1 = e0 + g->piece < g->row_elems ? e0 + g->piece : g->row_elems;
+  if (g->convert)      // fp32 -> bf16: row_elems / piece / dst_pitch in ELEMENTS
+    freud_f32_to_bf16((const float*)g->base + (size_t)g->idx[j] * g->row_elems + e0, (uint16_t*)g->dst + j * g->dst_pitch + e0, e1 - e0);
+  else                 // plain copy: the same three in BYTES
+    memcpy(g->dst + j * g->dst_pitch + e0, g->base + (size_t)g->idx[j] * g->row_elems + e0, e1 - e0);
+}
+
+void freud_gather_batch_f32_to_bf16(const float* base, const int64_t* idx, size_t count, size_t row_elems, uint16_t* dst,
+                                    size_t dst_pitch, size_t piece, int nthreads) {
+  if (piece == 0 || piece > row_elems) piece = row_elems;
+  gather_job g = {(const char*)base, idx, row_elems, (row_elems + piece - 1) / piece, piece, dst_pitch, (char*)dst, 1};
+  (void)pick_impl();
+  pool_parallel_for((long)(count * g.per), nthreads, gather_item, &g);
+}
+
+// the same for shards that travel as they are (fp16 / bf16 shards, fp32 delivered natively): a parallel row gather
+void freud_gather_batch_copy(const char* base, const int64_t* idx, size_t count, size_t row_bytes, char* dst, size_t dst_pitch_bytes,
+                             size_t piece_bytes, int nthreads) {
+  if (piece_bytes == 0 || piece_bytes > row_bytes) piece_bytes = row_bytes;
+  gather_job g = {base, idx, row_bytes, (row_bytes + piece_bytes - 1) / piece_bytes, piece_bytes, dst_pitch_bytes, dst, 0};
+  pool_parallel_for((long)(count * g.per), nthreads, gather_item, &g);
+}
+
 int freud_host_impl(void) { return pick_impl(); }
-int freud_host_version(void) { return 2; }
+int freud_host_version(void) { return 3; }

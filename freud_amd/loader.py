@@ -55,6 +55,10 @@ def _host_lib():
         lib.freud_f32_to_bf16_portable.restype = None
         lib.freud_convert_piece.argtypes = [C.c_void_p, C.c_int64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
         lib.freud_convert_piece.restype = None
+        lib.freud_gather_batch_f32_to_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        lib.freud_gather_batch_f32_to_bf16.restype = None
+        lib.freud_gather_batch_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        lib.freud_gather_batch_copy.restype = None
         lib.freud_host_impl.restype = C.c_int
         _HOST_LIB = lib
     return _HOST_LIB
@@ -148,12 +152,12 @@ class MemoryMappedActivationDataLoader:
         small = getattr(self._dataset.mmap, "nbytes", 1 << 62) <= limit
         if self.device.type == "cuda" and not self._convert and (mode == "1" or (mode not in ("0",) and small)):
             self._try_register()
-        # gather pool: a conversion thread moves ~8-11 GB/s of fp32 (AVX2; more with the AVX-512 streaming-store form), a
-        # 60 000-row tiny batch is 92 MB of fp32 per 0.6 ms train step -- round 3's 8 threads were the limit of the loader-fed
-        # rate on the driver's box (30.5 GB/s delivered).  A quarter of the host's hardware threads, between
-        # 1 and 24, per rank (a node's 8 ranks share the host: LOCAL_WORLD_SIZE divides the budget)
+        # gather threads (libfreud_host.so's own pthread pool, one C call per batch): a conversion thread moves 8-11 GB/s of fp32,
+        # a 60 000-row tiny batch is 92 MB of fp32 per 0.6 ms train step.  Round 3 drove 8 threads from a Python thread pool, one
+        # ctypes call per row; 24 Python threads delivered HALF of that on the 256-thread host of the GPU boxes (GIL hand-offs), so
+        # the interpreter is out of the loop now.  A sixteenth of the host's hardware threads per rank, between 1 and 16.
         lw = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1))
-        auto = min(24, max(1, (os.cpu_count() or 1) // (4 * min(lw, 2))))
+        auto = min(16, max(1, (os.cpu_count() or 1) // (8 * min(lw, 2))))
         self._gather_threads = dl_max_workers if dl_max_workers and dl_max_workers > 0 else auto
         self._pool = None
         self.skip_next = 0          # resume (train_sae f4): the next iterator drops this many leading batches unread
@@ -209,48 +213,35 @@ class MemoryMappedActivationDataLoader:
 
     # -- iteration -------------------------------------------------------------------------------
     def _gather(self, idxs: Sequence[int], out: np.ndarray) -> None:
-        """Rows idxs of the shard -> out[0 .. len(idxs)).  One row is ~1-8 MB, so the copy is memory-bandwidth work: a
-        single thread moves ~19 GB/s on the MI355X host, well under the PCIe link, hence a small thread pool (numpy
-        releases the GIL in the copy loop).  dl_max_workers > 0 sets the pool size (the reference hands that key to
-        torch's DataLoader as num_workers, train_sae.py:51-63); 0 = automatic."""
+        """Rows idxs of the shard -> out[0 .. len(idxs)).  One row is ~1-8 MB, so this is memory-bandwidth work; it runs as ONE
+        call into libfreud_host.so, which cuts the rows into pieces and spreads them over its own threads (no Python per row, the
+        GIL released for the whole batch).  dl_max_workers > 0 sets the thread count (the reference hands that key to torch's
+        DataLoader as num_workers, train_sae.py:51-63); 0 = automatic.  Without the library (never on a built tree) a plain loop."""
         mm = self._dataset.mmap
         nthreads = self._gather_threads
-        if self._convert:        # fp32 rows -> bf16 bit patterns (out is a uint16 / bf16-viewed buffer), libfreud_host.so
-            lib, row = _host_lib(), mm.shape[1]
-            idx64 = np.ascontiguousarray(np.asarray(idxs, dtype=np.int64))
-            out16 = out.view(np.uint16) if out.dtype != np.uint16 else out
-
-            if nthreads <= 1 or len(idx64) == 0:
-                lib.freud_gather_f32_to_bf16(mm.ctypes.data, idx64.ctypes.data, len(idx64), row, out16.ctypes.data)
-                return
-            # work items = pieces of rows (a multiple of 32 elements, so that every piece starts on a 64-byte line of the
-            # destination row): `per` pieces per row give every thread the same number of bytes whatever the batch size
-            per = max(1, -(-2 * nthreads // len(idx64)))
-            piece = ((row + per - 1) // per + 31) // 32 * 32
-            items = [(j, e0, min(e0 + piece, row)) for j in range(len(idx64)) for e0 in range(0, row, piece)]
-            base, dst0, stride = mm.ctypes.data, out16.ctypes.data, out16.strides[0]
-            rows_i = [int(v) for v in idx64]
-
-            def conv(t):
-                for j, e0, e1 in items[t::nthreads]:
-                    lib.freud_convert_piece(base, rows_i[j], row, e0, e1, dst0 + j * stride)
-            if self._pool is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="shard-gather")
-            list(self._pool.map(conv, range(nthreads)))
+        idx64 = np.ascontiguousarray(np.asarray(idxs, dtype=np.int64))
+        if len(idx64) == 0:
             return
-        if nthreads <= 1 or len(idxs) < 2 * nthreads:
+        row = mm.shape[1]
+        per = max(1, -(-2 * nthreads // len(idx64)))            # pieces per row: every thread gets the same bytes
+        if self._convert:        # fp32 rows -> bf16 bit patterns (out is a uint16 / bf16-viewed buffer)
+            lib = _host_lib()
+            out16 = out.view(np.uint16) if out.dtype != np.uint16 else out
+            piece = ((row + per - 1) // per + 31) // 32 * 32     # whole 64-byte lines of the destination
+            lib.freud_gather_batch_f32_to_bf16(mm.ctypes.data, idx64.ctypes.data, len(idx64), row, out16.ctypes.data,
+                                               out16.strides[0] // 2, piece, nthreads)
+            return
+        try:
+            lib = _host_lib()
+        except RuntimeError:
+            lib = None
+        if lib is None or out.strides[-1] != out.itemsize or mm.strides[-1] != mm.itemsize:
             for j, i in enumerate(idxs):
                 out[j] = mm[i]
             return
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="shard-gather")
-
-        def part(t):
-            for j in range(t, len(idxs), nthreads):
-                out[j] = mm[idxs[j]]
-        list(self._pool.map(part, range(nthreads)))
+        row_bytes = row * mm.itemsize
+        piece = ((row_bytes + per - 1) // per + 63) // 64 * 64
+        lib.freud_gather_batch_copy(mm.ctypes.data, idx64.ctypes.data, len(idx64), row_bytes, out.ctypes.data, out.strides[0], piece, nthreads)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, List[str]]]:
         batches = self.epoch_batches()
@@ -324,9 +315,16 @@ class MemoryMappedActivationDataLoader:
             return
         B, depth, dev = self.batch_size, self.depth, self.device
         tdtype = torch.bfloat16 if self._convert else torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
-        pinned = [torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)]
-        hbm = [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)]
+        # the pinned ring and its HBM twin are allocated ONCE per loader and reused by every epoch (pinning 3 x 46 MB per epoch
+        # cost several milliseconds of every epoch start; all work on them is finished when an epoch's iterator ends)
+        key = (B, T * d, tdtype, depth, str(dev))
+        if getattr(self, "_ring_key", None) != key:
+            self._ring = ([torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)],
+                          [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)])
+            self._ring_key = key
+        pinned, hbm = self._ring
         free = [threading.Semaphore(1) for _ in range(depth)]
+        copied = [None] * depth     # copy-stream event of the H2D copy that last read pinned[slot]
         ready: "queue.Queue" = queue.Queue()
         stop = threading.Event()
 
@@ -337,6 +335,8 @@ class MemoryMappedActivationDataLoader:
                     while not free[slot].acquire(timeout=0.1):
                         if stop.is_set():
                             return
+                    if copied[slot] is not None:
+                        copied[slot].synchronize()      # the slot's previous batch has left for the GPU
                     if self._convert:
                         self._gather(idxs, pinned[slot].view(torch.int16).numpy().view(np.uint16)[: len(idxs)])
                     else:
@@ -366,7 +366,10 @@ class MemoryMappedActivationDataLoader:
                     landed = torch.cuda.Event()
                     landed.record(copy_stream)
                 compute.wait_event(landed)
-                landed.synchronize()          # pinned[slot] may be refilled once the DMA has read it
+                # pinned[slot] may be refilled once the DMA has read it: the GATHER worker waits for that (copied[slot]), not
+                # this thread -- round 3 synchronised here, so the training thread sat ~0.8 ms per batch in a host wait instead
+                # of enqueueing the step
+                copied[slot] = landed
                 free[slot].release()
                 yield hbm[slot][: len(idxs)].view(len(idxs), T, d), [names[i] for i in idxs]
                 ev = torch.cuda.Event()
@@ -375,6 +378,8 @@ class MemoryMappedActivationDataLoader:
         finally:
             stop.set()
             th.join(timeout=5)
+            torch.cuda.current_stream(dev).synchronize()     # the ring is reused by the next epoch: nothing of this one is in flight
+            copy_stream.synchronize()
 
 
 def write_shards(folder: str, layer_name: str, rows: np.ndarray, tensor_shape: Sequence[int],
