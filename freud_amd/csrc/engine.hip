@@ -691,7 +691,9 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->gn_part, 1024 * 8);
   ALLOC(c->cn_part, (int64_t)(c->d_p / 32) * c->n_p * 4);
   ALLOC(c->cnorm, (int64_t)c->n_p * 4);
-  if (c->dw_tail_tiles > 0) ALLOC(c->dw_tail, (int64_t)c->dw_tail_tiles * c->dw_tail_pieces * 65536 * 4);
+  // overflow buffer of the tail-split weight-gradient launches: at most one round of pieces (256 tiles of 256 x 256 fp32); the
+  // round-sized column chunks of the data-parallel form (below) use it for their last, partial chunk as well
+  if (c->dw_tail_tiles > 0 || (c->d_p >= 1024 && c->d_p % 256 == 0 && c->n_p % 256 == 0)) ALLOC(c->dw_tail, (int64_t)256 * 65536 * 4);
   ALLOC(c->masked, 2048 * 4);
   ALLOC(c->cnt_part, (Mp / 128 + 1) * 4);
   c->stats_cap = DP_STATS_HEAD;
@@ -1774,7 +1776,41 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         if (e_ != hipSuccess) return fail(SAE_ERR_HIP, "staging buffer of the column chunks: %s", hipGetErrorString(e_));
       }
       const bool col_chunked = c->dist && c->dp_world > 0 && (c->p2p || col_staged) && c->dw_col_chunks > 1;
-      if (col_chunked) {
+      // Round 4: chunks sized by ROUNDS.  A chunk of floor(256 / (d_p / 256)) tile columns is one round of whole 256x256 tiles --
+      // it needs no split-K, writes straight into the gradient (or the staging block) and costs what the same tiles cost in the
+      // plain launch; the columns left over run like the plain launch's tail (K pieces through the overflow buffer).  Round 3's
+      // four equal chunks were 200 tiles each: 0.78 of a round, bought full with split-K slabs and a reduction pass (+2.8 % on
+      // one rank at C4; now +1.5 % with the peer exchange, +1.1 % with RCCL, section 5).  debug_flags 84 = the equal chunks.
+      const int nbm256 = d_p / 256, per_round = nbm256 > 0 ? 256 / nbm256 : 0;
+      const bool round_chunks = col_chunked && d_p % 256 == 0 && n_p % 256 == 0 && per_round >= 1 && n_p / 256 > per_round &&
+                                c->dw_tail != nullptr && c->cfg.debug_flags != 84 && !g_force_gemm128;
+      if (round_chunks) {
+        ev_begin(c, KID_DW, s);
+        const int nbn256 = n_p / 256;
+        for (int ct0 = 0; ct0 < nbn256;) {
+          const int nct = nbn256 - ct0 >= per_round ? per_round : nbn256 - ct0;
+          const int col0 = ct0 * 256, cols = nct * 256;
+          float* stage = c->p2p ? nullptr : c->col_stage + (int64_t)col0 * d_p;        // contiguous [d_p x cols] block (RCCL)
+          GemmArgs g{};
+          g.A0 = c->dxh; g.B0 = c->c + col0; g.A1 = c->xb_cur; g.B1 = c->dpre + col0; g.lda = d_p; g.ldb = n_p;
+          g.nbm = d_p / 128; g.nbn = cols / 128; g.ktiles0 = (int)(Mp / 64); g.ktiles = 2 * g.ktiles0;
+          g.splits = 1;
+          gemm_tail_plan(nbm256 * nct, g.ktiles, g.tail_tiles, g.tail_pieces);
+          if (nbm256 * nct >= 255) g.tail_tiles = g.tail_pieces = 0;      // (a full chunk: one round, nothing to split)
+          EpiSlab e{};
+          e.slab = c->p2p ? c->G + col0 : stage; e.slab_stride = 0; e.ld = c->p2p ? n_p : cols; e.tail = c->dw_tail;
+          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+          if (rc) return rc;
+          if (g.tail_tiles > 0)
+            hipLaunchKernelGGL(reduce_tail_kernel, dim3(g.tail_tiles, 16), dim3(256), 0, s, c->dw_tail, e.slab, e.ld, nbm256, nct,
+                               g.tail_tiles, g.tail_pieces);
+          if (c->p2p) exchange_block(c, col0, d_p, cols, n_p, s);
+          else exchange_staged(c, stage, col0, d_p, cols, n_p, s);
+          ct0 += nct;
+        }
+        ev_end(c, KID_DW, s);
+        dw_chunked = dw_chunked_any = true;
+      } else if (col_chunked) {
         const int cols = n_p / c->dw_col_chunks;
         ev_begin(c, KID_DW, s);
         for (int q = 0; q < c->dw_col_chunks; ++q) {

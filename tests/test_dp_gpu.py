@@ -132,9 +132,11 @@ import numpy as np, torch
 sys.path.insert(0, os.environ["FREUD_ROOT"])
 from freud_amd.engine import SaeEngine
 variant = sys.argv[1]
+carrier = sys.argv[2] if len(sys.argv) > 2 else "rccl"
 torch.cuda.set_device(0)
 g = torch.Generator().manual_seed(1)
-d, n, M = {"l1": (384, 1024, 2048), "l1_d1280": (1280, 1024, 1024), "topk": (768, 2048, 1024)}[variant]
+d, n, M = {"l1": (384, 1024, 2048), "l1_d1280": (1280, 1024, 1024), "l1_d1280_wide": (1280, 16384, 1024),
+           "topk": (768, 2048, 1024)}[variant]
 x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ torch.randn(64, d, generator=g)).to(torch.bfloat16).cuda()
 outs = []
 for dist_mode in (False, True):
@@ -150,8 +152,11 @@ for dist_mode in (False, True):
         eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": np.zeros(n, np.float32),
                         "W_dec": (We / We.norm(dim=1, keepdim=True)).numpy(), "b_dec": np.zeros(d, np.float32)})
         key = "W_dec"
-    if dist_mode:
+    if dist_mode and carrier == "rccl":
         eng.dist_init(SaeEngine.dist_unique_id(), 0, 1)
+        assert eng.dist_world() == 1
+    elif dist_mode:            # the peer exchange with one rank: export, "map the peers" (nobody), self-test, in-engine protocol
+        eng.p2p_init([eng.p2p_export()], 0, 1)
         assert eng.dist_world() == 1
     for i in range(4):
         eng.step(x, 1e-3)
@@ -163,13 +168,16 @@ print(json.dumps({"rel": rel, "m0": outs[0][1].tolist(), "m1": outs[1][1].tolist
 """
 
 
-@pytest.mark.parametrize("variant", ["l1", "l1_d1280", "topk"])
-def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant):
+@pytest.mark.parametrize("variant,carrier", [("l1", "rccl"), ("l1_d1280", "rccl"), ("topk", "rccl"),
+                                              ("l1_d1280_wide", "rccl"), ("l1_d1280_wide", "p2p")])
+def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant, carrier):
     """sae_dist_init with a communicator of ONE rank: statistics all-reduce on the communication stream, gradient ranges
     all-reduced as they become final, stream joins -- the whole in-engine protocol -- must reproduce the plain step
     (global statistics == local ones).  Child process: the communicator must not leak into the other tests.
     l1_d1280: the generic three-GEMM path, whose weight gradient travels as COLUMN chunks through a contiguous staging buffer
-    (summed there by RCCL, copied back into the strided block of the gradient buffer)."""
+    (summed there by RCCL, copied back into the strided block of the gradient buffer).  l1_d1280_wide (n = 16 384: 64 tile
+    columns): the ROUND-sized chunks -- 51 tile columns as one round of whole tiles written straight into the gradient (p2p) or
+    the staging block (RCCL), the 13 left over as K pieces through the overflow buffer -- on both in-engine carriers."""
     import json
     import os
     import subprocess
@@ -178,7 +186,7 @@ def test_in_engine_rccl_single_rank_equals_plain_step(tmp_path, variant):
     script = os.path.join(str(tmp_path), "child.py")
     open(script, "w").write(_DIST_CHILD)
     env = dict(os.environ, FREUD_ROOT=root, NCCL_DEBUG_FILE="/tmp/rccl_debug_%h_%p.log")
-    out = subprocess.run([sys.executable, script, variant], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, script, variant, carrier], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["rel"] < 1e-6, res
