@@ -30,6 +30,18 @@ class OracleEngine:
             return {"decoder.weight": (self.d, self.n), "encoder_bias": (self.n,)}
         return {"encoder.weight": (self.n, self.d), "encoder.bias": (self.n,), "W_dec": (self.n, self.d), "b_dec": (self.d,)}
 
+    def param_checksum(self):
+        """Stand-in of sae_param_checksum: 64-bit words over the bytes of parameters / both moments + the step count, so that
+        train()'s replica guard (freud_amd/dp.py: check_replicas) runs in the CPU data-parallel tests as well."""
+        import hashlib
+
+        def h(tensors):
+            m = hashlib.blake2b(digest_size=8)
+            for k in sorted(tensors):
+                m.update(np.ascontiguousarray(tensors[k].numpy() if hasattr(tensors[k], "numpy") else tensors[k]).tobytes())
+            return int.from_bytes(m.digest(), "little")
+        return (h(self.P), h(self.st.exp_avg), h(self.st.exp_avg_sq), int(self.st.step))
+
     def get_topk_state(self):
         return self.nfsf.numpy().copy()
 

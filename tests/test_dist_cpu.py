@@ -118,3 +118,57 @@ def test_topk_two_ranks_match_single_process_exactly(tmp_path):
     for step in range(1, 5):
         for tag in ("train/fvu", "train/auxk_loss", "train/dead_pct", "train/grad_norm"):
             assert sR[(tag, step)] == pytest.approx(s1[(tag, step)], rel=2e-5, abs=1e-7), (tag, step)
+
+
+def _diverge_worker(rank, world, port, cfg):
+    """train() on `world` gloo ranks with an engine whose rank 1 silently corrupts one weight in the third step: the replica
+    guard must stop EVERY rank before the next checkpoint is written."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import functools
+    from freud_amd import dp
+    from freud_amd.train_sae import train
+    from tests.fake_engine import OracleEngine
+
+    class Corrupting(OracleEngine):
+        def optimizer_step(self, lr, grad_scale=1.0, stream=None):
+            super().optimizer_step(lr, grad_scale, stream)
+            if rank == 1 and self.st.step == 3:
+                k = sorted(self.P)[0]
+                self.P[k].view(-1)[3] += 1e-3
+    try:
+        train(**cfg, engine_factory=functools.partial(Corrupting, autocast=False), dist_backend="gloo")
+        outcome = "no error"
+    except dp.ExchangeError as e:
+        outcome = "ExchangeError: " + str(e)
+    open(os.path.join(cfg["run_dir"], f"outcome_rank{rank}.txt"), "w").write(outcome)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_replica_guard_stops_every_rank_before_the_next_write(tmp_path):
+    """freud_amd/dp.py: check_replicas (round 4).  Replicas are bit-identical by construction; here rank 1's parameters change
+    behind the protocol's back during step 3.  The guard of that step's logging raises dp.ExchangeError on BOTH ranks -- naming
+    the diverged rank -- and the checkpoint of step 4 is never written (the one of step 2, checked and written before the
+    corruption, stays the last good one)."""
+    T, d, n_files = 6, 16, 16
+    g = torch.Generator().manual_seed(3)
+    rows = (torch.relu(torch.randn(n_files * T, 4, generator=g)) @ torch.randn(4, d, generator=g)).reshape(n_files, T * d)
+    folder = os.path.join(str(tmp_path), "train")
+    write_shards(folder, "enc", rows.numpy(), [T, d])
+    cfg = {
+        "whisper_config": {"model": "tiny", "layer_name": "enc"}, "seed": 0, "train_folder": folder, "val_folder": folder,
+        "device": "cpu", "lr": 1e-3, "weight_decay": 0.0, "steps": 6, "clip_thresh": 1.0, "dl_max_workers": 0, "log_tb_every": 1,
+        "save_every": 2, "val_every": 1000, "scheduler_params": {}, "start_checkpoint": None, "from_disk": True,
+        "autoencoder_variant": "l1", "autoencoder_config": {"n_dict_components": 32, "recon_alpha": 100.0},
+        "optimizer": "radam", "scheduler": "cosine", "batch_size": 2, "run_dir": os.path.join(str(tmp_path), "run"),
+    }
+    os.makedirs(cfg["run_dir"], exist_ok=True)
+    mp.spawn(_diverge_worker, args=(2, _free_port(), cfg), nprocs=2, join=True)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    outs = [open(os.path.join(cfg["run_dir"], f"outcome_rank{r}.txt")).read() for r in range(2)]
+    for o in outs:
+        assert o.startswith("ExchangeError") and "replicas diverged" in o and "rank 1 differs from rank 0 in parameters" in o, o
+    assert sorted(os.listdir(os.path.join(cfg["run_dir"], "checkpoints"))) == ["step2.pth"]
+
