@@ -166,6 +166,73 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
   if (FINAL_BARRIER) lds_barrier();        // the tile and the scratch areas are free again (persistent instantiation only)
 }
 
+// The same one-step bf16 epilogue with EIGHT consecutive columns per thread (round 4): functors that declare
+// `static constexpr bool WIDE8 = true` and `apply8(row, col, v0, v1, pre0, pre1)` store 16 bytes per lane and row instead of 8 --
+// half the store instructions of a store-issue-bound tail (MI355X_MICROARCH.md: 8-byte accesses run at 0.54-0.70 x the 16-byte
+// rate).  A thread owns columns 8 (tl % 16) .. + 7 of rows tl / 16 + 16 it (it = 0..7) of each 128-column pass; Epi::prefetch
+// keeps its 4-column granularity (two per call of apply8), batches of NB / 2 calls keep the prefetched registers the same.
+#ifndef G2_WIDE8
+#define G2_WIDE8 1           // tools/build_variant.sh A/B switch: 0 = every functor through the 4-column form
+#endif
+template <class E, class = void>
+struct epi_wide8 { static constexpr bool value = false; };
+template <class E>
+struct epi_wide8<E, std::void_t<decltype(E::WIDE8)>> { static constexpr bool value = G2_WIDE8 && E::WIDE8; };
+
+template <bool FINAL_BARRIER, class Epi>
+__device__ __forceinline__ void g2_epilogue_bf16_w8(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+  const int half = t >> 8, tl = t & 255, c8 = (tl & 15) * 8;
+  const int row0 = bm * G2_BM + 128 * half;
+  constexpr int NB = epi_prefetch_batch<Epi>::value / 2, BPP = 8 / NB, NQ = 2 * BPP;
+  static_assert(NB >= 1 && 8 % NB == 0, "prefetch batch");
+  typename Epi::Pre pre[2][NB][2];
+  auto prefetch_batch = [&](int q, typename Epi::Pre (&dst)[NB][2]) {
+    const int pass = q / BPP, b0 = (q % BPP) * NB;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int r = row0 + (tl >> 4) + 16 * (b0 + it), cc = bn * G2_BN + 128 * pass + c8;
+      dst[it][0] = epi.prefetch(r, cc);
+      dst[it][1] = epi.prefetch(r, cc + 4);
+    }
+  };
+  prefetch_batch(0, pre[0]);
+  {
+    bf16_t* dst = tile + (128 * wm + (lane & 31)) * G2_BF16_PITCH + 64 * wn + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<bf16x4*>(dst + 32 * i * G2_BF16_PITCH + 32 * j + 8 * gq) =
+              bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
+  }
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int pass = q / BPP, b0 = (q % BPP) * NB;
+    const int col0 = bn * G2_BN + 128 * pass;
+    const bf16_t* src = tile + (128 * half) * G2_BF16_PITCH + 128 * pass;
+    if (q + 1 < NQ) prefetch_batch(q + 1, pre[(q + 1) & 1]);
+    if (b0 == 0) epi.tile_begin(row0, col0, split);
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int row = (tl >> 4) + 16 * (b0 + it);
+      // (rows are 520 bytes apart: 8-byte aligned, so two 8-byte reads)
+      const bf16x4 q0 = *reinterpret_cast<const bf16x4*>(&src[row * G2_BF16_PITCH + c8]);
+      const bf16x4 q1 = *reinterpret_cast<const bf16x4*>(&src[row * G2_BF16_PITCH + c8 + 4]);
+      const f32x4 v0 = {(float)q0[0], (float)q0[1], (float)q0[2], (float)q0[3]};
+      const f32x4 v1 = {(float)q1[0], (float)q1[1], (float)q1[2], (float)q1[3]};
+      epi.apply8(row0 + row, col0 + c8, v0, v1, pre[q & 1][it][0], pre[q & 1][it][1]);
+    }
+    if (b0 + NB == 8)
+      epi.tile_end(reinterpret_cast<float*>(smem + G2_BF16_TILE_BYTES) + (2 * pass + half) * G2_BF16_SCRATCH_FLOATS);
+  }
+  if (FINAL_BARRIER) lds_barrier();
+}
+
 // Functors of long-K row-major GEMMs whose A operand streams from HBM (static constexpr bool DEEP_A_RING: the decoder,
 // x_hat = c W^T with K = n_dict) get a THREE-deep ring for the A tiles (see the K loop).
 template <class E, class = void>
@@ -447,7 +514,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #ifdef G2X_STAMP
   st2 = __builtin_readcyclecounter();
 #endif
-  if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc, smem, bm, bn, split, epi);
+  if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<PERSIST>(acc, smem, bm, bn, split, epi);
+  else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc, smem, bm, bn, split, epi);
   else g2_epilogue(acc, smem, bm, bn, split, epi);      // (both end with a barrier: LDS is free again)
 #ifdef G2X_STAMP
   if (threadIdx.x == 0 && g2x_stamps) {

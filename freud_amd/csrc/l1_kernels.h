@@ -190,6 +190,19 @@ struct EpiEnc {
     }
     if (!skip_store) EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
   }
+  static constexpr bool WIDE8 = true;                 // gemm256.h: eight columns per thread, 16-byte latent stores
+  __device__ void apply8(int row, int col, f32x4 v0, f32x4 v1, const Pre& p0, const Pre& p1) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float c0 = fmaxf(bf16_round(v0[j]) + p0.b[j], 0.f), c1 = fmaxf(bf16_round(v1[j]) + p1.b[j], 0.f);
+      if (row >= M) c0 = c1 = 0.f;
+      l1 += c0 + c1;
+      o[j] = (bf16_t)c0;
+      o[4 + j] = (bf16_t)c1;
+    }
+    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+  }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
