@@ -166,7 +166,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
 
   // (the operand scales are powers of two, so rounding the raw accumulator to bf16 first and un-scaling afterwards is the
   // same value as bf16(acc / (s_a s_b)): the functors that round first take the one-step bf16 epilogue of gemm256.h)
-  if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<false>(acc, smem, bm, bn, 0, epi);
+  if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<false>(acc, smem, bm, bn, 0, epi);
+  else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<false>(acc, smem, bm, bn, 0, epi);
   else g2_epilogue(acc, smem, bm, bn, 0, epi);
 }
 

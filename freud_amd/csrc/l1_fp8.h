@@ -199,6 +199,26 @@ struct EpiEnc8 {
     EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
     EPI_STORE(reinterpret_cast<unsigned*>(c8 + (int64_t)row * n_p + col), pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc));
   }
+  // gemm256.h (round 4): eight columns per thread -- a 16-byte bf16 and an 8-byte e4m3 store per row instead of two 8-byte and
+  // two 4-byte ones (this epilogue writes the latent twice, so its store instructions count double)
+  static constexpr bool WIDE8 = true;
+  __device__ void apply8(int row, int col, f32x4 v0, f32x4 v1, const Pre& p0, const Pre& p1) {
+    bf16x8 o;
+    float cv[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cv[j] = fmaxf(bf16_round(v0[j] * inv) + p0.b[j], 0.f);
+      cv[4 + j] = fmaxf(bf16_round(v1[j] * inv) + p1.b[j], 0.f);
+      if (row >= M) cv[j] = cv[4 + j] = 0.f;
+      l1 += cv[j] + cv[4 + j];
+      o[j] = (bf16_t)cv[j];
+      o[4 + j] = (bf16_t)cv[4 + j];
+    }
+    EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 q = {pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc), pack4_fp8(cv[4] * sc, cv[5] * sc, cv[6] * sc, cv[7] * sc)};
+    EPI_STORE(reinterpret_cast<u32x2*>(c8 + (int64_t)row * n_p + col), q);
+  }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
