@@ -477,6 +477,19 @@ def main():
               "workgroup %.0f-%.0f, whole-kernel cycles per workgroup: median %.0f, max %.0f, outside the loop (median) %.0f" %
               (np.median(st[:, 0] / st[:, 1]) * 100.0, np.median(st[:, 0] / st[:, 2]), len(st), st[:, 2].min(), st[:, 2].max(),
                np.median(whole), whole.max(), np.median(whole - st[:, 0])), file=sys.stderr)
+    if args.dbg == 67 and rank == 0 and args.variant == "topk":     # -DSEL_STAMP builds: phase stamps of the compact AuxK select
+        st = eng.debug_read(11, 4096 * 8).reshape(-1, 8)
+        slow = st[st[:, 7] >= 1000]
+        if len(slow):
+            last = np.array([r[int(r[7]) - 1001] for r in slow])
+            print("AuxK compact select: %d of %d rows took the SLOW path (block-wide counting probes): median %.0f cycles per row, marks %s" %
+                  (len(slow), len(st), np.median(last), np.median(slow[:, :7], axis=0).round().tolist()), file=sys.stderr)
+        st = st[(st[:, 5] > 0) & (st[:, 7] < 1000)]
+        if len(st):
+            names = ["row loaded + masked", "candidate count (block scan)", "lower bound L", "candidates appended", "histogram select + stores"]
+            d_ = np.diff(st[:, :6], axis=1)
+            print("AuxK compact select, cycles per row (median over %d rows): %s | total %.0f" %
+                  (len(st), ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, np.median(d_, axis=0))), np.median(st[:, 5])), file=sys.stderr)
     if args.variant == "topk":
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "

@@ -2553,6 +2553,15 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     for (int64_t i = 0; i < nq; ++i) out[i] = (float)tmp[(size_t)i];
     return SAE_OK;
   }
+  if (which == 11) {   // phase stamps of the compact AuxK select (-DSEL_STAMP builds only): [row][8] cycles since the row's start
+    if (!c->topk || !c->aux_dense) return fail(SAE_ERR_INVALID, "no AuxK buffers");
+    const int64_t rows = cap / 8 < c->last_M ? cap / 8 : c->last_M;
+    std::vector<unsigned long long> tmp((size_t)rows * 8);
+    HIP_TRY(hipMemcpy2D(tmp.data(), 64, reinterpret_cast<const char*>(c->aux_dense) + (size_t)c->n_p * 2 - 64, (size_t)c->n_p * 2, 64, (size_t)rows,
+                        hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < rows * 8; ++i) out[i] = (float)tmp[(size_t)i];
+    return SAE_OK;
+  }
   if (which == 5) {   // stamp sums of the diagnostic fused forward: [wg][wave][8] as floats
     const int64_t nq = (c->last_M / FF_BM) * 4 * 8;
     if (cap < nq) return fail(SAE_ERR_INVALID, "capacity too small");

@@ -376,6 +376,19 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   __shared__ int sc[4];
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
+#ifdef SEL_STAMP
+  // diagnostic build (tools/build_variant.sh selstamp -DSEL_STAMP; bench.py --dbg 67): s_memtime at the phase boundaries of the
+  // compact select, thread 0 of every row, into the last 64 bytes of the row's (otherwise unused) tail in `dense`
+  unsigned long long stamp_[8];
+  int nst_ = 0;
+#define SEL_MARK() do { if (COMPACT && t == 0 && nst_ < 8) stamp_[nst_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEL_FLUSH() do { if (COMPACT && t == 0) { unsigned long long* o_ = reinterpret_cast<unsigned long long*>(dense + (row + 1) * n_p) - 8; \
+    for (int i_ = 0; i_ < 8; ++i_) o_[i_] = i_ < nst_ ? stamp_[i_] - stamp_[0] : 0ull; } } while (0)
+#else
+#define SEL_MARK() do {} while (0)
+#define SEL_FLUSH() do {} while (0)
+#endif
+  SEL_MARK();
   if (only_flagged && !only_flagged[row]) return;     // the tile-driven kernel already selected this row
   const int k_req = k_ptr ? *k_ptr : k_fixed;
   if (k_ptr && k_req <= 0) return;      // AuxK pass without dead latents: nothing downstream reads its outputs (block-uniform)
@@ -423,6 +436,19 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     for (int v = 0; v < MAXV; ++v) cbits[v] = (v * 256 + t < nvec) ? (unsigned)vec_bits[v * 256 + t] : 0u;
   }
   auto cbits_of = [&](int v, int g) -> unsigned { return CBITS_AHEAD ? cbits[CBITS_AHEAD ? v : 0] : (g < nvec ? (unsigned)vec_bits[g] : 0u); };
+  // Round 4: ALL of the thread's row loads are issued before the first one is used (MAXV <= 12).  With the load and its masking in
+  // one loop body hipcc waited for every vector in turn -- twelve dependent HBM latencies, 24 k of a row's 35 k cycles in the
+  // compact select (stamps: `-DSEL_STAMP`, bench.py --dbg 67).
+  constexpr bool LOADS_AHEAD = MAXV <= 12;
+  if (LOADS_AHEAD) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int g = v * 256 + t;
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (g < nvec && (!COMPACT || cbits_of(v, g) != 0u)) w = __builtin_nontemporal_load(src + g);
+      keys[v] = w;
+    }
+  }
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int g = v * 256 + t;
@@ -432,7 +458,8 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
       // read exactly once (3.2 GB at C3): keep it out of the caches' way.  COMPACT: vectors without a dead column are not
       // read at all (with few dead latents that is most of the row)
       const unsigned cbv = COMPACT ? cbits_of(v, g) : 0u;
-      if (!COMPACT || cbv != 0u) w = __builtin_nontemporal_load(src + g);
+      if (LOADS_AHEAD) w = keys[v];
+      else if (!COMPACT || cbv != 0u) w = __builtin_nontemporal_load(src + g);
       if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
         cb = 0xFFu;
       } else {
@@ -460,8 +487,10 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   int ncand_l = 0;
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) ncand_l += __popc(cand[v]);
+  SEL_MARK();                                          // [1] row loaded and masked
   int ncand;
   (void)block_excl_scan_256(ncand_l, sc, &ncand);
+  SEL_MARK();                                          // [2] candidate count
   const int k = k_req < ncand ? k_req : ncand;     // where(dead, pre, -inf).topk(k_aux): k_aux <= num_dead by construction
   if (k <= 0) {
     if (write_dense) {
@@ -523,11 +552,18 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     if ((t & 63) == 0) wave_lb[t >> 6] = lo;
     __syncthreads();
     const unsigned int L = min(min(wave_lb[0], wave_lb[1]), min(wave_lb[2], wave_lb[3]));
-    if (L > 0) {                                       // block-uniform
+    SEL_MARK();                                        // [3] lower bound L
+    // L == 0: one of the waves holds fewer than kw positive values.  The main selection then goes to the counting probes below;
+    // the COMPACT (AuxK) select takes the candidate path all the same with EVERY positive key as a candidate -- dead latents are
+    // dead because their pre-activations are mostly negative, so a row has only a few hundred positive dead values, about k_aux
+    // of them: round 3 sent every such row (ALL rows of the C3 bench with 31 % dead, stamps of round 4) through ~17 block-wide
+    // probes over all 96 keys per thread, 106 k of the row's 136 k cycles.
+    const unsigned int Lc = (COMPACT && L == 0u) ? 1u : L;
+    if (Lc > 0) {                                      // block-uniform
       // Append the keys >= L to this WAVE's segment of the candidate list: positions come from a ballot + lane prefix and a
       // wave-uniform running count -- no LDS atomics (an add-with-return per hit cost a ~100-cycle round trip each; this
       // loop was 60 % of the kernel), and the scalar branch skips the pairs in which no lane of the wave has a hit.
-      const unsigned int lp = L * 0x00010001u;
+      const unsigned int lp = Lc * 0x00010001u;
       const int wv = t >> 6, lane = t & 63;
       unsigned int* seg = cand_pk + wv * TOPK_SEG_CAP;
       int wcount = 0;                                  // wave-uniform
@@ -556,6 +592,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
       if (lane == 0) wave_cnt[wv] = wcount;
       topk_pad_segment<TOPK_SEG_CAP>(seg, wcount, lane);
       __syncthreads();
+      SEL_MARK();                                      // [4] candidates appended
       const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
       const int C = c0 + c1 + c2 + c3;
       const bool fits = c0 <= TOPK_SEG_CAP && c1 <= TOPK_SEG_CAP && c2 <= TOPK_SEG_CAP && c3 <= TOPK_SEG_CAP;
@@ -576,59 +613,81 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
             mine[u] = cand_pk[sg * TOPK_SEG_CAP + li];
           }
         }
+        if (C <= k) {      // (only with Lc = 1: no more positive dead latents than k_aux in this row) every candidate is selected; the
+                           // zeros that fill the selection up carry neither activation nor gradient
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (mine[u] != 0u) crow[cpos((int)(0x1FFFFu - (mine[u] & 0x1FFFFu)))] = (unsigned short)(mine[u] >> 17);
+          SEL_MARK();
+          SEL_FLUSH();
+          return;
+        }
 #ifndef SEL_BINSEARCH
-        // Round 4: the k-th largest candidate by ONE histogram instead of a binary search over the 32-bit word (up to 32 probes,
-        // a block barrier each: the search was the larger part of this kernel at k_aux = 384, C ~ 450-600).  Candidates are
-        // >= L, and bf16 keys within two octaves of L differ from it by < 256: bin = min(255, key - L), an LDS add per
-        // candidate, a suffix scan over the 256 bins (one block scan) finds the bin B that holds the k-th largest and how many of
-        // its members are needed.  Bins above B are selected whole; bin B is ONE key value (unless it is the overflow bin), so its
-        // members tie on the value and the rule "lowest column first" ranks them: they go to a short list and count the
-        // members above them.  The overflow bin with more members than needed, or a bin B with > 256 members, falls back to the
-        // binary search below (block-uniform).
+        // Round 4: the k-th largest candidate by a two-level RADIX select instead of a binary search over the 32-bit word (up to 32
+        // probes, a block barrier each).  Level 1: histogram over the key's upper 8 bits (sign-free bf16: the exponent) -- an LDS add
+        // per candidate, one block scan over the reversed bins finds the bin B1 that holds the k-th largest and how many of its
+        // members are needed; level 2: the same over the lower 7 bits (the mantissa) of B1's members; what is left ties on the
+        // VALUE, and the rule "lowest column first" ranks it: the members go to a short list and count the members above them.
+        // An oversized tie (> 256) falls back to the binary search below (block-uniform).
         __shared__ int hist[256];
         __shared__ int sel_bin, sel_need, tie_n;
         __shared__ unsigned int tie_list[256];
-        hist[t] = 0;
-        if (t == 0) tie_n = 0;
-        __syncthreads();
-        int mybin[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          mybin[u] = -1;
-          if (mine[u] != 0u) {
-            const unsigned int dk = (mine[u] >> 17) - L;
-            mybin[u] = dk < 255u ? (int)dk : 255;
-            atomicAdd(&hist[mybin[u]], 1);
-          }
-        }
-        __syncthreads();
-        {
-          const int hr = hist[255 - t];                       // reversed: the prefix over t is the suffix over the bins
-          int tot;
-          const int excl = block_excl_scan_256(hr, sc, &tot);
-          if (excl < k && k <= excl + hr) {                   // exactly one thread (C >= k, hr > 0 there)
-            sel_bin = 255 - t;
-            sel_need = k - excl;
-          }
-        }
-        __syncthreads();
-        const int B = sel_bin, need = sel_need, inB = hist[B];
-        const bool take_all = need == inB;
-        if (take_all || (B < 255 && inB <= 256)) {            // block-uniform
+        int B1 = 0, need1 = 0, B2 = -1, need2 = 0, inB2 = 0;
+        bool all1 = false, all2 = false;
+#pragma unroll 1
+        for (int level = 0; level < 2; ++level) {
+          hist[t] = 0;
+          if (t == 0) tie_n = 0;
+          __syncthreads();
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (!take_all && mybin[u] == B) tie_list[atomicAdd(&tie_n, 1)] = mine[u];
-          if (!take_all) __syncthreads();
+            if (mine[u] != 0u) {
+              const int b1 = (int)(mine[u] >> 24), b2 = (int)((mine[u] >> 17) & 127u);
+              if (level == 0) atomicAdd(&hist[b1], 1);
+              else if (b1 == B1) atomicAdd(&hist[b2], 1);
+            }
+          __syncthreads();
+          const int hr = hist[255 - t];                       // reversed: the prefix over t is the suffix over the bins
+          const int want = level == 0 ? k : need1;
+          int tot;
+          const int excl = block_excl_scan_256(hr, sc, &tot);
+          if (excl < want && want <= excl + hr) {             // exactly one thread (the bins hold >= want candidates, hr > 0 there)
+            sel_bin = 255 - t;
+            sel_need = want - excl;
+          }
+          __syncthreads();
+          if (level == 0) {
+            B1 = sel_bin; need1 = sel_need;
+            all1 = need1 == hist[B1];
+            if (all1) break;                                  // (block-uniform) the whole bin is needed: no second level
+          } else {
+            B2 = sel_bin; need2 = sel_need; inB2 = hist[B2];
+            all2 = need2 == inB2;
+          }
+          __syncthreads();                                    // hist is cleared again at the top of level 1
+        }
+        if (all1 || all2 || inB2 <= 256) {                    // block-uniform
+          const bool ties = !all1 && !all2;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            bool sel = mybin[u] > B || (take_all && mybin[u] == B);
-            if (!take_all && mybin[u] == B) {
+            const int b1 = (int)(mine[u] >> 24), b2 = (int)((mine[u] >> 17) & 127u);
+            if (ties && mine[u] != 0u && b1 == B1 && b2 == B2) tie_list[atomicAdd(&tie_n, 1)] = mine[u];
+          }
+          if (ties) __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (mine[u] == 0u) continue;
+            const int b1 = (int)(mine[u] >> 24), b2 = (int)((mine[u] >> 17) & 127u);
+            bool sel = b1 > B1 || (b1 == B1 && (all1 || b2 > B2 || (b2 == B2 && all2)));
+            if (ties && b1 == B1 && b2 == B2) {
               int above = 0;
-              for (int i = 0; i < inB; ++i) above += tie_list[i] > mine[u] ? 1 : 0;
-              sel = above < need;
+              for (int i = 0; i < inB2; ++i) above += tie_list[i] > mine[u] ? 1 : 0;
+              sel = above < need2;
             }
             if (sel) crow[cpos((int)(0x1FFFFu - (mine[u] & 0x1FFFFu)))] = (unsigned short)(mine[u] >> 17);
           }
+          SEL_MARK();                                  // [5] selected and stored
+          SEL_FLUSH();
           return;
         }
 #endif
@@ -702,6 +761,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   }
   if (done) return;
   __syncthreads();
+  SEL_MARK();                                          // (slow path) [k] fast path not taken
 
   // ---- largest T in [1, 0x8000] with count(key >= T) >= k; T = 0 if fewer than k positive keys
   const int npos = topk_count_ge<MAXV>(keys, 1u, t, red);
@@ -812,6 +872,14 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     }
   }
   for (int j = sel_tot + t; j < kcap; j += 256) ti[j] = -1;
+#ifdef SEL_STAMP
+  SEL_MARK();                                          // slow path done
+  if (COMPACT && t == 0) {                              // slot 7 = 1000 + marks: tells the slow path from the histogram path (slot 7 = 0)
+    unsigned long long* o_ = reinterpret_cast<unsigned long long*>(dense + (row + 1) * n_p) - 8;
+    for (int i_ = 0; i_ < 7; ++i_) o_[i_] = i_ < nst_ ? stamp_[i_] - stamp_[0] : 0ull;
+    o_[7] = 1000ull + (unsigned long long)nst_;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -877,15 +945,24 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
   const unsigned int lp = L * 0x00010001u;
   unsigned int* seg = cand_pk + wv * SEG;
   int wcount = 0;
+  // Round 4: every load of the thread is issued before the first is used (the ballots below are wave-level control flow: with the
+  // load inside that loop each of the up to twelve vectors cost a full dependent memory latency)
+  u32x4 wv_[TSEL_VEC];
+  int col0_[TSEL_VEC];
 #pragma unroll
   for (int v = 0; v < TSEL_VEC; ++v) {
     const int vi = v * 256 + t;
-    u32x4 w = {0u, 0u, 0u, 0u};
-    int col0 = 0;
+    wv_[v] = u32x4{0u, 0u, 0u, 0u};
+    col0_[v] = 0;
     if (vi < nv) {
-      col0 = (int)tlist[vi >> 4] * 128 + (vi & 15) * 8;
-      w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + row * n_p + col0));
+      col0_[v] = (int)tlist[vi >> 4] * 128 + (vi & 15) * 8;
+      wv_[v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + row * n_p + col0_[v]));
     }
+  }
+#pragma unroll
+  for (int v = 0; v < TSEL_VEC; ++v) {
+    const u32x4 w = wv_[v];
+    const int col0 = col0_[v];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned int hit = ((w[q] | 0x80008000u) - lp) & 0x80008000u;
