@@ -96,8 +96,8 @@ void freud_convert_piece(const float* base, int64_t idx, size_t row_elems, size_
 }
 
 // ---- a small persistent thread pool (pthreads; no OpenMP: the process already hosts torch's OpenMP runtime, and a second one
-// in a helper library is a known source of oversubscription and fork trouble).  One job at a time (the loader's gather worker is
-// the only caller); workers sleep on a condition variable between jobs; work items are handed out by an atomic counter; the
+// in a helper library is a known source of oversubscription and fork trouble).  One job at a time (callers queue on a mutex: a process may run
+// a training and a validation loader); workers sleep on a condition variable between jobs; work items are handed out by an atomic counter; the
 // calling thread works too.
 #define POOL_MAX 64
 typedef void (*item_fn)(long item, void* arg);
@@ -144,12 +144,15 @@ static void* pool_worker(void* idp) {
   return NULL;
 }
 
+static pthread_mutex_t g_job_mu = PTHREAD_MUTEX_INITIALIZER;      // one job at a time: a process may run two loaders (training + validation)
+
 static void pool_parallel_for(long items, int nthreads, item_fn fn, void* arg) {
   if (nthreads > POOL_MAX + 1) nthreads = POOL_MAX + 1;
   if (nthreads <= 1 || items <= 1) {
     for (long it = 0; it < items; ++it) fn(it, arg);
     return;
   }
+  pthread_mutex_lock(&g_job_mu);
   pthread_mutex_lock(&g_pool.mu);
   while (g_pool.nth < nthreads - 1) {              // the caller is the last "thread" of the job
     if (pthread_create(&g_pool.th[g_pool.nth], NULL, pool_worker, (void*)(intptr_t)g_pool.nth) != 0) break;
@@ -166,6 +169,7 @@ static void pool_parallel_for(long items, int nthreads, item_fn fn, void* arg) {
   pthread_mutex_lock(&g_pool.mu);
   while (__atomic_load_n(&g_pool.active, __ATOMIC_ACQUIRE) != 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
   pthread_mutex_unlock(&g_pool.mu);
+  pthread_mutex_unlock(&g_job_mu);
 }
 
 // A whole batch in ONE call (round 4): rows idx[0..count) -> consecutive rows of dst, cut into pieces and spread over `nthreads`

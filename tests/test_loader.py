@@ -151,3 +151,39 @@ def test_gather_pool_splits_rows_into_pieces(tmp_path):
     assert len(got[1]) == 2
     for a, b in zip(got[1], got[12]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_two_loaders_share_the_host_thread_pool(tmp_path):
+    """libfreud_host.so has ONE thread pool; a process may run two loaders at once (training + validation).  Two Python threads
+    gathering concurrently must each get exactly their own rows."""
+    import threading
+    import numpy as np
+    import torch
+    from freud_amd.loader import MemoryMappedActivationDataLoader, write_shards
+    T, d, n_files = 64, 48, 24
+    rows = (torch.randn(n_files, T * d, generator=torch.Generator().manual_seed(4)) * 2).numpy().astype(np.float32)
+    folder = str(tmp_path / "f32")
+    write_shards(folder, "L", rows, [T, d])
+    from freud_amd.loader import _host_lib
+    ref_np = np.zeros(rows.shape, np.uint16)          # the library's own single-thread conversion (the -1.0 guard differs from torch's cast)
+    _host_lib().freud_f32_to_bf16_portable(rows.ctypes.data, ref_np.ctypes.data, rows.size)
+    ref = torch.from_numpy(ref_np.view(np.int16))
+    errors = []
+
+    def run(seed):
+        try:
+            for _ in range(20):
+                dl = MemoryMappedActivationDataLoader(folder, "L", 4, 6, None, {"shuffle": False, "drop_last": True}, deliver_dtype="bfloat16")
+                for bi, (x, _names) in enumerate(dl):
+                    got = x.reshape(4, T * d).view(torch.int16)
+                    if not torch.equal(got, ref[4 * bi: 4 * bi + 4]):
+                        errors.append((seed, bi))
+        except Exception as e:          # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(s,)) for s in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors[:3]
