@@ -187,6 +187,12 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the train step)"
+    # FREUD_BENCH_SHARE_GPU=1 (tests): every rank on GPU 0 with gloo as the host channel -- two RCCL ranks cannot share a device,
+    # the engine's own peer exchange can (tests/test_dp_gpu.py), so the N > 1 control flow of this file runs on a one-GPU box
+    share_gpu = os.environ.get("FREUD_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
+    ctrl_dev = "cpu" if share_gpu else "cuda"             # where the control tensors of the collectives below live
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = world > 1 or args.force_dist
@@ -204,7 +210,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from freud_amd.engine import SaeEngine
 
@@ -276,7 +285,7 @@ def main():
                 torch.cuda.synchronize()
                 elapsed = time.perf_counter() - t_spin
                 if use_dist:                     # every rank must leave after the same number of (collective) steps
-                    te = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+                    te = torch.tensor([elapsed], device=ctrl_dev, dtype=torch.float64)
                     dist.all_reduce(te, op=dist.ReduceOp.MAX)
                     elapsed = float(te.item())
                 if elapsed >= args.spinup:
@@ -318,7 +327,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device=ctrl_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         healthy = True
@@ -328,7 +337,7 @@ def main():
             except Exception as e:          # noqa: BLE001
                 print(f"[rank {rank}] in-engine exchange failed during the run: {e}", file=sys.stderr)
                 healthy = False
-            flag = torch.tensor([1 if healthy else 0], device="cuda", dtype=torch.int32)
+            flag = torch.tensor([1 if healthy else 0], device=ctrl_dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same decision
             healthy = int(flag.item()) == 1
             if healthy and world > 1:                        # replicas are bit-identical by construction: anything else is an exchange bug

@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_default_bench_line_follows_the_contract():
-    d = _line("r03_bench_default.json")
+    d = _line("r04_bench_default.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -44,6 +44,6 @@ def test_default_bench_line_follows_the_contract():
 
 
 def test_driver_style_line_has_enough_kernel_samples():
-    d = _line("r03_bench_default_driver_style.json")
+    d = _line("r04_bench_default_driver_style.json")
     assert d["steps"] == 20 and d["warmup"] == 5
     assert d["roofline"]["kernel_launches"] >= 10        # every step of a short run is bracketed

@@ -567,3 +567,67 @@ def test_param_checksum_is_deterministic_and_sensitive():
     assert sums[0] == sums[1] and sums[0][3] == 2
     assert sums[2][0] != sums[0][0]
 
+
+
+def _run_bench_ranks(world, extra_args, extra_env=None, timeout=900):
+    """bench.py as `world` processes on GPU 0, launched the way the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in the environment) with FREUD_BENCH_SHARE_GPU=1: every rank on device 0, gloo as the host channel (two RCCL ranks cannot share
+    a device; the engine's own peer exchange can).  Returns [(rc, stdout, stderr)] by rank."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, FREUD_BENCH_SHARE_GPU="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)] + extra_args, env=env,
+                                      cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for pr in procs:
+            so, se = pr.communicate(timeout=timeout)
+            res.append((pr.returncode, so, se))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_with_several_ranks_prints_one_line_with_the_guards_verdict(world):
+    """The N > 1 flow of bench.py -- the one the driver's scaling run takes -- end to end on one GPU: set-up of the peer exchange
+    (start-up self-test), audited warm-up steps (the exchanged gradient against a torch.distributed all-reduce of the same
+    contributions), barrier-bracketed timed region, max over ranks, replica checksums after the run, ONE JSON line from rank 0
+    whose value is the whole job's rows over that time."""
+    import json
+    res = _run_bench_ranks(world, ["--steps", "6", "--warmup", "4", "--rows", "8192", "--no-cpu-baseline", "--spinup", "0"])
+    for rc, so, se in res:
+        assert rc == 0, se[-3000:]
+    lines = [[l for l in so.splitlines() if l.startswith("{")] for _, so, _ in res]
+    assert len(lines[0]) == 1 and all(len(l) == 0 for l in lines[1:]), lines
+    d = json.loads(lines[0][0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["parallelism"] == f"dp{world}"
+    assert d["value"] == pytest.approx(8192 * world / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["config"]["dp"].startswith("in-engine peer exchange"), d["config"]["dp"]
+    g = d["config"]["dp_guards"]
+    assert g["audited_steps"] == 3 and g["max_rel_diff_vs_torch_distributed"] < 1e-5, g
+    assert g["replica_checksums"] == "identical" and g["replica_checksums_after_run"] == "identical", g
+    assert np.isfinite(d["loss"]["recon"]) and d["roofline"]["kernel_launches"] >= 6
+
+
+def test_bench_with_a_broken_peer_exchange_falls_back_and_says_so():
+    """Same launch with a fault injected into the peer exchange AFTER its start-up self-test (one shard of the all-gather is not
+    copied on rank 1): the audit of the first warm-up step catches it on every rank, the measurement is repeated from scratch on
+    the next carrier (host-driven here: two RCCL ranks cannot share this GPU), and the line carries the reason."""
+    import json
+    res = _run_bench_ranks(2, ["--steps", "4", "--warmup", "3", "--rows", "8192", "--no-cpu-baseline", "--spinup", "0"],
+                           {"FREUD_P2P_FAULT": "skip_phase2:1:12", "FREUD_P2P_TIMEOUT_MS": "20000"})
+    for rc, so, se in res:
+        assert rc == 0, se[-3000:]
+    d = json.loads([l for l in res[0][1].splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["dp"].startswith("host-driven"), d["config"]["dp"]
+    assert "fallback" in d["config"]["dp"] and "differs from the gloo all-reduce" in d["config"]["dp"], d["config"]["dp"]
+    assert np.isfinite(d["loss"]["recon"])
