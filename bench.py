@@ -499,6 +499,17 @@ def main():
             d_ = np.diff(st[:, :6], axis=1)
             print("AuxK compact select, cycles per row (median over %d rows): %s | total %.0f" %
                   (len(st), ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, np.median(d_, axis=0))), np.median(st[:, 5])), file=sys.stderr)
+    if args.dbg == 68 and rank == 0 and args.variant == "topk":     # -DTSEL_STAMP builds: phase stamps of the tile-driven main select
+        st = eng.debug_read(12, 4096 * 8).reshape(-1, 8)
+        st = st[st[:, 6] > 0]
+        if len(st):
+            names = ["tile maxima in registers", "L + candidate tile list", "candidate tiles in registers", "candidates appended",
+                     "block barrier", "ranked + stored"]
+            d_ = np.diff(st[:, :7], axis=1)
+            print("tile-driven select, shader cycles per row (median over %d rows): %s | total %.0f | "
+                  "candidates %.0f, candidate tiles %.0f (median)" %
+                  (len(st), ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, np.median(d_, axis=0))), np.median(st[:, 6]),
+                   np.median(st[:, 7] // 1000), np.median(st[:, 7] % 1000)), file=sys.stderr)
     if args.variant == "topk":
         out["metric"] = f"SAE train activations/sec (TopK d={d} n={n} k={args.k})"
         out["config"]["workload"] = (f"TopK SAE d={d} n={n} k={args.k} train step, M={M} rows/GPU/step, Adam, x {args.x_dtype} "

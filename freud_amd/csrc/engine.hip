@@ -176,7 +176,7 @@ struct sae_ctx {
   float *e = nullptr, *dh = nullptr, *e2_part = nullptr, *a2_part = nullptr, *dbd_part = nullptr, *ds_part = nullptr, *tkf = nullptr;
   int *top_idx = nullptr, *aux_idx = nullptr, *tk = nullptr;
   bf16_t *top_vals = nullptr, *aux_vals = nullptr, *multi_vals = nullptr;   // selected activations, compact [M_p][kcap]
-  unsigned short* tile_max = nullptr;   // [M_p][n_p / 128] maxima of the pre-activation tiles (tile-driven select)
+  unsigned short* tile_max = nullptr;   // [M_p][n_p / 64] maxima of the pre-activation tiles (tile-driven select)
   unsigned char* sel_flag = nullptr;    // [M_p] rows the tile-driven select left to the general kernel
   bool dense_valid = false;     // the masked dense rows of the last forward were written (else: topk_densify on demand)
   bool multi_dense_valid = false;   // the same for the multi-TopK (4k) rows
@@ -409,7 +409,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   TALLOC(c->top_idx, Mp * c->k * 4);
   TALLOC(c->aux_idx, Mp * c->k_aux_cap * 4);
   TALLOC(c->top_vals, Mp * c->k * 2);
-  TALLOC(c->tile_max, Mp * (c->n_p / 128) * 2);
+  TALLOC(c->tile_max, Mp * (c->n_p / TSEL_TILE) * 2);
   TALLOC(c->sel_flag, Mp);
   TALLOC(c->aux_vals, Mp * c->k_aux_cap * 2);
   HIP_TRY(hipHostMalloc((void**)&c->dead_hint, 64, hipHostMallocDefault));
@@ -1977,7 +1977,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
   c->multi_dense_valid = write_dense;
   // tile-driven main select (topk_select_tiles_kernel): when no dense row is wanted, every column is a candidate and k fits
   // (rows it cannot take -- too many qualifying tiles or candidates -- fall to the register kernel: n_p <= 2048 * 44)
-  const bool tile_select = !write_dense && n == n_p && k <= n_p / 128 && n_p / 128 <= TSEL_MAX_TILES && n_p <= 2048 * 44 &&
+  const bool tile_select = !write_dense && n == n_p && k <= n_p / TSEL_TILE && n_p / TSEL_TILE <= TSEL_MAX_TILES && n_p <= 2048 * 44 &&
                            c->cfg.debug_flags != 75;
 
   {
@@ -2033,8 +2033,12 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     // did_fire follows out.encoded.top_indices (train_sae.py:442), which forward() re-binds to the 4k selection when
     // cfg.multi_topk is set (topkautoencoder.py:135)
     if (tile_select) {
-      hipLaunchKernelGGL(topk_select_tiles_kernel, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->tile_max, c->top_idx,
-                         reinterpret_cast<unsigned short*>(c->top_vals), c->multi ? (float*)nullptr : did_fire, k, k, n_p, M, c->sel_flag);
+      if (n_p <= 4096 * 8)
+        hipLaunchKernelGGL(topk_select_tiles_kernel<8>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->tile_max, c->top_idx,
+                           reinterpret_cast<unsigned short*>(c->top_vals), c->multi ? (float*)nullptr : did_fire, k, k, n_p, M, c->sel_flag);
+      else
+        hipLaunchKernelGGL(topk_select_tiles_kernel<32>, dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->tile_max, c->top_idx,
+                           reinterpret_cast<unsigned short*>(c->top_vals), c->multi ? (float*)nullptr : did_fire, k, k, n_p, M, c->sel_flag);
       only_flagged = c->sel_flag;      // the general kernel below then only takes the rows flagged as left over
     }
     launch_select(c->dense, c->top_idx, c->top_vals, c->multi ? (float*)nullptr : did_fire, nullptr, nullptr, k, k);
@@ -2553,6 +2557,15 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     for (int64_t i = 0; i < nq; ++i) out[i] = (float)tmp[(size_t)i];
     return SAE_OK;
   }
+#ifdef TSEL_STAMP
+  if (which == 12) {   // phase stamps of the tile-driven main select (-DTSEL_STAMP builds only): [row][8] cycles since the row's start
+    const int64_t rows = cap / 8 < 4096 ? cap / 8 : 4096;
+    std::vector<unsigned long long> tmp((size_t)rows * 8);
+    HIP_TRY(hipMemcpyFromSymbol(tmp.data(), HIP_SYMBOL(tsel_stamp_buf), tmp.size() * 8, 0, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < rows * 8; ++i) out[i] = (float)tmp[(size_t)i];
+    return SAE_OK;
+  }
+#endif
   if (which == 11) {   // phase stamps of the compact AuxK select (-DSEL_STAMP builds only): [row][8] cycles since the row's start
     if (!c->topk || !c->aux_dense) return fail(SAE_ERR_INVALID, "no AuxK buffers");
     const int64_t rows = cap / 8 < c->last_M ? cap / 8 : c->last_M;

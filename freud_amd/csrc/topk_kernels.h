@@ -91,7 +91,7 @@ __global__ __launch_bounds__(1024) void dead_mask_kernel(const long long* __rest
 }
 
 // encoder epilogue: pre = relu(bf16(acc + bias)) (Linear under autocast: bf16 addmm, one rounding), rows >= M zero
-// tmax != null: also the maximum of every (row, 128-column tile) for the tile-driven select (topk_select_tiles_kernel), which
+// tmax != null: also the maximum of every (row, 64-column tile) for the tile-driven select (topk_select_tiles_kernel), which
 // then reads only the tiles that can hold one of the row's k largest values.
 // The arithmetic is done on PACKED bf16 pairs: v_cvt_pk_bf16_f32 rounds two sums at once, ReLU is a signed 16-bit max with 0
 // (negative floats are negative as int16), the maximum is an unsigned 16-bit max (values >= 0: the pattern orders like the
@@ -103,7 +103,7 @@ struct EpiTopkEnc {
   const float* bias;    // [n_p] fp32 master ALREADY ROUNDED to bf16 (round_bias_kernel: autocast casts it)
   int64_t M;
   int n_p;
-  unsigned short* tmax; // [M_p][n_p / 128] bf16 bit patterns, or null
+  unsigned short* tmax; // [M_p][n_p / 64] bf16 bit patterns (maxima of 64-column tiles), or null
   typedef __attribute__((ext_vector_type(2))) short s16x2;
   typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
   typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -146,13 +146,14 @@ struct EpiTopkEnc {
     lds_barrier();
     if (t < 128) {
       const u32x4* r = reinterpret_cast<const u32x4*>(sc + t * PITCH);
-      unsigned int m = 0;
+      unsigned int m[2] = {0u, 0u};                     // entry e of the row = the maximum of columns 4 e .. 4 e + 3
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const u32x4 w = r[q];
-        m = max(max(m, w[0]), max(max(w[1], w[2]), w[3]));
+        m[q >> 2] = max(max(m[q >> 2], w[0]), max(max(w[1], w[2]), w[3]));
       }
-      tmax[(int64_t)(row0_ + t) * (n_p >> 7) + (col0_ >> 7)] = (unsigned short)m;
+      // two 64-column maxima per row and 128-column sub-tile, one 4-byte store (the row pitch n_p / 64 is even)
+      *reinterpret_cast<unsigned int*>(tmax + (int64_t)(row0_ + t) * (n_p >> 6) + (col0_ >> 6)) = m[0] | (m[1] << 16);
     }
   }
 };
@@ -884,29 +885,45 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
 
 // ------------------------------------------------------------------------------------------
 // Tile-driven select (training, main selection: no dead filter, no dense row): the encoder GEMM's epilogue left the
-// maximum of every 128-column tile of the row (EpiTopkEnc::tmax).  The k-th largest tile maximum L is a provable lower
+// maximum of every 64-column tile of the row (EpiTopkEnc::tmax).  The k-th largest tile maximum L is a provable lower
 // bound of the k-th largest value (k tiles hold a value >= L each), so only the tiles whose maximum reaches L can hold a
-// selected value: typically a third of the row is read instead of all of it.  The keys >= L of those tiles are ranked
+// selected value: k tiles unless maxima tie -- a sixth of the row at C3 (64 of 384 tiles) instead of all of it.  The keys >= L of those tiles are ranked
 // exactly like in topk_select_reg_kernel's fast path (one sortable word per candidate: value, then lowest column).
 // Returns 0 work for rows it cannot take (flag[row] = 1: more than the candidate capacity, or L == 0) -- the caller runs
 // topk_select_reg_kernel afterwards with `only_flagged`, which skips the rows done here.
 // ------------------------------------------------------------------------------------------
-constexpr int TSEL_MAX_TILES = 1024;     // n_p <= 131072
-constexpr int TSEL_VEC = 12;             // 16-byte vectors per thread at most (3072 vectors = 192 tiles)
+constexpr int TSEL_TILE = 64;            // columns per tile maximum (round 3: 128 -- twice the candidate bytes and compaction work per row)
+constexpr int TSEL_MAX_TILES = 2048;     // n_p <= 131072
+constexpr int TSEL_VEC = 8;              // 16-byte vectors per thread at most (2048 vectors = 256 tiles; rows with more are left to the general kernel)
+#ifdef TSEL_STAMP
+// diagnostic build (tools/build_variant.sh tselstamp -DTSEL_STAMP; bench.py --dbg 68): s_memtime at the phase boundaries of the first
+// 4096 rows, wave 0: [row][8] = cycles since the row's start
+__device__ unsigned long long tsel_stamp_buf[4096 * 8];
+#define TSEL_MARK() do { if (t == 64 * lead && nst_ < 8) stamp_[nst_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSEL_FLUSH() do { if (t == 64 * lead && row < 4096) { for (int i_ = 0; i_ < 8; ++i_) tsel_stamp_buf[row * 8 + i_] = i_ < nst_ ? stamp_[i_] - stamp_[0] : 0ull; } } while (0)
+#else
+#define TSEL_MARK() do {} while (0)
+#define TSEL_FLUSH() do {} while (0)
+#endif
+template <int NPER>                     // tile maxima per lane: n_p <= 4096 NPER (8: C3's 384 tiles; 32: any supported n_p)
 __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __restrict__ pre, const unsigned short* __restrict__ tmax,
                                                                 int* __restrict__ top_idx, unsigned short* __restrict__ vals,
                                                                 float* __restrict__ did_fire, int k, int kcap, int n_p, int64_t M,
                                                                 unsigned char* __restrict__ flag) {
   constexpr int SEG = 256;
-  __shared__ __attribute__((aligned(16))) unsigned short tm[TSEL_MAX_TILES + 8];
   __shared__ unsigned short tlist[TSEL_MAX_TILES];
   __shared__ __attribute__((aligned(16))) unsigned int cand_pk[4 * SEG];
   __shared__ int wave_cnt[4];
-  __shared__ int nq_s;
-  __shared__ unsigned int L_s;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int64_t row = blockIdx.x;
-  const int ntiles = n_p >> 7;
+  const int ntiles = n_p / TSEL_TILE;
+  // The row's leader wave runs the descent below and ranks the first 64 candidates at the end.  (Rotating the leader with a hash
+  // of the row -- in case wave 0 of every workgroup shared a SIMD -- was 4 % SLOWER: 358 against 344 us, -DTSEL_ROTATE_LEADER.)
+#ifdef TSEL_ROTATE_LEADER
+  const int lead = (int)(((blockIdx.x >> 3) * 0x9E3779B1u) >> 30);
+#else
+  constexpr int lead = 0;
+#endif
   int* ti = top_idx + row * kcap;
   unsigned short* tv = vals + row * kcap;
   if (t == 0) flag[row] = 0;
@@ -914,55 +931,98 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
     for (int j = t; j < kcap; j += 256) ti[j] = -1;
     return;
   }
-  for (int i = t; i < ntiles; i += 256) tm[i] = tmax[row * ntiles + i];
-  if (t < 8) tm[ntiles + t] = 0;                    // pad to a multiple of 8 (a zero behind the last tile never outranks anything)
-  if (t == 0) nq_s = 0;
-  __syncthreads();
-  // L = k-th largest tile maximum: every tile ranks itself (ties by index) -- broadcast reads, 8 tile maxima per 16 bytes
-  for (int i = t; i < ntiles; i += 256) {
-    const unsigned int my = ((unsigned int)tm[i] << 16) | (unsigned int)(0xFFFF - i);
-    int rank = 0;
-    for (int j = 0; j < ntiles; j += 8) {
-      const u32x4 w = *reinterpret_cast<const u32x4*>(&tm[j]);
+#ifdef TSEL_STAMP
+  unsigned long long stamp_[8];
+  int nst_ = 0;
+#endif
+  TSEL_MARK();                                      // [0] start
+  // Round 4: WAVE 0 finds L and the candidate tiles in registers -- lane l holds the maxima of tiles l, l + 64, ...; L = the k-th
+  // largest maximum by a bitwise descent over the 15 value bits (bf16 patterns of non-negative numbers): "at least k maxima >= T"
+  // is one ballot + population count per 64 tiles, all on the scalar unit; the candidate list is the ballot's prefix order.  The
+  // other three waves wait at the barrier: a waiting wave takes no issue slots, and the kernel is issue-bound (DESIGN section 4
+  // "TopK": every wave running the descent for itself, without the barrier, was 6 % slower).
+  __shared__ unsigned int L_s;
+  __shared__ int nq_s;
+  if (wv == lead) {
+    static_assert(NPER * 64 <= TSEL_MAX_TILES, "tlist");
+    unsigned int tmv[NPER];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const unsigned int key = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-        rank += (((key << 16) | (unsigned int)(0xFFFF - (j + e))) > my) ? 1 : 0;
+    for (int q = 0; q < NPER; ++q) {
+      tmv[q] = 0u;
+      if (64 * q < ntiles) {                            // (uniform)
+        const int i = 64 * q + lane;
+        if (i < ntiles) tmv[q] = tmax[row * ntiles + i];
       }
     }
-    if (rank == k - 1) L_s = tm[i];
+#ifdef TSEL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TSEL_MARK();                                      // [1] tile maxima in registers
+    unsigned int Lw = 0u;
+#pragma unroll 1
+    for (int bit = 14; bit >= 0; --bit) {
+      const unsigned int T = Lw | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int q = 0; q < NPER; ++q)
+        if (64 * q < ntiles) cnt += (int)__popcll(__ballot(tmv[q] >= T));
+      if (cnt >= k) Lw = T;
+    }
+    int nqw = 0;
+    if (Lw != 0u) {
+#pragma unroll
+      for (int q = 0; q < NPER; ++q)
+        if (64 * q < ntiles) {
+          const bool mine = tmv[q] >= Lw;
+          const unsigned long long bm = __ballot(mine);
+          if (mine) tlist[nqw + (int)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)(64 * q + lane);
+          nqw += (int)__popcll(bm);
+        }
+    }
+    if (lane == 0) {
+      L_s = Lw;
+      nq_s = nqw;
+    }
   }
   __syncthreads();
   const unsigned int L = L_s;
-  if (L == 0) {                                     // fewer than k tiles with a positive value: the general kernel takes the row
+  if (L == 0u) {                                    // fewer than k tiles with a positive value: the general kernel takes the row
     if (t == 0) flag[row] = 1;
     return;
   }
-  for (int i = t; i < ntiles; i += 256)
-    if (tm[i] >= L) tlist[atomicAdd(&nq_s, 1)] = (unsigned short)i;      // order irrelevant (candidates are ranked by value / column)
-  __syncthreads();
-  const int nv = nq_s * 16;                          // 16-byte vectors to read
+  const int nq = nq_s;
+  constexpr int VPT = TSEL_TILE / 8;                 // 16-byte vectors per tile
+  const int nv = nq * VPT;                           // 16-byte vectors to read
+  TSEL_MARK();                                      // [2] L and the candidate tile list
   const unsigned int lp = L * 0x00010001u;
   unsigned int* seg = cand_pk + wv * SEG;
-  int wcount = 0;
-  // Round 4: every load of the thread is issued before the first is used (the ballots below are wave-level control flow: with the
-  // load inside that loop each of the up to twelve vectors cost a full dependent memory latency)
+  // Round 4: every load of the thread is issued before the first is used (with the load inside the compaction loop each of the
+  // up to twelve vectors cost a full dependent memory latency); vector slots past the row's candidate tiles are skipped
+  // block-uniformly (two of the eight slots are in use at C3).
   u32x4 wv_[TSEL_VEC];
-  int col0_[TSEL_VEC];
 #pragma unroll
   for (int v = 0; v < TSEL_VEC; ++v) {
-    const int vi = v * 256 + t;
     wv_[v] = u32x4{0u, 0u, 0u, 0u};
-    col0_[v] = 0;
-    if (vi < nv) {
-      col0_[v] = (int)tlist[vi >> 4] * 128 + (vi & 15) * 8;
-      wv_[v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + row * n_p + col0_[v]));
+    if (v * 256 < nv) {
+      const int vi = v * 256 + t;
+      if (vi < nv)
+        wv_[v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pre + row * n_p + (int)tlist[vi / VPT] * TSEL_TILE + (vi % VPT) * 8));
     }
   }
+#ifdef TSEL_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TSEL_MARK();                                      // [3] candidate tiles in registers
+#ifndef TSEL_SCAN_COMPACT
+  // compaction: one ballot per dword and one per 16-bit half with a hit (about one value in a hundred of the candidate tiles
+  // reaches L, but a wave's 512 values per vector nearly always hold some, so nearly every branch below is taken)
+  int wcount = 0;
 #pragma unroll
   for (int v = 0; v < TSEL_VEC; ++v) {
+    if (v * 256 >= nv) continue;
     const u32x4 w = wv_[v];
-    const int col0 = col0_[v];
+    const int vi = v * 256 + t;
+    const int col0 = vi < nv ? (int)tlist[vi / VPT] * TSEL_TILE + (vi % VPT) * 8 : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned int hit = ((w[q] | 0x80008000u) - lp) & 0x80008000u;
@@ -982,16 +1042,63 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
       }
     }
   }
+#else
+  // Tried in round 4 (-DTSEL_SCAN_COMPACT), NOT faster (kernel 391 against 379 us, profiles/r04_tile_select_builds.txt) although
+  // its stamps show 27 % fewer cycles in this phase: compaction in two passes over the registers: (1) every lane counts its own values >= L (packed compare: bit 15 / 31 of
+  // (w | 0x8000'8000) - L'L per 16-bit half), ONE wave-wide exclusive scan of the counts (DPP) gives the lane its first slot in
+  // the wave's segment; (2) the few lanes with hits (a lane's eight values of a vector hold one with probability ~8 %) walk the
+  // set bits of their hit mask and store the keys.
+  // hit mask of a vector: bit q = the low half of dword q (column 2 q), bit 16 + q = its high half (column 2 q + 1)
+  auto hit_mask = [&](const u32x4& w) -> unsigned int {
+    const unsigned int h0 = ((w[0] | 0x80008000u) - lp) & 0x80008000u, h1 = ((w[1] | 0x80008000u) - lp) & 0x80008000u;
+    const unsigned int h2 = ((w[2] | 0x80008000u) - lp) & 0x80008000u, h3 = ((w[3] | 0x80008000u) - lp) & 0x80008000u;
+    return (h0 >> 15) | (h1 >> 14) | (h2 >> 13) | (h3 >> 12);
+  };
+  int cnt = 0;
+#pragma unroll
+  for (int v = 0; v < TSEL_VEC; ++v)
+    if (v * 256 < nv) cnt += __popc(hit_mask(wv_[v]));
+  int incl = cnt;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);      // row_shr:1 (lanes without a source add 0)
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);      // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);      // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);      // row_shr:8: inclusive within the row of 16
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);      // row_bcast15: rows 1, 3 += lane 15 of the row before
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);      // row_bcast31: rows 2, 3 += lane 31
+  const int wcount = __builtin_amdgcn_readlane(incl, 63);
+  int pos = incl - cnt;
+#pragma unroll
+  for (int v = 0; v < TSEL_VEC; ++v) {
+    if (v * 256 >= nv) continue;
+    const u32x4 w = wv_[v];
+    unsigned int u = hit_mask(w);
+    if (u != 0u) {
+      const int vi = v * 256 + t;
+      const int col0 = (int)tlist[vi / VPT] * TSEL_TILE + (vi % VPT) * 8;
+      while (u != 0u) {
+        const int b = __ffs(u) - 1;
+        u &= u - 1u;
+        const int q = b & 3, h = b >> 4;
+        const unsigned int dw = q == 0 ? w[0] : (q == 1 ? w[1] : (q == 2 ? w[2] : w[3]));
+        const unsigned int key = (dw >> (16 * h)) & 0xFFFFu;
+        if (pos < SEG) seg[pos] = (key << 17) | (0x1FFFFu - (unsigned int)(col0 + 2 * q + h));
+        ++pos;
+      }
+    }
+  }
+#endif
+  TSEL_MARK();                                      // [4] candidates appended
   if (lane == 0) wave_cnt[wv] = wcount;
   topk_pad_segment<SEG>(seg, wcount, lane);
   __syncthreads();
+  TSEL_MARK();                                      // [5] block barrier
   const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
   const int C = c0 + c1 + c2 + c3;
-  if (nq_s * 16 > TSEL_VEC * 256 || c0 > SEG || c1 > SEG || c2 > SEG || c3 > SEG) {     // block-uniform
+  if (nv > TSEL_VEC * 256 || c0 > SEG || c1 > SEG || c2 > SEG || c3 > SEG) {     // block-uniform
     if (t == 0) flag[row] = 1;
     return;
   }
-  for (int i = t; i < C; i += 256) {
+  for (int i = ((wv - lead) & 3) * 64 + lane; i < C; i += 256) {      // candidates 0..63 on the leader, 64..127 on the wave after it, ...
     const int sg = i < c0 ? 0 : (i < c0 + c1 ? 1 : (i < c0 + c1 + c2 ? 2 : 3));
     const int li = i - (sg == 0 ? 0 : (sg == 1 ? c0 : (sg == 2 ? c0 + c1 : c0 + c1 + c2)));
     const unsigned int my = cand_pk[sg * SEG + li];
@@ -1006,6 +1113,12 @@ __global__ __launch_bounds__(256) void topk_select_tiles_kernel(const bf16_t* __
     }
   }
   for (int j = k + t; j < kcap; j += 256) ti[j] = -1;
+#ifdef TSEL_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSEL_MARK();                                      // [6] ranked and stored
+  if (t == 64 * lead && nst_ < 8) stamp_[nst_++] = stamp_[0] + (unsigned long long)(C * 1000 + nq);     // [7] candidates * 1000 + candidate tiles
+  TSEL_FLUSH();
+#endif
 }
 
 // masked dense row from the compact selection (only when somebody asks for it: sae_latent_buffer, sae_latent_colmax,
