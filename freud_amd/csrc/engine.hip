@@ -460,7 +460,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
     TALLOC(c->tkd, 64);
     TALLOC(c->dead_cols, (size_t)c->n_p * 4);
     TALLOC(c->vec_rank, (size_t)(c->n_p / 8) * 4);
-    TALLOC(c->vec_bits, (size_t)(c->n_p / 8));
+    TALLOC(c->vec_bits, (size_t)vec_bits_t_offset(c->n_p) + VEC_BITS_T_BYTES);     // the table + its transposed copy (topk_aux.h)
     TALLOC(c->Wdd_b, c->nW * 2);
     TALLOC(c->aux_dbe_part, (Mp / 128) * c->n_p * 4);
     HIP_TRY(hipMemset(c->tkd, 0, 64));

@@ -62,6 +62,16 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const long long* __r
       }
     vec_bits[i >> 3] = (unsigned char)bits;
   }
+  // the transposed copy the compact select reads (topk_select_reg_kernel<12, true>: thread t of a row's workgroup owns the vectors
+  // t, t + 256, ...): [256][16] bytes behind the table, zeros past the row's end
+  if (n_p <= 32768) {
+    __syncthreads();                       // (the table above: global writes of this workgroup)
+    unsigned char* vt = vec_bits + vec_bits_t_offset(n_p);
+    for (int i = t; i < VEC_BITS_T_BYTES; i += 1024) {
+      const int g = (i & 15) * 256 + (i >> 4);
+      vt[i] = g < n_p / 8 ? vec_bits[g] : (unsigned char)0;
+    }
+  }
   // ND_p: a multiple of 256 where the dictionary's padded size is one (the 256x256 GEMM kernel then applies), else of 128 --
   // never beyond n_p, the width of every compact buffer
   const int gran = (n_p & 255) ? 128 : 256;

@@ -359,6 +359,9 @@ __device__ __forceinline__ int topk_count_ge(const u32x4 (&keys)[MAXV], unsigned
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// byte offset of the transposed copy of vec_bits behind the table (dead_compact_kernel; n_p <= 32768)
+__host__ __device__ __forceinline__ int vec_bits_t_offset(int n_p) { return ((n_p / 8 + 15) / 16) * 16; }
+constexpr int VEC_BITS_T_BYTES = 256 * 16;
 #ifndef SEL_OCC
 #define SEL_OCC 4        // waves per SIMD the compact AuxK select is compiled for
 #endif
@@ -433,8 +436,12 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   constexpr bool CBITS_AHEAD = COMPACT && MAXV <= 12;
   unsigned cbits[CBITS_AHEAD ? MAXV : 1];
   if (CBITS_AHEAD) {
+    // the thread's bytes of vec_bits (vectors t, t + 256, ...) are the same for every row: dead_compact_kernel keeps them transposed
+    // behind the table ([256 threads][16 bytes], zeros past the row's end) -- one 16-byte load instead of twelve predicated byte
+    // loads (with their branches ~180 of the ~800 instructions this phase issued per thread; the phase is issue-bound)
+    const u32x4 cbw = *reinterpret_cast<const u32x4*>(vec_bits + vec_bits_t_offset(n_p) + 16 * t);
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) cbits[v] = (v * 256 + t < nvec) ? (unsigned)vec_bits[v * 256 + t] : 0u;
+    for (int v = 0; v < MAXV; ++v) cbits[v] = (cbw[v >> 2] >> (8 * (v & 3))) & 0xFFu;
   }
   auto cbits_of = [&](int v, int g) -> unsigned { return CBITS_AHEAD ? cbits[CBITS_AHEAD ? v : 0] : (g < nvec ? (unsigned)vec_bits[g] : 0u); };
   // Round 4: ALL of the thread's row loads are issued before the first one is used (MAXV <= 12).  With the load and its masking in
@@ -446,22 +453,27 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     for (int v = 0; v < MAXV; ++v) {
       const int g = v * 256 + t;
       u32x4 w = {0u, 0u, 0u, 0u};
-      if (g < nvec && (!COMPACT || cbits_of(v, g) != 0u)) w = __builtin_nontemporal_load(src + g);
+      // (COMPACT: a non-zero byte implies g < nvec)
+      if (CBITS_AHEAD ? cbits_of(v, g) != 0u : (g < nvec && (!COMPACT || cbits_of(v, g) != 0u))) w = __builtin_nontemporal_load(src + g);
       keys[v] = w;
     }
   }
+  // Compact select with the dead bits up front: a vector past the row's end has no dead bits and was not loaded, so the bound is
+  // the block-uniform "any vector of this slot in the row" (a scalar branch) instead of a per-lane one (exec-mask save / restore
+  // around every vector's masking).  (With NO branch at all hipcc spilled 186 registers instead of 40 and the kernel ran 60 % slower.)
+  {
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int g = v * 256 + t;
     u32x4 w = {0u, 0u, 0u, 0u};
     unsigned cb = 0;
-    if (g < nvec) {
+    if (CBITS_AHEAD ? v * 256 < nvec : g < nvec) {
       // read exactly once (3.2 GB at C3): keep it out of the caches' way.  COMPACT: vectors without a dead column are not
       // read at all (with few dead latents that is most of the row)
       const unsigned cbv = COMPACT ? cbits_of(v, g) : 0u;
       if (LOADS_AHEAD) w = keys[v];
       else if (!COMPACT || cbv != 0u) w = __builtin_nontemporal_load(src + g);
-      if (dead == nullptr && n == n_p) {               // every column is a candidate (block-uniform)
+      if (!COMPACT && dead == nullptr && n == n_p) {   // every column is a candidate (block-uniform)
         cb = 0xFFu;
       } else {
         if (COMPACT) {
@@ -484,6 +496,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     }
     keys[v] = w;
     cand[v] = cb;
+  }
   }
   int ncand_l = 0;
 #pragma unroll
