@@ -1998,7 +1998,19 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       hipLaunchKernelGGL((topk_prep_x_kernel<T, false>), dim3(g2), dim3(256), 0, s, x, bd, c->xs, M, d, Mp, d_p);
     const int64_t TD = T_rows * d;
     if (!gs)   // (data parallel: the variance comes from the column statistics summed over the ranks, below)
-      hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
+    {
+      bool vec = false;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (B <= TV_MAXB && TD % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+          vec = true;
+          if (B <= 32)
+            hipLaunchKernelGGL((total_variance_vec_kernel<32, 8>), dim3((unsigned)((TD + 2047) / 2048)), dim3(256), 0, s, x, B, TD, c->tv_part);
+          else
+            hipLaunchKernelGGL((total_variance_vec_kernel<64, 4>), dim3((unsigned)((TD + 1023) / 1024)), dim3(256), 0, s, x, B, TD, c->tv_part);
+        }
+      }
+      if (!vec) hipLaunchKernelGGL(total_variance_kernel<T>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, s, x, B, TD, c->tv_part);
+    }
   }
   {  // pre = relu(sae_in We^T + be)
     GemmArgs g{};

@@ -65,6 +65,57 @@ __global__ __launch_bounds__(256) void total_variance_kernel(const T* __restrict
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// The same for bf16 activations with up to NB files per batch, T*d a multiple of 8 and 16-byte aligned rows: a thread owns COLS (8
+// or 4) consecutive columns and keeps all B of their vectors in registers (128 registers either way: NB = 32 x 16 bytes or NB = 64
+// x 8 bytes), so the batch is read from HBM once, in wide loads that are all in flight together -- the per-column kernel above
+// makes 2 B dependent 2-byte loads per thread and reached 1.2 TB/s (82 us at C3).  Same arithmetic per column (float mean in file
+// order, float square, double sum); part[i] still covers columns [256 i, 256 i + 256) (now: a thread's columns in order, then a
+// butterfly over the 256 / COLS threads of the part).
+constexpr int TV_MAXB = 64;
+template <int NB, int COLS>
+__global__ __launch_bounds__(256) void total_variance_vec_kernel(const bf16_t* __restrict__ x, int B, int64_t TD, double* __restrict__ part) {
+  typedef __attribute__((ext_vector_type(COLS / 2))) unsigned int vec_t;
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * COLS;
+  vec_t v[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < COLS / 2; ++q) v[b][q] = 0u;
+    if (b < B && c0 < TD) v[b] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(x + (int64_t)b * TD + c0));
+  }
+  auto val = [&](int b, int e) { return __uint_as_float((e & 1) ? (v[b][e >> 1] & 0xFFFF0000u) : (v[b][e >> 1] << 16)); };
+  float mean[COLS];
+#pragma unroll
+  for (int e = 0; e < COLS; ++e) mean[e] = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < B) {
+#pragma unroll
+      for (int e = 0; e < COLS; ++e) mean[e] += val(b, e);
+    }
+#pragma unroll
+  for (int e = 0; e < COLS; ++e) mean[e] /= (float)B;
+  double sc[COLS];
+#pragma unroll
+  for (int e = 0; e < COLS; ++e) sc[e] = 0.0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < B) {
+#pragma unroll
+      for (int e = 0; e < COLS; ++e) {
+        const float dlt = val(b, e) - mean[e];
+        sc[e] += (double)(dlt * dlt);
+      }
+    }
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < COLS; ++e) s += sc[e];
+  constexpr int GROUP = 256 / COLS;                 // threads per part (32 or 64: inside one wave)
+#pragma unroll
+  for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & (GROUP - 1)) == 0 && c0 < TD) part[c0 >> 8] = s;
+}
+
 // dead_mask = num_frames_since_fired > threshold (train_sae.py:436-439); tk[0] = num_dead, tk[1] = k_aux,
 // tkf[0] = aux scale = min(num_dead / (d/2), 1) (topkautoencoder.py:111-115).  One block.
 __global__ __launch_bounds__(1024) void dead_mask_kernel(const long long* __restrict__ nfsf, unsigned char* __restrict__ dead,
