@@ -32,11 +32,17 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const long long* __r
   const int per = ((n_p / 8 + 1023) / 1024) * 8;           // columns per thread, a multiple of 8
   const int c0 = t * per;
   int cnt = 0;
+  // the thread's dead bits stay in registers for the second walk (per <= 128 columns: n_p <= 131072): reading dead[] back from
+  // global memory was a chain of dependent round trips in this one-workgroup kernel
+  unsigned long long dbits[2] = {0ull, 0ull};
+  const bool inreg = per <= 128;
+#pragma unroll 8
   for (int i = c0; i < c0 + per && i < n_p; ++i) {
     const bool dd = i < n && (double)nfsf[i] > threshold;
     dead[i] = dd;
     did_fire[i] = 0.f;
     cnt += dd;
+    if (dd && inreg) dbits[(i - c0) >> 6] |= 1ull << ((i - c0) & 63);
   }
   int inc = cnt;
 #pragma unroll
@@ -55,8 +61,12 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const long long* __r
   for (int i = c0; i < c0 + per && i < n_p; i += 8) {
     unsigned bits = 0;
     vec_rank[i >> 3] = pos;
+    unsigned b8 = 0;
+    if (inreg) b8 = (unsigned)(dbits[((i - c0) >> 6) & 1] >> ((i - c0) & 63)) & 0xFFu;      // (i - c0 is a multiple of 8)
+    else
+      for (int e = 0; e < 8; ++e) b8 |= dead[i + e] ? (1u << e) : 0u;                         // written by this thread above
     for (int e = 0; e < 8; ++e)
-      if (dead[i + e]) {                 // written by this thread above
+      if ((b8 >> e) & 1u) {
         bits |= 1u << e;
         dead_cols[pos++] = i + e;
       }
