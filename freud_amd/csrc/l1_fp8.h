@@ -79,10 +79,13 @@ __global__ __launch_bounds__(256) void fp8_scales_kernel(const float* __restrict
   __shared__ float red[3][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float amax = 0.f, rmax = 0.f, bmax = 0.f;
+  // (one workgroup: unrolled so that eight trips' loads are in flight together -- 320 dependent trips over the bias were 76 us at C5)
+#pragma unroll 8
   for (int i = threadIdx.x; i < nparts; i += 256) {
     amax = fmaxf(amax, part[2 * i]);
     rmax = fmaxf(rmax, part[2 * i + 1]);
   }
+#pragma unroll 8
   for (int i = threadIdx.x; i < n; i += 256) bmax = fmaxf(bmax, bias[i]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
