@@ -1303,7 +1303,7 @@ extern "C" int sae_p2p_leave(sae_ctx* c) {
 // buffer: each gives wrong sums here, before the first training step.  A rank that cannot reach its peers times out (status
 // word) instead of corrupting a run.  FREUD_P2P_FAULT=skip_phase2:<rank> is caught here (tests/test_dp_gpu.py).
 constexpr int P2P_SELFTEST_EPOCHS = 4;
-static int p2p_selftest(sae_ctx* c) {
+static int p2p_selftest_body(sae_ctx* c) {
   hipStream_t s = c->comm_stream;
   const int64_t n = c->nparams;
   const int64_t ns = c->stats_cap < 4096 ? c->stats_cap : 4096;        // doubles of the statistics buffer exercised (>= DP_STATS_HEAD)
@@ -1367,6 +1367,18 @@ static int p2p_selftest(sae_ctx* c) {
                              "in %d exchanges per payload form", bad_total, bad_kind[0], bad_kind[1], bad_kind[2], bad_kind[3], bad_kind[4], P2P_SELFTEST_EPOCHS);
   }
   return SAE_OK;
+}
+// The ranks enter the self-test right after the hand-shake that exchanged their handles, i.e. within milliseconds of each other:
+// a peer whose flags do not arrive within 20 s never will (mappings that do not reach the other device), and the caller falls back
+// to another exchange that much sooner than after the run-time limit (FREUD_P2P_TIMEOUT_MS, 120 s: a step may wait for a peer
+// that writes a checkpoint).
+static int p2p_selftest(sae_ctx* c) {
+  const unsigned long long keep = c->p2p_timeout_ticks;
+  const unsigned long long limit = 2000000000ull;            // 20 s of the 100 MHz counter
+  if (c->p2p_timeout_ticks > limit) c->p2p_timeout_ticks = limit;
+  const int rc = p2p_selftest_body(c);
+  c->p2p_timeout_ticks = keep;
+  return rc;
 }
 
 extern "C" int sae_dist_set_overlap(sae_ctx* c, int nranges) {
