@@ -499,6 +499,14 @@ def main():
             d_ = np.diff(st[:, :6], axis=1)
             print("AuxK compact select, cycles per row (median over %d rows): %s | total %.0f" %
                   (len(st), ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, np.median(d_, axis=0))), np.median(st[:, 5])), file=sys.stderr)
+    if args.dbg == 69 and rank == 0 and args.variant == "topk":     # -DCSCF_STAMP builds: phase stamps of csc_fill
+        st = eng.debug_read(13, 1024 * 8).reshape(-1, 8)
+        st = st[st[:, 6] > 0]
+        if len(st):
+            names = ["positions initialised", "indices loaded", "LDS slots", "activations loaded", "stores issued", "stores acknowledged"]
+            d_ = np.diff(st[:, :7], axis=1)
+            print("csc_fill, shader cycles per workgroup (median over %d): %s | total %.0f" %
+                  (len(st), ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, np.median(d_, axis=0))), np.median(st[:, 6])), file=sys.stderr)
     if args.dbg == 68 and rank == 0 and args.variant == "topk":     # -DTSEL_STAMP builds: phase stamps of the tile-driven main select
         st = eng.debug_read(12, 4096 * 8).reshape(-1, 8)
         st = st[st[:, 6] > 0]

@@ -2141,7 +2141,9 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
                          c->csc_total);
       hipLaunchKernelGGL(csc_scan_latents_kernel, dim3(1), dim3(1024), 0, s, c->csc_total, n_p, c->csc_start, c->csc_item_start);
       hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent);
-      hipLaunchKernelGGL(csc_fill_kernel, dim3(nb, nseg), dim3(64), lds, s, ps, c->tk, M, n_p, c->csc_block_off, c->csc_start, c->csc_entries);
+      const int nseg_fill = (n_p + CSC_FILL_NP - 1) / CSC_FILL_NP;     // (32-bit position counters: 16 384 latents per 64 KiB)
+      hipLaunchKernelGGL(csc_fill_kernel, dim3(nb, nseg_fill), dim3(64), (n_p < CSC_FILL_NP ? n_p : CSC_FILL_NP) * 4, s, ps, c->tk, M, n_p,
+                         c->csc_block_off, c->csc_start, c->csc_entries);
       ev_end(c, KID_TK_DDENSE, s);
       ev_begin(c, KID_TK_DWD, s);
       {
@@ -2581,6 +2583,15 @@ extern "C" int sae_debug_read(sae_ctx* c, int which, float* out, int64_t cap) {
     for (int64_t i = 0; i < nq; ++i) out[i] = (float)tmp[(size_t)i];
     return SAE_OK;
   }
+#ifdef CSCF_STAMP
+  if (which == 13) {   // phase stamps of csc_fill (-DCSCF_STAMP builds only): [workgroup][8] cycles since its start
+    const int64_t rows = cap / 8 < 4096 ? cap / 8 : 4096;
+    std::vector<unsigned long long> tmp((size_t)rows * 8);
+    HIP_TRY(hipMemcpyFromSymbol(tmp.data(), HIP_SYMBOL(cscf_stamp_buf), tmp.size() * 8, 0, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < rows * 8; ++i) out[i] = (float)tmp[(size_t)i];
+    return SAE_OK;
+  }
+#endif
 #ifdef TSEL_STAMP
   if (which == 12) {   // phase stamps of the tile-driven main select (-DTSEL_STAMP builds only): [row][8] cycles since the row's start
     const int64_t rows = cap / 8 < 4096 ? cap / 8 : 4096;

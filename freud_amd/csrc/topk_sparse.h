@@ -19,9 +19,10 @@
 //                  segments of 32 768 latents, one wave per (row block, segment): any n_p);
 //   2. csc_scan_blocks: per latent, exclusive prefix over the row blocks (+ the latent's total);
 //   3. csc_scan_latents: exclusive prefix over the latents (list starts) and over the work-item counts;
-//   4. csc_fill:   the same wave walks its rows IN ORDER; an LDS add-with-return hands every entry its rank inside
-//                  (block, latent) -- LDS operations of one wave execute in program order, and the indices of one
-//                  (row, pass) are distinct, so the ranks do not depend on timing.
+//   4. csc_fill:   a wave per row block (and per segment of 16 384 latents) walks its rows IN ORDER; its LDS counters start at the
+//                  (block, latent) runs' first slots and an LDS add-with-return hands every entry its slot -- LDS operations of
+//                  one wave execute in program order, and the indices of one (row, pass) are distinct, so the order does not
+//                  depend on timing.
 #pragma once
 #include "topk_kernels.h"
 
@@ -145,57 +146,115 @@ __global__ __launch_bounds__(256) void csc_items_kernel(const unsigned int* __re
   for (unsigned int i = item_start[j]; i < item_start[j + 1]; ++i) item_latent[i] = (unsigned int)j;
 }
 
+#ifdef CSCF_STAMP
+// diagnostic build (tools/build_variant.sh cscfstamp -DCSCF_STAMP; bench.py --dbg 69): s_memtime at the phase boundaries of csc_fill,
+// one row of 8 per workgroup: cycles since the workgroup's start
+__device__ unsigned long long cscf_stamp_buf[4096 * 8];
+#define CSCF_MARK() do { if (lane == 0 && nst_ < 8) stamp_[nst_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSCF_MARK() do {} while (0)
+#endif
 // ---- 4. fill: entries[start[j] + block_off[b][j] + rank] ----------------------------------------------------------------------
+// Round 4: the LDS counters of a (row block, dictionary segment) are 32-bit POSITIONS, initialised to start[j] + block_off[b][j] by a
+// coalesced stream of the two tables (16-byte loads) -- the LDS add-with-return then IS the entry's slot.  Before, u16 rank counters
+// started at zero and every entry gathered start[j] and block_off[b][j] (two scattered 4-byte loads per entry: a third of the
+// kernel by its stamps).  Segments of CSC_FILL_NP latents: 64 KiB of counters per wave.
+constexpr int CSC_FILL_NP = 16384;
 __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int* __restrict__ tk, int64_t M, int n_p,
                                                       const unsigned int* __restrict__ block_off, const unsigned int* __restrict__ start,
                                                       CscEntry* __restrict__ entries) {
   extern __shared__ unsigned int ctr32[];
   const int lane = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
-  const int seg0 = blockIdx.y * CSC_MAX_NP, seg1 = min(seg0 + CSC_MAX_NP, n_p), segn = seg1 - seg0;    // as in csc_count_kernel
-  for (int i = lane; i < segn / 2; i += 64) ctr32[i] = 0u;
+  // Row block of this workgroup.  A latent's entries of CONSECUTIVE row blocks are neighbours in the list (8 bytes each: sixteen
+  // blocks share a 128-byte line), and workgroups go to the XCDs round robin: with block = blockIdx.x the neighbours were written
+  // through eight different L2s, every store a partial line on its way to HBM.  XCD x now takes the blocks [x nb/8, (x+1) nb/8):
+  // neighbours meet in ONE L2 within microseconds and leave as whole lines.
+#ifdef CSCF_NO_XCD_REMAP
+  const int blk = blockIdx.x;
+#else
+  const int nb8 = gridDim.x >> 3;
+  const int blk = (int)blockIdx.x < 8 * nb8 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#endif
+  const int64_t r0 = (int64_t)blk * CSC_ROWS;
+  const int seg0 = blockIdx.y * CSC_FILL_NP, seg1 = min(seg0 + CSC_FILL_NP, n_p), segn = seg1 - seg0;    // (n_p: a multiple of 128)
+#ifdef CSCF_STAMP
+  unsigned long long stamp_[8];
+  int nst_ = 0;
+#endif
+  CSCF_MARK();                                    // [0]
+  {
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(start + seg0);
+    const u32x4* b4 = reinterpret_cast<const u32x4*>(block_off + (int64_t)blk * n_p + seg0);
+    u32x4* c4 = reinterpret_cast<u32x4*>(ctr32);
+#pragma unroll 8
+    for (int i = lane; i < segn / 4; i += 64) c4[i] = s4[i] + b4[i];
+  }
   __syncthreads();
-  const unsigned int* boff = block_off + (int64_t)blockIdx.x * n_p;
+  CSCF_MARK();                                    // [1] positions initialised
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
     for (int q0 = 0; q0 < kcap; q0 += 64) {     // order inside (block, latent): pass, index chunk, row -- fixed, never timing
-      // Four phases, each with all of its memory operations in flight together (round 4): with the gathers, the LDS add and the store
-      // of a row in one loop body the wave made 64 dependent round trips per chunk: kernel 202 -> 184 us at C3.
+      // Phases with all of their memory operations in flight together (with the load, the LDS add and the store of a row in one loop
+      // body the wave made 64 dependent round trips per chunk), and loads from CLAMPED addresses + a select instead of predicated
+      // loads (a load in its own exec-masked block is followed by its use inside that block, i.e. by a wait).  The activations are
+      // loaded after the LDS phase, one register each: next to the indices they made a fourth 64-entry array, which went to AGPRs
+      // through a copy that WAITED for every 2-byte load in turn (84 k of the workgroup's 211 k cycles, -DCSCF_STAMP).
       int v[CSC_ROWS];
-      unsigned short a[CSC_ROWS];
       const int q = q0 + lane;
-#pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (1) the chunk's indices and activations
-        const bool ok = q < kcap && r0 + r < M;
-        v[r] = ok ? ps.idx[pass][(r0 + r) * kcap + q] : -1;
-        a[r] = ok ? reinterpret_cast<const unsigned short*>(ps.vals[pass])[(r0 + r) * kcap + q] : (unsigned short)0;
+      const int qc = q < kcap ? q : kcap - 1;
+      const int qbad = q < kcap ? 0 : (int)0x80000000;          // (ORed into the index: negative = no entry; a select on the loaded
+#pragma unroll                                                  //  value let hipcc turn the load back into a predicated one)
+      for (int r = 0; r < CSC_ROWS; ++r) {        // (1) the chunk's indices
+        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
+        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (r0 + r < M ? 0 : (int)0x80000000);
       }
-      unsigned int base[CSC_ROWS];
+#ifdef CSCF_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      CSCF_MARK();                                // [2] indices loaded
+      unsigned int pos[CSC_ROWS];
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (2) where the (block, latent) run starts: two gathers per entry
-        const int j = v[r];
-        base[r] = (j >= seg0 && j < seg1) ? start[j] + boff[j] : 0u;
+      for (int r = 0; r < CSC_ROWS; ++r) {        // (2) the slot: LDS add with return; one wave, program order, distinct j within a
+        const int j = v[r];                       //     (row, pass) -- the order inside (block, latent) never depends on timing
+        pos[r] = 0xFFFFFFFFu;
+        if (j >= seg0 && j < seg1) pos[r] = atomicAdd(&ctr32[j - seg0], 1u);
       }
-      unsigned int old[CSC_ROWS];
+#ifdef CSCF_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      CSCF_MARK();                                // [3] slots
+      __builtin_amdgcn_sched_barrier(0);          // (the activation loads below must not move up into the phases above)
+      unsigned int a[CSC_ROWS];
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (3) rank inside (block, latent): LDS add with return; one wave, program order,
-        const int j = v[r];                       //     distinct j within a (row, pass)
-        old[r] = 0u;
-        if (j >= seg0 && j < seg1) old[r] = atomicAdd(&ctr32[(j - seg0) >> 1], (j & 1) ? 0x10000u : 1u);
+      for (int r = 0; r < CSC_ROWS; ++r) {        // (3) the activations, one register each, all in flight
+        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
+        a[r] = (unsigned int)reinterpret_cast<const unsigned short*>(ps.vals[pass])[rr * kcap + qc];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef CSCF_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      CSCF_MARK();                                // [4] activations loaded
 #pragma unroll
       for (int r = 0; r < CSC_ROWS; ++r) {        // (4) the entries
-        const int j = v[r];
-        if (j < seg0 || j >= seg1) continue;
-        const unsigned int rank = (j & 1) ? (old[r] >> 16) : (old[r] & 0xFFFFu);
+        if (pos[r] == 0xFFFFFFFFu) continue;
         CscEntry e;
         e.row_pass = (unsigned int)(r0 + r) | ((unsigned int)pass << 30);
-        e.act = __uint_as_float((unsigned int)a[r] << 16);
-        entries[base[r] + rank] = e;
+        e.act = __uint_as_float(a[r] << 16);
+        entries[pos[r]] = e;
       }
+      CSCF_MARK();                                // [5] stores issued
+#ifdef CSCF_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      CSCF_MARK();                                // [6] stores acknowledged
     }
   }
+#ifdef CSCF_STAMP
+  if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0)
+    for (int i = 0; i < 8; ++i) cscf_stamp_buf[blockIdx.x * 8 + i] = i < nst_ ? stamp_[i] - stamp_[0] : 0ull;
+#endif
 }
 
 #ifndef SB_E
