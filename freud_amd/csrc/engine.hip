@@ -1637,6 +1637,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       g.nbm = (int)(Mp / 256); g.nbn = d_p / 256; g.ktiles = n_p / 128;
       EpiDec<T> e{};
       e.x = x; e.dxh = c->dxh; e.scal = c->scal; e.sq_part = c->sq_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = d_p / 128;
+      e.vec_all = (M == Mp && d == d_p && d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * sizeof(T))) == 0) ? 1 : 0;
       e.vscale = c->scal8 + S8_INV_DEC;
       ev_begin(c, KID_DEC_FWD, s);
       rc = launch_gemm8(g, e, s);
@@ -1664,6 +1665,7 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     g.group_m = 4;       // (gemm.h: GemmArgs::group_m)
     EpiDec<T> e{};
     e.x = x; e.dxh = c->dxh; e.scal = c->scal; e.sq_part = c->sq_part; e.M = M; e.d = d; e.d_p = d_p; e.nbn = g.nbn;
+    e.vec_all = (M == Mp && d == d_p && d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * sizeof(T))) == 0) ? 1 : 0;
     ev_begin(c, KID_DEC_FWD, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
     ev_end(c, KID_DEC_FWD, s);

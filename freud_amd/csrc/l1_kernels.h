@@ -232,8 +232,20 @@ struct EpiDec {
     tile_id = (row0 / GEMM_BM) * nbn + col0 / GEMM_BN;
   }
   struct Pre { float xv[4]; };
+  // vec_all (host: no padded row or column -- M == M_p, d == d_p -- and x aligned to four elements): ONE unconditional vector load
+  // per call.  The general form below is four predicated scalar loads, and hipcc keeps each in its own exec-masked block WITH its
+  // conversion, i.e. with a wait: 128 dependent round trips per thread and tile in the decoder's epilogue (found in round 4 through
+  // the same pattern in csc_fill_kernel; a decoder tile's "prefetch one batch ahead" never overlapped anything).
+  int vec_all;
   __device__ Pre prefetch(int row, int col) const {
     Pre p;
+    if (vec_all) {
+      typedef T vec4_t __attribute__((ext_vector_type(4)));
+      const vec4_t q = *reinterpret_cast<const vec4_t*>(x + (int64_t)row * d + col);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p.xv[j] = (float)q[j];
+      return p;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) p.xv[j] = (row < M && col + j < d) ? load_as_float(x + (int64_t)row * d + col + j) : 0.f;
     return p;

@@ -52,18 +52,24 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
   const int lane = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * CSC_ROWS;
   const int seg0 = blockIdx.y * CSC_MAX_NP, seg1 = min(seg0 + CSC_MAX_NP, n_p), segn = seg1 - seg0;
-  for (int i = lane; i < segn / 2; i += 64) ctr32[i] = 0u;
+  for (int i = lane; i < segn / 8; i += 64) reinterpret_cast<u32x4*>(ctr32)[i] = u32x4{0u, 0u, 0u, 0u};     // (segn: a multiple of 128)
   __syncthreads();
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
     for (int q0 = 0; q0 < kcap; q0 += 64) {
       // the block's CSC_ROWS rows of this 64-wide index chunk: every load is issued before the first LDS add (one memory
-      // latency per chunk instead of one per row)
+      // latency per chunk instead of one per row) -- from CLAMPED addresses, the lanes / rows without an entry marked by an OR into
+      // the index: with `ok ? load : -1` hipcc predicates every load and waits for it inside its block (csc_fill_kernel)
       int v[CSC_ROWS];
       const int q = q0 + lane;
+      const int qc = q < kcap ? q : kcap - 1;
+      const int qbad = q < kcap ? 0 : (int)0x80000000;
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) v[r] = (q < kcap && r0 + r < M) ? ps.idx[pass][(r0 + r) * kcap + q] : -1;
+      for (int r = 0; r < CSC_ROWS; ++r) {
+        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
+        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (r0 + r < M ? 0 : (int)0x80000000);
+      }
 #pragma unroll
       for (int r = 0; r < CSC_ROWS; ++r)
         if (v[r] >= seg0 && v[r] < seg1)
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
     }
   }
   __syncthreads();
-  unsigned int* out = reinterpret_cast<unsigned int*>(counts + (int64_t)blockIdx.x * n_p + seg0);
-  for (int i = lane; i < segn / 2; i += 64) out[i] = ctr32[i];
+  u32x4* out = reinterpret_cast<u32x4*>(counts + (int64_t)blockIdx.x * n_p + seg0);
+  for (int i = lane; i < segn / 8; i += 64) out[i] = reinterpret_cast<const u32x4*>(ctr32)[i];
 }
 
 // ---- 2. per latent: exclusive prefix over the row blocks, total -----------------------------------------------------------
