@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void normalize_cast_kernel(float* __restrict__
   const int col = blockIdx.x * 64 + tx, r0 = blockIdx.y * 64;
   if (ty == 0) {
     float ss = 0.f;
-    for (int i = 0; i < nslab; ++i) ss += part[(int64_t)i * n_p + col];
+#pragma unroll 8
+    for (int i = 0; i < nslab; ++i) ss += part[(int64_t)i * n_p + col];      // (unrolled: eight partials in flight, same order)
     denom_s[tx] = fmaxf(sqrtf(ss), 1e-12f);
   }
   __syncthreads();
@@ -441,19 +442,45 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restri
   if (fin.cnt_part && blockIdx.x == gridDim.x - 1) finalize_losses_block256(fin);
   double ss = 0;
   const int n4p = n_p / 4;
+  // a + piece 1 + piece 2 + ... in piece order, the loads of up to eight pieces in flight together (round 4: with one load per trip
+  // of a plain loop every piece was a dependent round trip -- ~11 of them per element at C2, about half of this kernel's 15 us)
+  auto add_pieces = [](f32x4 a, const f32x4* p, int64_t stride, int cnt) -> f32x4 {
+    int k = 1;
+    for (; k + 7 < cnt; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    if (k + 3 < cnt) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(k + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += v[u];
+      k += 4;
+    }
+    if (k + 1 < cnt) {
+      const f32x4 v0 = p[k * stride], v1 = p[(k + 1) * stride];
+      a += v0;
+      a += v1;
+      k += 2;
+    }
+    if (k < cnt) a += p[k * stride];
+    return a;
+  };
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 a;
     if (i < nW4) {
       const f32x4* s = reinterpret_cast<const f32x4*>(slab);
-      a = s[i];
       const int cnt = bal_m > 0 ? bal_pieces((int)(i % n4p) >> 5, bal_m) : splits;
-      for (int k = 1; k < cnt; ++k) a += s[i + k * stride4];
+      a = add_pieces(s[i], s + i, stride4, cnt);
     } else {
       const int64_t j4 = i - nW4;
       const f32x4* s = reinterpret_cast<const f32x4*>(db_part);
-      a = s[j4];
       const int cnt = bal_m > 0 ? bal_pieces((int)j4 >> 5, bal_m) : db_rows;
-      for (int k = 1; k < cnt; ++k) a += s[j4 + (int64_t)k * n4p];
+      a = add_pieces(s[j4], s + j4, (int64_t)n4p, cnt);
     }
     reinterpret_cast<f32x4*>(grad)[i] = a;
     if (grad_bf16) reinterpret_cast<bf16x4*>(grad_bf16)[i] = bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
