@@ -1209,6 +1209,10 @@ __global__ __launch_bounds__(256) void topk_densify_kernel(const bf16_t* __restr
 // [l*cpl, (l+1)*cpl), so every gathered W_dec row is read as one contiguous, fully coalesced line by the wave.
 // NPAIR > 0: d_p == 128 * NPAIR is a compile-time constant, so a lane's 4 * NPAIR bytes of a W_dec row are fetched with
 // unconditional (mergeable into dwordx2/x4) loads and two gathered rows are kept in flight; NPAIR == 0: any d_p <= 1536.
+#ifndef TKD_ROWS
+#define TKD_ROWS 2        // gathered W_dec rows in flight per wave and trip of topk_decode_kernel (C3, one box: 2 -> 801 us, 4 -> 821,
+                          // 8 -> 903: the gather is bound by what misses the L2s, not by its round trips)
+#endif
 template <typename T, int NPAIR = 0>
 __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ x, const bf16_t* __restrict__ vals,
                                                            const int* __restrict__ idx, int kcap, const bf16_t* __restrict__ Wd,
@@ -1233,28 +1237,31 @@ __global__ __launch_bounds__(256) void topk_decode_kernel(const T* __restrict__ 
     const float my_a = my_i >= 0 ? (float)rv[jj] : 0.f;
     const int cnt = kcap - j0 < 64 ? kcap - j0 : 64;
     if constexpr (NPAIR > 0) {
-      // two gathered rows per trip (negative = padding index: row 0 is read and weighted by 0)
-      for (int j = 0; j < cnt; j += 2) {
-        const int i0 = __shfl(my_i, j, 64), i1 = __shfl(my_i, j + 1 < 64 ? j + 1 : j, 64);
-        const float a0 = i0 >= 0 ? __shfl(my_a, j, 64) : 0.f;
-        const float a1 = (j + 1 < cnt && i1 >= 0) ? __shfl(my_a, j + 1 < 64 ? j + 1 : j, 64) : 0.f;
-        const unsigned* w0 = reinterpret_cast<const unsigned*>(Wd + (int64_t)(i0 >= 0 ? i0 : 0) * d_p + c0);
-        const unsigned* w1 = reinterpret_cast<const unsigned*>(Wd + (int64_t)((j + 1 < cnt && i1 >= 0) ? i1 : 0) * d_p + c0);
-        unsigned u0[NPAIR], u1[NPAIR];
+      // TKD_ROWS gathered rows per trip, all of their loads in flight together (negative = padding index: row 0 is read and
+      // weighted by 0); the products are added in index order whatever the trip length
+      for (int j = 0; j < cnt; j += TKD_ROWS) {
+        float av[TKD_ROWS];
+        const unsigned* wp[TKD_ROWS];
 #pragma unroll
-        for (int p = 0; p < NPAIR; ++p) u0[p] = w0[p];
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p) u1[p] = w1[p];
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p) {
-          acc[2 * p] += a0 * __uint_as_float(u0[p] << 16);
-          acc[2 * p + 1] += a0 * __uint_as_float(u0[p] & 0xFFFF0000u);
+        for (int r = 0; r < TKD_ROWS; ++r) {
+          const int jr = j + r < 64 ? j + r : 63;              // (wave-uniform)
+          const int ir = __shfl(my_i, jr, 64);
+          const bool ok = j + r < cnt && ir >= 0;
+          av[r] = ok ? __shfl(my_a, jr, 64) : 0.f;
+          wp[r] = reinterpret_cast<const unsigned*>(Wd + (int64_t)(ok ? ir : 0) * d_p + c0);
         }
+        unsigned u[TKD_ROWS][NPAIR];
 #pragma unroll
-        for (int p = 0; p < NPAIR; ++p) {
-          acc[2 * p] += a1 * __uint_as_float(u1[p] << 16);
-          acc[2 * p + 1] += a1 * __uint_as_float(u1[p] & 0xFFFF0000u);
-        }
+        for (int r = 0; r < TKD_ROWS; ++r)
+#pragma unroll
+          for (int p = 0; p < NPAIR; ++p) u[r][p] = wp[r][p];
+#pragma unroll
+        for (int r = 0; r < TKD_ROWS; ++r)
+#pragma unroll
+          for (int p = 0; p < NPAIR; ++p) {
+            acc[2 * p] += av[r] * __uint_as_float(u[r][p] << 16);
+            acc[2 * p + 1] += av[r] * __uint_as_float(u[r][p] & 0xFFFF0000u);
+          }
       }
     } else {
       for (int j = 0; j < cnt; ++j) {
