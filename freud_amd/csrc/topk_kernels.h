@@ -1309,7 +1309,9 @@ __global__ __launch_bounds__(1024) void topk_finalize_kernel(const double* __res
   __shared__ double red[4][16];
   double a = 0, b = 0, c = 0, m = 0;
   const bool have_aux = a2_part != nullptr && tk[0] > 0;     // with no dead latent the AuxK kernels did not run
+#pragma unroll 8      // (one workgroup: eight trips' loads in flight, same order of the sums)
   for (int i = threadIdx.x; i < n_tv; i += 1024) a += tv_part[i];
+#pragma unroll 8
   for (int64_t i = threadIdx.x; i < Mp; i += 1024) {
     b += (double)e2_part[i];
     if (have_aux) c += (double)a2_part[i];
@@ -1583,6 +1585,7 @@ __global__ __launch_bounds__(256) void topk_dsae_colsum_kernel(const float* __re
   const int n0 = blockIdx.y * 64;
   if (c >= d_p) return;
   float s = 0.f;
+#pragma unroll 8      // (eight trips' loads in flight, same order of the sum)
   for (int i = 0; i < 64 && n0 + i < n_p; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
   part[(int64_t)blockIdx.y * d_p + c] = s;
 }
@@ -1596,7 +1599,9 @@ __global__ __launch_bounds__(1024) void topk_dbd_kernel(const float* __restrict_
   const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (c < d_p) {
+#pragma unroll 8
     for (int i = w; i < nb; i += 16) s += dbd_part[(int64_t)i * d_p + c];
+#pragma unroll 8
     for (int i = w; i < nt; i += 16) s -= ds_part[(int64_t)i * d_p + c];
   }
   red[w][lane] = s;
