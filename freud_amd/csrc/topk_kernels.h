@@ -1585,8 +1585,9 @@ __global__ __launch_bounds__(256) void topk_dsae_colsum_kernel(const float* __re
   const int n0 = blockIdx.y * 64;
   if (c >= d_p) return;
   float s = 0.f;
+  const int cnt = n_p - n0 < 64 ? n_p - n0 : 64;
 #pragma unroll 8      // (eight trips' loads in flight, same order of the sum)
-  for (int i = 0; i < 64 && n0 + i < n_p; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
+  for (int i = 0; i < cnt; ++i) s += dbe[n0 + i] * (float)We_b[(int64_t)(n0 + i) * d_p + c];
   part[(int64_t)blockIdx.y * d_p + c] = s;
 }
 
