@@ -26,7 +26,13 @@
 #pragma once
 #include "topk_kernels.h"
 
-constexpr int CSC_ROWS = 64;          // rows per counting block (one wave)
+constexpr int CSC_SUB = 64;           // rows a wave holds in registers at a time
+#ifndef CSC_ROWS_N
+#define CSC_ROWS_N 128
+#endif
+constexpr int CSC_ROWS = CSC_ROWS_N;  // rows per counting block (one wave, CSC_ROWS / CSC_SUB rounds; round 3: 64 -- twice the count / offset
+                                      // tables, 150 MB of them at C3)
+static_assert(CSC_ROWS % CSC_SUB == 0 && CSC_ROWS * 3 < 65536, "u16 counters per (block, latent)");
 constexpr int CSC_MAX_NP = 32768;     // latents per counting segment (u16 LDS counters: 64 KiB per wave)
 constexpr int CSC_CHUNK = 256;        // entries per work item of the gradient kernel
 
@@ -57,21 +63,22 @@ __global__ __launch_bounds__(64) void csc_count_kernel(SparsePasses ps, const in
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
-    for (int q0 = 0; q0 < kcap; q0 += 64) {
-      // the block's CSC_ROWS rows of this 64-wide index chunk: every load is issued before the first LDS add (one memory
+    for (int q0 = 0; q0 < kcap; q0 += 64)
+    for (int64_t rs = r0; rs < r0 + CSC_ROWS; rs += CSC_SUB) {
+      // CSC_SUB rows of this 64-wide index chunk: every load is issued before the first LDS add (one memory
       // latency per chunk instead of one per row) -- from CLAMPED addresses, the lanes / rows without an entry marked by an OR into
       // the index: with `ok ? load : -1` hipcc predicates every load and waits for it inside its block (csc_fill_kernel)
-      int v[CSC_ROWS];
+      int v[CSC_SUB];
       const int q = q0 + lane;
       const int qc = q < kcap ? q : kcap - 1;
       const int qbad = q < kcap ? 0 : (int)0x80000000;
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {
-        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
-        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (r0 + r < M ? 0 : (int)0x80000000);
+      for (int r = 0; r < CSC_SUB; ++r) {
+        const int64_t rr = rs + r < M ? rs + r : M - 1;
+        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (rs + r < M ? 0 : (int)0x80000000);
       }
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r)
+      for (int r = 0; r < CSC_SUB; ++r)
         if (v[r] >= seg0 && v[r] < seg1)
           atomicAdd(&ctr32[(v[r] - seg0) >> 1], (v[r] & 1) ? 0x10000u : 1u);   // (a block holds < 65536 entries of a latent)
     }
@@ -200,28 +207,29 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
   for (int pass = 0; pass < 3; ++pass) {
     if (!ps.idx[pass] || (ps.gated[pass] && tk[0] <= 0)) continue;
     const int kcap = ps.kcap[pass];
-    for (int q0 = 0; q0 < kcap; q0 += 64) {     // order inside (block, latent): pass, index chunk, row -- fixed, never timing
+    for (int q0 = 0; q0 < kcap; q0 += 64)       // order inside (block, latent): pass, index chunk, row -- fixed, never timing
+    for (int64_t rs = r0; rs < r0 + CSC_ROWS; rs += CSC_SUB) {
       // Phases with all of their memory operations in flight together (with the load, the LDS add and the store of a row in one loop
       // body the wave made 64 dependent round trips per chunk), and loads from CLAMPED addresses + a select instead of predicated
       // loads (a load in its own exec-masked block is followed by its use inside that block, i.e. by a wait).  The activations are
       // loaded after the LDS phase, one register each: next to the indices they made a fourth 64-entry array, which went to AGPRs
       // through a copy that WAITED for every 2-byte load in turn (84 k of the workgroup's 211 k cycles, -DCSCF_STAMP).
-      int v[CSC_ROWS];
+      int v[CSC_SUB];
       const int q = q0 + lane;
       const int qc = q < kcap ? q : kcap - 1;
       const int qbad = q < kcap ? 0 : (int)0x80000000;          // (ORed into the index: negative = no entry; a select on the loaded
 #pragma unroll                                                  //  value let hipcc turn the load back into a predicated one)
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (1) the chunk's indices
-        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
-        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (r0 + r < M ? 0 : (int)0x80000000);
+      for (int r = 0; r < CSC_SUB; ++r) {        // (1) the chunk's indices
+        const int64_t rr = rs + r < M ? rs + r : M - 1;
+        v[r] = ps.idx[pass][rr * kcap + qc] | qbad | (rs + r < M ? 0 : (int)0x80000000);
       }
 #ifdef CSCF_STAMP
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       CSCF_MARK();                                // [2] indices loaded
-      unsigned int pos[CSC_ROWS];
+      unsigned int pos[CSC_SUB];
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (2) the slot: LDS add with return; one wave, program order, distinct j within a
+      for (int r = 0; r < CSC_SUB; ++r) {        // (2) the slot: LDS add with return; one wave, program order, distinct j within a
         const int j = v[r];                       //     (row, pass) -- the order inside (block, latent) never depends on timing
         pos[r] = 0xFFFFFFFFu;
         if (j >= seg0 && j < seg1) pos[r] = atomicAdd(&ctr32[j - seg0], 1u);
@@ -231,10 +239,10 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
 #endif
       CSCF_MARK();                                // [3] slots
       __builtin_amdgcn_sched_barrier(0);          // (the activation loads below must not move up into the phases above)
-      unsigned int a[CSC_ROWS];
+      unsigned int a[CSC_SUB];
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (3) the activations, one register each, all in flight
-        const int64_t rr = r0 + r < M ? r0 + r : M - 1;
+      for (int r = 0; r < CSC_SUB; ++r) {        // (3) the activations, one register each, all in flight
+        const int64_t rr = rs + r < M ? rs + r : M - 1;
         a[r] = (unsigned int)reinterpret_cast<const unsigned short*>(ps.vals[pass])[rr * kcap + qc];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -243,10 +251,10 @@ __global__ __launch_bounds__(64) void csc_fill_kernel(SparsePasses ps, const int
 #endif
       CSCF_MARK();                                // [4] activations loaded
 #pragma unroll
-      for (int r = 0; r < CSC_ROWS; ++r) {        // (4) the entries
+      for (int r = 0; r < CSC_SUB; ++r) {        // (4) the entries
         if (pos[r] == 0xFFFFFFFFu) continue;
         CscEntry e;
-        e.row_pass = (unsigned int)(r0 + r) | ((unsigned int)pass << 30);
+        e.row_pass = (unsigned int)(rs + r) | ((unsigned int)pass << 30);
         e.act = __uint_as_float(a[r] << 16);
         entries[pos[r]] = e;
       }
