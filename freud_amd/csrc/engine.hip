@@ -197,6 +197,7 @@ struct sae_ctx {
   bool topk_csc = false;
   unsigned short* csc_counts = nullptr;
   unsigned int *csc_block_off = nullptr, *csc_total = nullptr, *csc_start = nullptr, *csc_item_start = nullptr, *csc_item_latent = nullptr;
+  unsigned int* csc_multi = nullptr;      // [0] = number of latents with no or several work items, [4 ...] = those latents (csc_items_kernel)
   CscEntry* csc_entries = nullptr;
   float *csc_part = nullptr, *csc_pbe = nullptr;
   int64_t csc_max_items = 0;
@@ -450,6 +451,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
     TALLOC(c->csc_start, (size_t)(c->n_p + 1) * 4);
     TALLOC(c->csc_item_start, (size_t)(c->n_p + 1) * 4);
     TALLOC(c->csc_item_latent, (size_t)c->csc_max_items * 4);
+    TALLOC(c->csc_multi, (size_t)(c->n_p + 4) * 4);
     TALLOC(c->csc_entries, (size_t)emax * sizeof(CscEntry));
     TALLOC(c->csc_part, (size_t)c->csc_max_items * 2 * c->d_p * 4);
     TALLOC(c->csc_pbe, (size_t)c->csc_max_items * 4);
@@ -493,7 +495,7 @@ extern "C" void sae_destroy(sae_ctx* c) {
                   c->multi_dense, c->multi_idx, c->em, c->dm_b, c->m2_part, c->x8, c->c8, c->W8, c->W8t, c->scal8, c->x8_part, c->dxh8,
                   c->stats, c->stats_part, c->Gb, c->top_vals, c->aux_vals, c->multi_vals, c->tile_max, c->sel_flag, c->csc_counts, c->csc_block_off, c->csc_total, c->csc_start, c->csc_item_start,
                   c->csc_item_latent, c->csc_entries, c->csc_part, c->csc_pbe, c->tkd, c->dead_cols, c->vec_rank, c->vec_bits, c->Wdd_b,
-                  c->aux_dbe_part, c->be_r, c->cnorm, c->dw_tail};
+                  c->aux_dbe_part, c->be_r, c->cnorm, c->dw_tail, c->csc_multi};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->dead_hint) (void)hipHostFree(c->dead_hint);
@@ -2142,7 +2144,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       hipLaunchKernelGGL(csc_scan_blocks_kernel, dim3((n_p + 63) / 64), dim3(1024), 0, s, c->csc_counts, nb, n_p, c->csc_block_off,
                          c->csc_total);
       hipLaunchKernelGGL(csc_scan_latents_kernel, dim3(1), dim3(1024), 0, s, c->csc_total, n_p, c->csc_start, c->csc_item_start);
-      hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent);
+      HIP_TRY(hipMemsetAsync(c->csc_multi, 0, 16, s));
+      hipLaunchKernelGGL(csc_items_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, c->csc_item_start, n_p, c->csc_item_latent, c->csc_multi);
       const int nseg_fill = (n_p + CSC_FILL_NP - 1) / CSC_FILL_NP;     // (32-bit position counters: 16 384 latents per 64 KiB)
       hipLaunchKernelGGL(csc_fill_kernel, dim3(nb, nseg_fill), dim3(64), (n_p < CSC_FILL_NP ? n_p : CSC_FILL_NP) * 4, s, ps, c->tk, M, n_p,
                          c->csc_block_off, c->csc_start, c->csc_entries);
@@ -2161,8 +2164,8 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       }
       ev_end(c, KID_TK_DWD, s);
       ev_begin(c, KID_TK_DWE, s);
-      hipLaunchKernelGGL(sparse_combine_kernel, dim3(n_p, d_p / 64), dim3(256), 0, s, c->csc_part, c->csc_pbe, c->csc_item_start, n_p,
-                         d_p, gWd, gWe, gbe, c->db_part);
+      hipLaunchKernelGGL(sparse_combine_kernel, dim3(4096), dim3(256), 0, s, c->csc_part, c->csc_pbe, c->csc_item_start, n_p,
+                         d_p, gWd, gWe, gbe, c->db_part, c->csc_multi);
       ev_end(c, KID_TK_DWE, s);
       HIP_TRY(hipGetLastError());
       if (auxc) {

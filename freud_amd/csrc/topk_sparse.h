@@ -152,11 +152,15 @@ __global__ __launch_bounds__(1024) void csc_scan_latents_kernel(const unsigned i
 }
 
 // ---- 3b. item -> latent table (one thread per latent writes its chunks' slots) --------------------------------------------------
+// ... and the list of the latents with no or several work items (multi[0] = their number, multi[4 ...] = the latents, in any order:
+// sparse_combine_kernel treats them independently), zeroed by the host before this kernel.
 __global__ __launch_bounds__(256) void csc_items_kernel(const unsigned int* __restrict__ item_start, int n_p,
-                                                        unsigned int* __restrict__ item_latent) {
+                                                        unsigned int* __restrict__ item_latent, unsigned int* __restrict__ multi) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n_p) return;
-  for (unsigned int i = item_start[j]; i < item_start[j + 1]; ++i) item_latent[i] = (unsigned int)j;
+  const unsigned int i0 = item_start[j], i1 = item_start[j + 1];
+  for (unsigned int i = i0; i < i1; ++i) item_latent[i] = (unsigned int)j;
+  if (i1 - i0 != 1) multi[4 + atomicAdd(&multi[0], 1u)] = (unsigned int)j;
 }
 
 #ifdef CSCF_STAMP
@@ -392,15 +396,21 @@ __global__ __launch_bounds__(64 * SB_WAVES) void sparse_bwd_kernel(SparsePasses 
 __global__ __launch_bounds__(256) void sparse_combine_kernel(const float* __restrict__ part, const float* __restrict__ pbe,
                                                              const unsigned int* __restrict__ item_start, int n_p, int d_p,
                                                              float* __restrict__ gWd, float* __restrict__ gWe, float* __restrict__ gbe,
-                                                             float* __restrict__ dbe_exact) {
-  // grid (n_p, d_p / 64): 64 columns per block; the 4 waves take the items i0 + w, i0 + w + 4, ... and their sums meet in LDS
-  // in wave order (fixed order -> deterministic); a latent that fires on most rows has hundreds of items
+                                                             float* __restrict__ dbe_exact, const unsigned int* __restrict__ multi) {
+  // A fixed grid of workgroups walks the units (listed latent, 64 columns); the 4 waves take the items i0 + w, i0 + w + 4, ... and
+  // their sums meet in LDS in wave order (fixed order -> deterministic); a latent that fires on most rows has hundreds of items.
+  // (Round 3 launched one workgroup per (latent, 64 columns) of the WHOLE dictionary -- 295 k at C3, nearly all of which read two
+  // words and left: the kernel's 98 us were mostly their dispatch.)
   __shared__ float red[2][4][64];
-  const int j = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int chunks = d_p >> 6;
+  const unsigned int units = multi[0] * (unsigned int)chunks;
+  for (unsigned int u = blockIdx.x; u < units; u += gridDim.x) {
+  const int j = (int)multi[4 + u / chunks], cy = (int)(u % chunks);
   const unsigned int i0 = item_start[j], i1 = item_start[j + 1];
-  if (i1 - i0 == 1) return;                           // written by its single work item itself
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.y * 64 + lane;
+  const int c = cy * 64 + lane;
   float a = 0.f, b = 0.f;
+#pragma unroll 8      // (eight trips' loads in flight, same order: a latent that fires on most rows has 64 trips per wave here)
   for (unsigned int i = i0 + w; i < i1; i += 4) {
     a += part[(int64_t)i * 2 * d_p + c];
     b += part[(int64_t)i * 2 * d_p + d_p + c];
@@ -412,10 +422,12 @@ __global__ __launch_bounds__(256) void sparse_combine_kernel(const float* __rest
     gWd[(int64_t)j * d_p + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
     gWe[(int64_t)j * d_p + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
   }
-  if (blockIdx.y == 0 && threadIdx.x == 0) {
+  if (cy == 0 && threadIdx.x == 0) {
     float s = 0.f;
     for (unsigned int i = i0; i < i1; ++i) s += pbe[i];
     dbe_exact[j] = s;
     gbe[j] = bf16_round(s);
+  }
+  __syncthreads();                                    // (red is reused by the next unit)
   }
 }
