@@ -23,6 +23,11 @@ run (45 ms) is timed on the ramp and reads ~7 % slower than any run of a second 
 workload itself: a second of a bare MFMA loop (tried: more power than the step draws) leaves the chip throttled and the
 following steps 10 % SLOWER (0.66 vs 0.60 ms) -- the steady state of a training run is the one its own steps settle into.
 The timed region is still exactly K steps after W warm-up steps.
+
+N > 1: the exchange is set up before the warm-up (peer exchange -> in-engine RCCL -> host-driven, whichever passes its checks; the
+peer exchange's first warm-up steps are audited against a torch.distributed all-reduce and the replicas' checksums compared after
+the run); `config.dp` / `config.dp_guards` of the line say which carrier ran and what was checked.  FREUD_BENCH_SHARE_GPU=1 (tests)
+puts every rank on GPU 0 with gloo as the host channel, so that this flow can run on a one-GPU box.
 """
 import argparse
 import json
