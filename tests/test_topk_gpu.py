@@ -574,3 +574,27 @@ def test_topk_multi_topk_with_auxk_matches_oracle(n_dead):
     got = eng.get_topk_state()
     assert np.mean((got == 0) != fired) < 0.01           # boundary ties in the 4k selection move a few latents
     eng.close()
+
+
+@pytest.mark.parametrize("B", [5, 40, 70])
+def test_total_variance_forms_match_oracle_on_bf16_batches(B):
+    """FVU = sum e^2 / total variance, the variance over the FILES of a batch (topkautoencoder.py:104-106).  bf16 activations take the
+    one-pass register kernels (up to 32 files: eight columns per thread; up to 64: four), more files the per-column kernel: all three
+    against the oracle on the same bf16-rounded batch."""
+    from freud_amd.engine import SaeEngine
+    d, n, k, T = 384, 1024, 8, 4
+    P, x = _make_case(d, n, k, B, T, seed=3)
+    xb = x.to(torch.bfloat16)
+    M = B * T
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.0)
+    eng.set_topk_options(1e9, T)
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    eng.forward_backward(xb.cuda())
+    eng.optimizer_step(1e-4)
+    m = eng.metrics()
+    out = O.topk_train_step(xb.float(), P, O.OptState(), k=k, lr=1e-4, clip_thresh=1.0, dead_mask=None, auxk_alpha=0.0, optimizer="adam")
+    tv = ((xb.float() - xb.float().mean(0)) ** 2).sum().item()
+    assert np.isfinite(m[0]) and tv > 0
+    assert m[0] == pytest.approx(out["fvu"].item(), rel=3e-3)
+    assert m[2] == pytest.approx(out["mse"].item(), rel=3e-3)
+    eng.close()
