@@ -201,8 +201,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = world > 1 or args.force_dist
-    if world > 1:
-        os.environ.setdefault("FREUD_P2P_FINEGRAINED", "1")      # (freud_amd/train_sae.py: peer-read buffers in fine-grained memory)
+    if use_dist:
+        # (freud_amd/train_sae.py: peer-read buffers in fine-grained memory; --force-dist too, so that the one-rank overhead figures
+        # are measured in the configuration multi-GPU runs actually use -- ADVICE r4)
+        os.environ.setdefault("FREUD_P2P_FINEGRAINED", "1")
     if use_dist:
         import torch.distributed as dist
         # RCCL writes its NCCL_DEBUG output (version banner, warnings) to STDOUT: send it to a file instead so that
@@ -229,6 +231,7 @@ def main():
     total_steps, base_lr = 100000, 4e-4
 
     def attempt(mode_override=None):
+        # (reads `use_dist` of the enclosing scope at call time: the plain reference pass of an N > 1 run switches it off)
         """engine + data-parallel set-up + spin-up + warm-up + the timed region.  Returns (engine, step function, seconds of the
         timed region, exchange in force, healthy)."""
         grads, works = None, []
@@ -358,6 +361,23 @@ def main():
         return eng, one_step, dt, dp_mode, healthy, audit_info
 
     args.dp_host_flag = args.dp_host
+    # N > 1 (or --force-dist): the SAME step without any exchange, on this rank's GPU, in this process, right before the data-parallel
+    # run -- K steps after W warm-up steps, max over the ranks like the headline.  ms_per_step minus this is what the exchange costs
+    # on the critical path (dp_timing.exposed_exchange_ms): the first multi-GPU run explains its own efficiency.
+    plain_ms = None
+    if use_dist and os.environ.get("FREUD_BENCH_PLAIN_REF", "1") != "0":
+        saved = (use_dist, args.dp_overlap)
+        use_dist, args.dp_overlap = False, 1
+        try:
+            eng0, _, dt0, _, _, _ = attempt()
+            eng0.close()
+            del eng0
+            plain_ms = dt0 / args.steps * 1e3
+        finally:
+            use_dist, args.dp_overlap = saved
+        t = torch.tensor([plain_ms], device=ctrl_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        plain_ms = float(t.item())
     eng, one_step, dt, dp_mode, healthy, audit_info = attempt()
     dp_fallback = None
     if not healthy:
@@ -395,16 +415,43 @@ def main():
     f8 = {"bf16": 0.0, "fp8": 0.4, "fp8bwd": 0.6}[args.precision] if args.variant == "l1" else 0.0
     step_peak = 1.0 / (f8 / PEAK_FP8_TFLOPS + (1.0 - f8) / PEAK_BF16_TFLOPS)
 
-    breakdown = None
-    if args.breakdown or args.precision != "bf16":        # every rank runs the extra steps (they contain collectives); rank 0 reports
+    breakdown, dp_timing = None, None
+    if args.breakdown or args.precision != "bf16" or use_dist:   # every rank runs the extra steps (they contain collectives); rank 0 reports
+        n_diag = 16 if use_dist else 10
         eng.profile(2)
-        for i in range(10):
+        for i in range(n_diag):
             one_step(args.warmup + args.steps + i)
-        breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in eng.kernel_times().items()}
+        kt = eng.kernel_times()
+        breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}
         eng.profile(0)
-        if rank == 0:
+        if use_dist:
+            # the exchange's own time per step, from HIP events on the stream it runs on (level-2 profile of n_diag extra steps after
+            # the timed region; a peer-exchange kernel's time INCLUDES its wait for the slowest rank): max and min over the ranks
+            xs, xn = kt.get("dp_exchange", (0.0, 0))
+            ss, sn = kt.get("dp_stats_exchange", (0.0, 0))
+            compute = sum(v[0] for k, v in kt.items() if k not in ("dp_exchange", "dp_stats_exchange", "fwd_bwd_total"))
+            loc = torch.tensor([xs / n_diag, ss / n_diag, compute / n_diag], device=ctrl_dev, dtype=torch.float64)
+            hi, lo = loc.clone(), loc.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            in_engine = dp_mode in ("p2p", "rccl")
+            dp_timing = {
+                "carrier": dp_mode,
+                "exchange_ms": float(hi[0]) if in_engine else None,
+                "exchange_ms_min_over_ranks": float(lo[0]) if in_engine else None,
+                "exchange_launches_per_step": xn / n_diag if in_engine else None,
+                "stats_exchange_ms": float(hi[1]) if in_engine else None,
+                "compute_kernels_ms": float(hi[2]),
+                "plain_ms_per_step": plain_ms,
+                "exposed_exchange_ms": (ms_per_step - plain_ms) if plain_ms is not None else None,
+                "how": f"exchange_ms / stats_exchange_ms: HIP events around the exchange launches of {n_diag} extra steps after the timed "
+                       "region (sum per step, max over ranks; includes the wait for the slowest rank); plain_ms_per_step: the same "
+                       "step WITHOUT any exchange, same process and GPU, K steps after W warm-up (max over ranks); "
+                       "exposed_exchange_ms = ms_per_step - plain_ms_per_step",
+            }
+        if rank == 0 and (args.breakdown or args.precision != "bf16"):
             print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
-        else:
+        if rank != 0 or not (args.breakdown or args.precision != "bf16"):
             breakdown = None
 
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the value
@@ -456,6 +503,8 @@ def main():
     }
     if breakdown:
         out["kernel_ms"] = breakdown
+    if dp_timing:
+        out["dp_timing"] = dp_timing
     if args.precision != "bf16" and breakdown:
         # the two fp8 GEMMs against the dense fp8 MFMA peak (2 M d n FLOPs each), next to the (bf16) dominant kernel above
         out["dtype"] = ("fp8 (e4m3 encoder/decoder GEMMs, fp32 accumulate) + bf16 backward" if args.precision == "fp8" else

@@ -98,13 +98,16 @@ enum KernelId {
   KID_TK_DWE,
   KID_TK_DSAE,
   KID_TK_AUX,
+  KID_EXCHANGE,        // data parallel: the gradient exchange (peer-exchange kernel or ncclAllReduce), on the stream it runs on
+  KID_STATS_XCHG,      // data parallel: the batch statistics (push inside finalize_losses, or the statistics kernel + its exchange)
   KID_STEP_TOTAL,
   KID_COUNT
 };
 static const char* kKernelNames[KID_COUNT] = {"prep_w", "prep_x", "enc_fwd_gemm", "dec_fwd_gemm", "fwd_fused_gemm", "dpre_gemm",
                                               "dw_gemm", "bwd_fused_gemm", "reduce_grads", "clip_adam", "topk_enc_gemm", "topk_select",
                                               "topk_decode", "topk_ddense_gemm", "topk_dwdec_gemm", "topk_dwenc_gemm",
-                                              "topk_dsaein_colsum", "topk_auxk_backward", "fwd_bwd_total"};
+                                              "topk_dsaein_colsum", "topk_auxk_backward", "dp_exchange", "dp_stats_exchange",
+                                              "fwd_bwd_total"};
 constexpr int EV_RING = 64;
 
 struct EvRing {
@@ -917,8 +920,13 @@ static void p2p_launch(sae_ctx* c, int channel, const P2PSeg* segs, int nseg, in
         dist_fail(c, "exchange audit", "snapshot copy failed");
     }
   }
+  // (level-2 profile only: the exchange's own duration -- launch to last barrier, i.e. including the wait for the slowest peer --
+  // on the stream it runs on; bench.py reports it as dp_timing.exchange_ms)
+  const int kid = channel == 0 ? KID_STATS_XCHG : KID_EXCHANGE;
+  ev_begin(c, kid, s);
   if (channel == 0) hipLaunchKernelGGL(p2p_allreduce_kernel<2>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
   else hipLaunchKernelGGL(p2p_allreduce_kernel<4>, dim3(grid), dim3(P2P_THREADS), 0, s, a);
+  ev_end(c, kid, s);
   if (hipGetLastError() != hipSuccess) dist_fail(c, "peer exchange launch", "hipLaunchKernel failed");
 }
 
@@ -939,7 +947,9 @@ static void exchange_range(sae_ctx* c, int64_t offset, int64_t count, hipStream_
     p2p_launch(c, 1, &g, 1, p2p_grid(count / 4), nullptr, s);
     return;
   }
+  ev_begin(c, KID_EXCHANGE, s);
   const ncclResult_t r = ncclAllReduce(c->G + offset, c->G + offset, (size_t)count, ncclFloat, ncclSum, c->comm, s);
+  ev_end(c, KID_EXCHANGE, s);
   if (r != ncclSuccess) dist_fail(c, "ncclAllReduce of a gradient range", ncclGetErrorString(r));
 }
 
@@ -981,6 +991,7 @@ static inline void exchange_staged(sae_ctx* c, float* stage, int64_t off, int ro
     dist_fail(c, "gradient block hand-over", "event record / wait failed");
     return;
   }
+  ev_begin(c, KID_EXCHANGE, c->comm_stream);
   const ncclResult_t r = ncclAllReduce(stage, stage, (size_t)rows * cols, ncclFloat, ncclSum, c->comm, c->comm_stream);
   if (r != ncclSuccess) {
     dist_fail(c, "ncclAllReduce of a staged gradient block", ncclGetErrorString(r));
@@ -989,6 +1000,7 @@ static inline void exchange_staged(sae_ctx* c, float* stage, int64_t off, int ro
   if (hipMemcpy2DAsync(c->G + off, (size_t)pitch * 4, stage, (size_t)cols * 4, (size_t)cols * 4, (size_t)rows, hipMemcpyDeviceToDevice,
                        c->comm_stream) != hipSuccess)
     dist_fail(c, "staged gradient block", "copy back failed");
+  ev_end(c, KID_EXCHANGE, c->comm_stream);
 }
 
 // Fused d = 384 backward, data parallel: column range [c0, c0 + cols) of dW and of db is final on stream s (`last`: with it
@@ -1023,10 +1035,12 @@ static void fused_exchange(sae_ctx* c, int range, int nranges, int c0, int cols,
   }
   // RCCL: contiguous buffers only -- the whole gradient in one piece (sae_dist_set_overlap refuses ranges without peer mappings)
   if (c->payload == SAE_DTYPE_BF16) {     // bf16 copy of the parameters' gradient + the fp32 scalars, one RCCL group
+    ev_begin(c, KID_EXCHANGE, xs);
     ncclResult_t r = ncclGroupStart();
     if (r == ncclSuccess) r = ncclAllReduce(c->Gb, c->Gb, (size_t)c->nparams, ncclBfloat16, ncclSum, c->comm, xs);
     if (r == ncclSuccess) r = ncclAllReduce(c->G + c->nparams, c->G + c->nparams, (size_t)tail, ncclFloat, ncclSum, c->comm, xs);
     const ncclResult_t e = ncclGroupEnd();
+    ev_end(c, KID_EXCHANGE, xs);
     if (r == ncclSuccess) r = e;
     if (r != ncclSuccess) dist_fail(c, "ncclAllReduce of the bf16 gradient", ncclGetErrorString(r));
     c->grads_in_bf16 = true;
@@ -1314,6 +1328,16 @@ static int p2p_selftest_body(sae_ctx* c) {
   HIP_TRY(hipMemcpy(keep.data(), c->G, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(keep_stats.data(), c->stats, (size_t)ns * 8, hipMemcpyDeviceToHost));
   unsigned int bad_total = 0, bad_kind[5] = {};
+  // whatever way this function is left, the gradient tail and the statistics head get back what they held: a context that falls
+  // back to RCCL or the host carrier must not inherit self-test patterns
+  struct Restore {
+    sae_ctx* c; std::vector<float>& g; std::vector<double>& st;
+    ~Restore() {
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(c->G, g.data(), g.size() * 4, hipMemcpyHostToDevice);
+      (void)hipMemcpy(c->stats, st.data(), st.size() * 8, hipMemcpyHostToDevice);
+    }
+  } restore{c, keep, keep_stats};
   auto collect = [&](int kind) -> int {
     unsigned int st[2] = {};
     HIP_TRY(hipMemcpyAsync(st, c->p2p_status, 8, hipMemcpyDeviceToHost, s));
@@ -1358,13 +1382,10 @@ static int p2p_selftest_body(sae_ctx* c) {
       if (rc) return rc;
     }
   }
-  HIP_TRY(hipMemcpy(c->G, keep.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->stats, keep_stats.data(), (size_t)ns * 8, hipMemcpyHostToDevice));
   if (c->dist_error) return fail(SAE_ERR_HIP, "peer exchange self-test: %s", c->dist_errmsg);
   if (bad_total) {
-    // tell the peers: a rank whose own sums were right must not go on with one whose sums were wrong
-    unsigned int code = P2P_ST_SELFTEST;
-    (void)hipMemcpy(c->p2p_status, &code, 4, hipMemcpyHostToDevice);
+    // (a rank whose own sums were right must not go on with one whose sums were wrong: the ranks agree on the outcome over the
+    // host channel -- freud_amd/dp.py: _all_agree -- and the ones that passed leave again with sae_p2p_leave)
     return fail(SAE_ERR_HIP, "peer exchange self-test: %u wrong values (fp32 %u, bf16 payload %u, strided block %u, fp64 statistics %u, statistics push %u) "
                              "in %d exchanges per payload form", bad_total, bad_kind[0], bad_kind[1], bad_kind[2], bad_kind[3], bad_kind[4], P2P_SELFTEST_EPOCHS);
   }
@@ -1699,9 +1720,11 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     } else if (gs && c->dist) {
       HIP_TRY(hipStreamWaitEvent(s, c->ev_stats, 0));      // the summed statistics have arrived
     }
+    if (push.world > 0) ev_begin(c, KID_STATS_XCHG, s);
     hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1024), 0, s, c->l1_part, (int)(Mp / 128), c->sq_part,
                        (int)(Mp / 128), c->scal, c->G + c->nparams, M, d, alpha, c->cnt_part, (int)(Mp / 128),
                        push.world > 0 ? (const double*)nullptr : gs, push);
+    if (push.world > 0) ev_end(c, KID_STATS_XCHG, s);
   }
   bool dw_chunked_any = false;
   if (backward) {
@@ -2372,7 +2395,9 @@ static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, v
       g.off = 0; g.pitch = c->stats_n; g.rows = 1; g.cols = (int)c->stats_n; g.kind = P2P_F64;
       p2p_launch(c, 0, &g, 1, p2p_grid(c->stats_n / 2), nullptr, c->comm_stream);
     } else {
+      ev_begin(c, KID_STATS_XCHG, c->comm_stream);
       NCCL_TRY(ncclAllReduce(c->stats, c->stats, (size_t)c->stats_n, ncclDouble, ncclSum, c->comm, c->comm_stream));
+      ev_end(c, KID_STATS_XCHG, c->comm_stream);
     }
     HIP_TRY(hipEventRecord(c->ev_stats, c->comm_stream));
   }

@@ -146,12 +146,30 @@ static void* pool_worker(void* idp) {
 
 static pthread_mutex_t g_job_mu = PTHREAD_MUTEX_INITIALIZER;      // one job at a time: a process may run two loaders (training + validation)
 
+// fork(): the child inherits g_pool.nth > 0 and possibly locked mutexes, but none of the worker threads -- its first job would wait
+// for `active` to reach 0 for ever (multiprocessing's 'fork' start method, torch DataLoader workers).  The child starts
+// with an empty pool and fresh locks; its workers are created by its own first job.
+static void pool_atfork_child(void) {
+  pthread_mutex_init(&g_pool.mu, NULL);
+  pthread_cond_init(&g_pool.cv_work, NULL);
+  pthread_cond_init(&g_pool.cv_done, NULL);
+  pthread_mutex_init(&g_job_mu, NULL);
+  g_pool.nth = 0;
+  g_pool.gen = 0;
+  g_pool.use = 0;
+  g_pool.active = 0;
+  g_pool.shutdown = 0;
+}
+static pthread_once_t g_atfork_once = PTHREAD_ONCE_INIT;
+static void pool_register_atfork(void) { pthread_atfork(NULL, NULL, pool_atfork_child); }
+
 static void pool_parallel_for(long items, int nthreads, item_fn fn, void* arg) {
   if (nthreads > POOL_MAX + 1) nthreads = POOL_MAX + 1;
   if (nthreads <= 1 || items <= 1) {
     for (long it = 0; it < items; ++it) fn(it, arg);
     return;
   }
+  pthread_once(&g_atfork_once, pool_register_atfork);
   pthread_mutex_lock(&g_job_mu);
   pthread_mutex_lock(&g_pool.mu);
   while (g_pool.nth < nthreads - 1) {              // the caller is the last "thread" of the job
@@ -207,4 +225,4 @@ void freud_gather_batch_copy(const char* base, const int64_t* idx, size_t count,
 }
 
 int freud_host_impl(void) { return pick_impl(); }
-int freud_host_version(void) { return 3; }
+int freud_host_version(void) { return 4; }

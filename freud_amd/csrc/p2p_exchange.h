@@ -43,6 +43,7 @@
 // The reference's CPU autocast rounds exactly these weight gradients to bf16 as well.
 #pragma once
 #include "common.h"
+#include "p2p_index.h"
 
 constexpr int P2P_MAX_WORLD = 8;
 constexpr int P2P_MAX_BLOCKS = 64;
@@ -69,14 +70,14 @@ struct P2PArgs {
   int nseg, rank, world, channel;
   unsigned long long epoch;
   unsigned long long timeout_ticks;          // of s_memrealtime (100 MHz)
-  unsigned int* status;                      // device word, sticky: P2P_ST_TIMEOUT | P2P_ST_POISONED (| P2P_ST_SELFTEST by the self-test)
+  unsigned int* status;                      // device word, sticky: P2P_ST_TIMEOUT | P2P_ST_POISONED
   unsigned int* status_host;                 // the same word in host-mapped memory (may be null): the step loop polls it for free
   double* gn_part;                           // optional: per-workgroup sum of squares of the REDUCED values (clip norm)
   int fault;                                 // test hook (FREUD_P2P_FAULT): 1 = skip the phase-2 copy of shard (rank + 1) % world
 };
 
 constexpr unsigned long long P2P_POISON = 1ull << 63;      // a flag value with this bit: the writer has left the protocol
-enum { P2P_ST_TIMEOUT = 1u, P2P_ST_POISONED = 2u, P2P_ST_SELFTEST = 4u };
+enum { P2P_ST_TIMEOUT = 1u, P2P_ST_POISONED = 2u };
 
 __device__ __forceinline__ void p2p_mark_failed(unsigned int* status, unsigned int* status_host, unsigned int code) {
   atomicOr(status, code);
@@ -150,19 +151,12 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2PArgs a) {
   for (int q = 0; q < P2P_MAX_WORLD; ++q) ss[q] = 0;
 
   // vectors [v0, v1) of slice (q, blockIdx.x) of segment g; address of vector v of segment g
+  // (p2p_index.h: plain index arithmetic, also compiled for the host by tests/test_p2p_index.py, which checks for worlds 1-8 and
+  // every grid that the slices of a segment cover it exactly once)
   auto slice_of = [&](const P2PSeg& g, int q, unsigned& v0, unsigned& v1) {
-    const unsigned total = (unsigned)g.rows * (unsigned)(g.cols / EPV);
-    const unsigned shard = (total + a.world - 1) / a.world, slice = (shard + gridDim.x - 1) / gridDim.x;
-    v0 = q * shard + blockIdx.x * slice;
-    v1 = v0 + slice;
-    if (v1 > (q + 1) * shard) v1 = (q + 1) * shard;
-    if (v1 > total) v1 = total;
+    p2p_slice_of((unsigned)g.rows * (unsigned)(g.cols / EPV), (unsigned)a.world, gridDim.x, (unsigned)q, blockIdx.x, v0, v1);
   };
-  auto elem_of = [&](const P2PSeg& g, unsigned v) -> int64_t {
-    if (g.rows == 1) return g.off + (int64_t)v * EPV;
-    const unsigned vpr = (unsigned)(g.cols / EPV), row = v / vpr;
-    return g.off + (int64_t)row * g.pitch + (int64_t)(v - row * vpr) * EPV;
-  };
+  auto elem_of = [&](const P2PSeg& g, unsigned v) -> int64_t { return p2p_elem_of(g.off, g.pitch, g.rows, g.cols, EPV, v); };
 
   __shared__ int fail_s;
   if (threadIdx.x == 0) fail_s = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky

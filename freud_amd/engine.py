@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -121,15 +122,23 @@ def load() -> C.CDLL:
         "sae_kernel_name": (C.c_char_p, [C.c_int]),
         "sae_dominant_kernel": (C.c_int, [vp]),
     }
+    skipped = []
     for name, (res, args) in sig.items():
         try:
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
         except AttributeError:
-            if os.environ.get("FREUD_SAE_LIB"):      # an OLDER build timed against this one (tools/ab_bench.sh): calling the entry point fails
+            # FREUD_SAE_ALLOW_OLD_LIB=1 (set by the A/B tools that time an OLDER build against this one, tools/ab_bench.sh): the
+            # missing entry points are named once and fail when called.  A user-supplied FREUD_SAE_LIB alone does NOT switch the
+            # header / library check off (a stale library would otherwise fail at an arbitrary call site mid-training).
+            if os.environ.get("FREUD_SAE_ALLOW_OLD_LIB") == "1":
+                skipped.append(name)
                 continue
-            raise
+            raise EngineError(f"{LIB_PATH} does not export {name}: the library is older than include/freud_sae.h "
+                              "(rebuild it, or set FREUD_SAE_ALLOW_OLD_LIB=1 for an A/B timing of an old build)") from None
         fn.restype = res
         fn.argtypes = args
+    if skipped:
+        print(f"freud_amd.engine: {LIB_PATH} lacks {', '.join(skipped)} (FREUD_SAE_ALLOW_OLD_LIB=1)", file=sys.stderr)
     _lib = lib
     return lib
 

@@ -318,11 +318,19 @@ class MemoryMappedActivationDataLoader:
         # the pinned ring and its HBM twin are allocated ONCE per loader and reused by every epoch (pinning 3 x 46 MB per epoch
         # cost several milliseconds of every epoch start; all work on them is finished when an epoch's iterator ends)
         key = (B, T * d, tdtype, depth, str(dev))
-        if getattr(self, "_ring_key", None) != key:
-            self._ring = ([torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)],
-                          [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)])
-            self._ring_key = key
-        pinned, hbm = self._ring
+        new_ring = lambda: ([torch.empty((B, T * d), dtype=tdtype, pin_memory=True) for _ in range(depth)],
+                            [torch.empty((B, T * d), dtype=tdtype, device=dev) for _ in range(depth)])
+        # the shared ring belongs to ONE live iterator at a time: a second iterator on the same loader (or an epoch whose
+        # predecessor's gather worker has not ended, below) gets buffers of its own
+        shared = not getattr(self, "_ring_busy", False)
+        if shared:
+            if getattr(self, "_ring_key", None) != key:
+                self._ring = new_ring()
+                self._ring_key = key
+            pinned, hbm = self._ring
+            self._ring_busy = True
+        else:
+            pinned, hbm = new_ring()
         free = [threading.Semaphore(1) for _ in range(depth)]
         copied = [None] * depth     # copy-stream event of the H2D copy that last read pinned[slot]
         ready: "queue.Queue" = queue.Queue()
@@ -377,9 +385,14 @@ class MemoryMappedActivationDataLoader:
                 consumed[slot] = ev
         finally:
             stop.set()
-            th.join(timeout=5)
+            th.join(timeout=60)         # (the worker looks at `stop` between batches; a gather stalls at worst for one batch's page faults)
             torch.cuda.current_stream(dev).synchronize()     # the ring is reused by the next epoch: nothing of this one is in flight
             copy_stream.synchronize()
+            if shared:
+                if th.is_alive():       # a straggler may still write into pinned[slot]: the ring is abandoned to it, the next epoch
+                    self._ring_key = None   # allocates a fresh one (round 4 ignored the join result: silent batch corruption)
+                    self._ring = None
+                self._ring_busy = False
 
 
 def write_shards(folder: str, layer_name: str, rows: np.ndarray, tensor_shape: Sequence[int],

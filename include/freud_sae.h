@@ -205,7 +205,10 @@ int sae_dist_set_payload(sae_ctx* ctx, int dtype);
  *                       cannot be reached makes it FAIL after min(FREUD_P2P_TIMEOUT_MS, 20 s) (default 120000: a liveness bound of the run's steps)
  *                       instead of hanging.  Afterwards sae_forward_backward / sae_step run the data-parallel protocol
  *                       through the peer exchange; sae_dist_world() == world.  FREUD_P2P_FINEGRAINED=1 (read by sae_create)
- *                       puts the three peer-read buffers in fine-grained memory (no cache maintenance needed; slower).
+ *                       puts the three peer-read buffers in fine-grained memory (a peer never caches their lines non-coherently, so
+ *                       correctness does not rest on cache maintenance; measured free for the LOCAL kernels on one GPU at C2 and C4,
+ *                       profiles/r04_ab_finegrained_c{2,4}.txt; its cross-device cost is unmeasured).  Default of train() / bench.py
+ *                       for WORLD_SIZE > 1.
  *   sae_dist_set_overlap  fused d = 384 path: launch the backward in `nranges` column-tile ranges; each range's gradient is
  *                       exchanged on the communication stream under the next range's backward (needs the peer exchange:
  *                       RCCL sums contiguous buffers only).  1 (default) = one launch, exchanged in line.

@@ -263,6 +263,17 @@ def test_four_processes_one_gpu_train_like_one_process(tmp_path):
     _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=4)
 
 
+@pytest.mark.parametrize("case", ["l1_fused", "l1_generic"])
+def test_eight_processes_one_gpu_train_like_one_process(tmp_path, case):
+    """EIGHT ranks -- the world the peer exchange is built for and the size of the driver's scaling run -- as eight processes on
+    one GPU (8 x <= 48 exchange workgroups are co-resident on 256 CUs): seven peers per exchange workgroup, eight shards, every
+    `q < world` index path of p2p_allreduce_kernel (only 2 and 4 ranks had ever executed).  l1_fused: the whole gradient
+    in line (segments of 98 304, 256 and TWO vectors: the last one is smaller than the world, so six ranks own an empty shard);
+    l1_generic (d = 1280): strided 2-D column blocks on the communication stream.  The host-side model of the same index functions
+    for worlds 1-8 is tests/test_p2p_index.py."""
+    _ranks_vs_single_process(tmp_path, case, "float32", 1, world=8)
+
+
 def test_two_processes_coarse_grained_buffers(tmp_path):
     """Multi-rank runs put the peer-read buffers in fine-grained memory by default (train_sae.py); FREUD_P2P_FINEGRAINED=0 keeps
     them coarse-grained -- the form whose cross-device visibility rests on the fences alone -- and must train the same."""
@@ -281,7 +292,7 @@ def _ranks_vs_single_process(tmp_path, case, payload, overlap, world, extra_env=
     import os
     from freud_amd.loader import write_shards
     d, n, T = {"l1_fused": (384, 1024, 64), "l1_generic": (1280, 512, 32), "topk": (384, 1024, 32)}[case]
-    n_files, B, steps = 16, (2 if world == 2 else 1), 4
+    n_files, B, steps = (16 if world <= 4 else 32), (2 if world == 2 else 1), 4
     g = torch.Generator().manual_seed(11)
     rows = ((torch.relu(torch.randn(n_files * T, 16, generator=g)) * 0.2) @ torch.randn(16, d, generator=g)).reshape(n_files, T * d)
     for f, frac in ((0, 0.5), (3, 0.3), (5, 0.6), (10, 0.2)):
@@ -596,7 +607,7 @@ def _run_bench_ranks(world, extra_args, extra_env=None, timeout=900):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_with_several_ranks_prints_one_line_with_the_guards_verdict(world):
     """The N > 1 flow of bench.py -- the one the driver's scaling run takes -- end to end on one GPU: set-up of the peer exchange
     (start-up self-test), audited warm-up steps (the exchanged gradient against a torch.distributed all-reduce of the same
@@ -616,6 +627,12 @@ def test_bench_with_several_ranks_prints_one_line_with_the_guards_verdict(world)
     assert g["audited_steps"] == 3 and g["max_rel_diff_vs_torch_distributed"] < 1e-5, g
     assert g["replica_checksums"] == "identical" and g["replica_checksums_after_run"] == "identical", g
     assert np.isfinite(d["loss"]["recon"]) and d["roofline"]["kernel_launches"] >= 6
+    # the line explains its own efficiency: the exchange's duration, and the step without any exchange timed in
+    # the same process -- exposed = ms_per_step - plain
+    t = d["dp_timing"]
+    assert t["carrier"] == "p2p" and t["exchange_launches_per_step"] == 1.0, t
+    assert 0 < t["exchange_ms_min_over_ranks"] <= t["exchange_ms"] and t["stats_exchange_ms"] > 0, t
+    assert t["plain_ms_per_step"] > 0 and t["exposed_exchange_ms"] == pytest.approx(d["ms_per_step"] - t["plain_ms_per_step"], abs=1e-9), t
 
 
 def test_bench_with_a_broken_peer_exchange_falls_back_and_says_so():

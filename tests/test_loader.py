@@ -187,3 +187,36 @@ def test_two_loaders_share_the_host_thread_pool(tmp_path):
     for th in ths:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_host_thread_pool_survives_fork():
+    """libfreud_host.so's pthread pool is process-global.  A child forked AFTER the parent has run a batch (multiprocessing
+    'fork', torch DataLoader workers) inherits `nth > 0` but none of the worker threads; without the pthread_atfork handler its first
+    batch waits for ever.  Run in a subprocess (the fork must not happen inside the pytest process with its own threads)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, signal
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from freud_amd.loader import _host_lib
+lib = _host_lib()
+rows = np.random.default_rng(0).standard_normal((16, 4096)).astype(np.float32)
+idx = np.arange(16, dtype=np.int64)
+def batch():
+    out = np.zeros((16, 4096), np.uint16)
+    lib.freud_gather_batch_f32_to_bf16(rows.ctypes.data, idx.ctypes.data, 16, 4096, out.ctypes.data, 4096, 1024, 8)
+    return out
+ref = batch()                       # the parent's pool now has 7 workers
+pid = os.fork()
+if pid == 0:
+    signal.alarm(20)                # a hang ends the child with SIGALRM
+    ok = np.array_equal(batch(), ref) and np.array_equal(batch(), ref)
+    os._exit(0 if ok else 3)
+_, status = os.waitpid(pid, 0)
+assert np.array_equal(batch(), ref)         # the parent's pool still works
+sys.exit(0 if (os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0) else 4)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FREUD_SAE_ALLOW_OLD_LIB=1      # freud_amd/engine.py: an older build may lack entry points of the current header
 # same-box A/B timing: interleaved bench runs of the in-tree library ("current") and the given alternates
 for i in 1 2 3; do
   for lib in "" "$@"; do

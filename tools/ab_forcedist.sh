@@ -1,4 +1,5 @@
 #!/bin/bash
+export FREUD_SAE_ALLOW_OLD_LIB=1      # freud_amd/engine.py: an older build may lack entry points of the current header
 # same-box, interleaved: the C2 step alone against the same step with the whole data-parallel protocol on one rank
 # (peer exchange fp32 / bf16 payload, in-engine RCCL, host-driven) -- separate bench runs differ by +-1.5 %, pairs do not
 for i in 1 2 3; do

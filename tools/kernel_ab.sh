@@ -1,4 +1,5 @@
 #!/bin/bash
+export FREUD_SAE_ALLOW_OLD_LIB=1      # freud_amd/engine.py: an older build may lack entry points of the current header
 # Same-box comparison of per-kernel times between engine builds (run ON the GPU box from the repo root):
 #   LIBS="current name1 name2" KERNELS="substr1,substr2" bash tools/kernel_ab.sh <out dir under gpurun_out/> <bench.py args...>
 # "current" = freud_amd/lib/libfreud_sae.so, other names = build/ab/libfreud_sae_<name>.so (tools/build_variant.sh).
