@@ -14,6 +14,7 @@
 #include "../../include/freud_sae.h"
 #include "l1_kernels.h"
 #include "gemm256.h"
+#include "gemm256s.h"
 #include "gemm256_fp8.h"
 #include "l1_fp8.h"
 #include "dp_kernels.h"
@@ -23,6 +24,7 @@
 #include <unistd.h>
 
 static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
+static bool g_no_stream = false;       // FREUD_GEMM_STREAM=0 / debug_flags 86: the K = d GEMMs in gemm256.h's tile form (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
@@ -377,6 +379,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   c->nparams = 2 * c->nW + c->n_p + c->d_p;
   const int64_t ntail = SAE_NUM_METRICS + c->n_p;       // metrics + did_fire flags ride in the all-reduced buffer
   g_force_gemm128 = c->cfg.force_gemm128 == 1;
+  g_no_stream = c->cfg.debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
   const int splits = choose_splits(c->n_p / 128, c->d_p / 128, Mp / 64);
   c->dw_splits = splits;
 #define TALLOC(ptr, bytes)                                                                                   \
@@ -580,6 +583,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     return SAE_OK;
   }
   g_force_gemm128 = cfg->force_gemm128 == 1;
+  g_no_stream = cfg->debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
   c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
   if (const char* ov = getenv("FREUD_DW_SPLITS")) {       // timing sweeps of the split-K factor of the weight-gradient GEMM
     const int v = atoi(ov);
@@ -1495,8 +1499,30 @@ extern "C" int sae_dist_poll(sae_ctx* c) {
 // ------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------
+// true: launch_gemm runs this GEMM in the streaming form of gemm256s.h (the K = d GEMMs: row-major x row-major, one K segment,
+// thousands of static output tiles) -- callers that size a per-workgroup output of the functor ask first
+template <int AM, int BM_, class Epi>
+static bool gemm_streams(const GemmArgs& g) {
+  if constexpr (!(G2_STREAM && epi_stream<Epi>::value && AM == OP_ROW && BM_ == OP_ROW)) return false;
+  if (g_no_stream || g_force_gemm128 || g.nbm % 2 != 0 || g.nbn % 2 != 0) return false;
+  return !g.dyn && g.splits == 1 && g.tail_tiles == 0 && g.ktiles == g.ktiles0 && g.ktiles >= 2 && g.seg1_gate == nullptr && g.lda == g.ldb &&
+         (g.nbm / 2) * (g.nbn / 2) >= 4 * G2_PERSIST_STATIC;
+}
+
 template <int AM, int BM_, class Epi>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
+  if constexpr (G2_STREAM && epi_stream<Epi>::value && AM == OP_ROW && BM_ == OP_ROW) {
+    if (gemm_streams<AM, BM_, Epi>(g)) {
+      auto kerns = gemm256s_bf16_kernel<Epi>;
+      LDS_ATTR(kerns, G2S_LDS_BYTES, g_device);
+      GemmArgs g2 = g;
+      g2.nbm = g.nbm / 2;
+      g2.nbn = g.nbn / 2;
+      hipLaunchKernelGGL(kerns, dim3(G2_PERSIST_STATIC), dim3(512), G2S_LDS_BYTES, s, g2, epi);
+      HIP_TRY(hipGetLastError());
+      return SAE_OK;
+    }
+  }
   if (!g_force_gemm128 && g.nbm % 2 == 0 && g.nbn % 2 == 0) {   // both output dimensions are multiples of 256
     auto kern256 = gemm256_bf16_kernel<AM, BM_, Epi>;
     constexpr bool a3 = G2_A3 && epi_deep_a_ring<Epi>::value;     // (gemm256.h: three A slots + two B slots)
@@ -1537,7 +1563,22 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, hipStream_t s) {
 }
 
 template <class Epi>
+static bool gemm8_streams(const Gemm8Args& g) {
+  if constexpr (!(G2_STREAM && epi_stream<Epi>::value)) return false;
+  return !g_no_stream && g.ktiles >= 2 && g.lda == g.ldb && g.nbm * g.nbn >= 4 * G2_PERSIST_STATIC;
+}
+
+template <class Epi>
 static int launch_gemm8(const Gemm8Args& g, const Epi& epi, hipStream_t s) {
+  if constexpr (G2_STREAM && epi_stream<Epi>::value) {
+    if (gemm8_streams<Epi>(g)) {
+      auto kerns = gemm256s_fp8_kernel<Epi>;
+      LDS_ATTR(kerns, G2S_LDS_BYTES, g_device);
+      hipLaunchKernelGGL(kerns, dim3(G2_PERSIST_STATIC), dim3(512), G2S_LDS_BYTES, s, g, epi);
+      HIP_TRY(hipGetLastError());
+      return SAE_OK;
+    }
+  }
   auto kern = gemm256_fp8_kernel<Epi>;
   constexpr int lds = g8_lds_bytes<Epi>();
   LDS_ATTR(kern, lds, g_device);
@@ -1649,6 +1690,8 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       g.nbm = (int)(Mp / 256); g.nbn = n_p / 256; g.ktiles = d_p / 128;
       EpiEnc8 e{};
       e.c = c->c; e.c8 = c->c8; e.bias = b; e.scal8 = c->scal8; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = n_p / 128;
+      // (streaming form: one L1 partial per workgroup, the rest of the per-tile range zeroed -- as for EpiEnc below)
+      if (gemm8_streams<EpiEnc8>(g)) HIP_TRY(hipMemsetAsync(c->l1_part, 0, (size_t)(Mp / 128) * (n_p / 128) * 4, s));
       ev_begin(c, KID_ENC_FWD, s);
       rc = launch_gemm8(g, e, s);
       ev_end(c, KID_ENC_FWD, s);
@@ -1676,6 +1719,9 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     EpiEnc e{};
     e.c = c->c; e.bias = b; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = g.nbn;
     e.skip_store = c->cfg.debug_flags == 70;
+    // (streaming form: one L1 partial per WORKGROUP in l1_part[0 .. grid); finalize_losses sums the whole per-tile range, so the
+    // rest of it is zeroed -- 4 bytes per 128x128 tile)
+    if (gemm_streams<OP_ROW, OP_ROW, EpiEnc>(g)) HIP_TRY(hipMemsetAsync(c->l1_part, 0, (size_t)g.nbm * g.nbn * 4, s));
     ev_begin(c, KID_ENC_FWD, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
     ev_end(c, KID_ENC_FWD, s);

@@ -31,6 +31,19 @@
 
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime / s_memrealtime around the tile loop per wave into a.stamps[wg][wave][8]
 // ([3] iterations, [4] loop cycles, [5] loop time in 10 ns ticks, [6] prologue cycles, [7] whole-kernel cycles).
+#ifndef FF2_PACKED
+#define FF2_PACKED 1         // tools/build_variant.sh A/B switch: 0 = round 4's element-wise latent arithmetic
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 template <typename T, bool PAD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -227,14 +240,17 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     const int64_t dst_rstride = j >= 2 ? (int64_t)a.n_p : 0;
     f32x4 bq[4];
     float l1_it = 0.f;
+    f32x2_t l1_pk = {0.f, 0.f}, pr = {0.f, 0.f};
     bf16x8 cw;
     const f32x16 S = Scur;
 
     // 48 MFMA slots: EVEN slot i = decoder MFMA i / 2 of tile j-1 (m = 12 ks + 3 mb + dtl: accumulators rotate), ODD slot i =
     // encoder MFMA i / 2 of tile j+1 (a chain through one accumulator: interleaved with the decoder its dependent issue is
     // never back to back).  Fragments are requested >= 6 slots ahead.
-#pragma unroll
-    for (int i = 0; i < 48; ++i) {
+    // (static_for: the slot index is a template constant -- `#pragma unroll` gives up silently above LLVM's size threshold, and the
+    // loop then indexes every register array dynamically: 1.8 KB of scratch per lane, seen in round 5 after a few added lines)
+    static_for<0, 48>([&](auto slot_tag) {
+      constexpr int i = decltype(slot_tag)::value;
       // ---- fragment prefetch
       if ((i & 1) == 0 && i <= 40) ring[(i / 2 + 3) % RING] = enc_frag(SLOT_E, i / 2 + 3);         // encoder k = i/2 + 3 (slot i + 7)
       if (i == 42 || i == 44 || i == 46) ring[(i - 42) / 2] = enc_frag(SLOT_EN, (i - 42) / 2);      // k = 0..2 of the NEXT iteration
@@ -259,6 +275,35 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         glds4(a.bias + (int64_t)jb * FF_BN, (unsigned)(lane * 4),
               (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + FF_FIXED_LDS + ((j + 2) & (FF_BIAS_RING_TILES - 1)) * FF_BN * 4)));
       }
+#if FF2_PACKED
+      // latent elements in PAIRS (round 5): pair p = elements 2 p, 2 p + 1 of S at the gaps 4 + 4 p (both rounded to bf16 by ONE
+      // v_cvt_pk_bf16_f32, then back to fp32: two shifts) and 6 + 4 p (bias by one v_pk_add_f32, two max, the L1 sum by one
+      // v_pk_add_f32, the pair's bf16 by one v_cvt_pk).  The loop is bound by the vector instructions it issues between its MFMAs
+      // (113 per iteration by the disassembly: 32 adds, 24 conversions, 16 shifts, 16 max, 16 AGPR reads); this form issues 24 fewer.
+      // Same values per element; the L1 partial sums associate differently (two chains instead of one).
+      if (i >= 4 && i <= 32 && (i & 3) == 0) {
+        const int e = (i - 4) >> 1;                      // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{S[e], S[e + 1]}, bf16x2));
+        pr = f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+      }
+      if (i >= 6 && i <= 34 && (i & 3) == 2) {
+        const int e = (i - 6) >> 1;
+        // rounded to bf16 BEFORE the fp32 bias add (CPU autocast).  (inline asm: hipcc scalarises this one packed add into two
+        // v_add_f32 although both operands sit in aligned register pairs)
+        f32x2_t sv;
+        const f32x2_t bp = {bq[e >> 2][e & 3], bq[e >> 2][(e & 3) + 1]};
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(sv) : "v"(pr), "v"(bp));
+        // ReLU on the BITS (signed integer max with 0: negative floats, -0.0 included, are negative integers): fmaxf on the
+        // output of the asm above costs a second, canonicalising v_max per element
+        sv = f32x2_t{__int_as_float(max(__float_as_int(sv[0]), 0)), __int_as_float(max(__float_as_int(sv[1]), 0))};
+        if (PAD) sv = row_ok ? sv : f32x2_t{0.f, 0.f};
+        l1_pk += sv;
+        cw[e & 7] = (bf16_t)sv[0];
+        cw[(e & 7) + 1] = (bf16_t)sv[1];
+        if ((e & 7) == 6)      // the eight values of k-step e >> 3: one 16-byte chunk of this lane's row
+          *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e >> 3)]) = cw;
+      }
+#else
       // latent element e at gap 4 + 2 e
       if (i >= 4 && i <= 34 && (i & 1) == 0) {
         const int e = (i - 4) >> 1;                      // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
@@ -269,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         if ((e & 7) == 7)      // the eight values of k-step e >> 3: one 16-byte chunk of this lane's row
           *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e >> 3)]) = cw;
       }
+#endif
       // two full-line pieces of the finished pair per iteration: LDS reads in one gap, global store 8 gaps later
       if (i == 29 || i == 33) {
         const int p = 2 * (PH & 1) + (i == 33);
@@ -293,8 +339,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(i / 2) % RING], xfrag[i / 2], Snxt, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    l1_acc += l1_it;
+    });
+    l1_acc += l1_it + (l1_pk[0] + l1_pk[1]);
   };
   if (STAMP) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int j4 = 0; j4 < a.ntiles; j4 += 4) {            // ntiles is a multiple of 4 (n_p is a multiple of 128)

@@ -17,6 +17,7 @@
 // The unscaled instruction is reached through the scaled builtin with zero scales (hipcc selects v_mfma_f32_32x32x64_f8f6f4).
 #pragma once
 #include "gemm256.h"
+#include "gemm256s.h"
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -175,4 +176,122 @@ template <class Epi>
 constexpr int g8_lds_bytes() {
   return G2_A3 && epi_deep_a_ring<Epi>::value ? G2_A3_LDS_BYTES
          : epi_rounds_first<Epi>::value && G2_BF16_LDS_BYTES > G2_LDS_BYTES ? G2_BF16_LDS_BYTES : G2_LDS_BYTES;
+}
+
+// Streaming form (gemm256s.h) of the fp8 K = d GEMMs (the fp8 encoder: ten 128-byte K tiles per output tile, so the tile form's
+// prologue + epilogue weigh twice what they do in the bf16 kernel): one continuous stream of K tiles per workgroup, the next output
+// tile's first two K tiles requested by the hand-over slots of this tile's last two, wave-private epilogue in the CU's last 32 KiB.
+// Functors opt in with STREAM (the bf16 interface of gemm256s.h: the accumulator is rounded to bf16 first, exact under the
+// power-of-two operand scales).
+template <class Epi>
+__global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
+  const int nk = g.ktiles, ntiles = g.nbm * g.nbn;
+  epi.s_begin();
+  int blk = blockIdx.x;
+  if (blk < ntiles) {
+    int bm, bn;
+    tile_coords(xcd_remap(blk, ntiles), g.nbm, g.nbn, bm, bn);
+    const unsigned char* a_cur = g.A + (int64_t)(bm * G2_BM) * g.lda;
+    const unsigned char* b_cur = g.B + (int64_t)(bn * G2_BN) * g.ldb;
+    unsigned voff[4];          // (lda == ldb: both operands are [rows][d_p] -- the host launches this form only then)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) voff[q] = g8_src_off(4 * w + q, lane, g.lda);
+    typedef __attribute__((address_space(3))) char* lptr_t;
+    const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+    const unsigned piece0 = (unsigned)__builtin_amdgcn_readfirstlane(4 * w * 1024);
+    auto issue = [&](const unsigned char* pa, const unsigned char* pb, int stage, int q) {
+      const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
+      glds16_x2(pa, pb, voff[q], voff[q], dst, dst + G2_OPER_BYTES);
+    };
+    char* eb = smem + 2 * G2_STAGE_BYTES + w * 4096;
+    const int rr = lane >> 3, c8 = 8 * (lane & 7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(a_cur, b_cur, 0, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(a_cur + 128, b_cur + 128, 1, q);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    i32x8 fa[4], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = g8_frag(smem, 128 * wm + 32 * i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+    f32x16 acc[4][2];        // (started from a zero MFMA source by the first K step of every tile: gemm256s.h)
+    int cur = 0;
+    for (;;) {
+      const int nblk = blk + gridDim.x;
+      const bool more = nblk < ntiles;
+      int bm2 = bm, bn2 = bn;
+      if (more) tile_coords(xcd_remap(nblk, ntiles), g.nbm, g.nbn, bm2, bn2);
+      const unsigned char* a_nxt = more ? g.A + (int64_t)(bm2 * G2_BM) * g.lda : a_cur + (int64_t)(nk - 2) * 128;
+      const unsigned char* b_nxt = more ? g.B + (int64_t)(bn2 * G2_BN) * g.ldb : b_cur + (int64_t)(nk - 2) * 128;
+      auto pa = [&](int j) { return j < nk ? a_cur + (int64_t)j * 128 : a_nxt + (int64_t)(j - nk) * 128; };
+      auto pb = [&](int j) { return j < nk ? b_cur + (int64_t)j * 128 : b_nxt + (int64_t)(j - nk) * 128; };
+      const int row_w = bm * G2_BM + 128 * wm, col_l = bn * G2_BN + 64 * wn + c8;
+      typename Epi::SPre pre0[4];
+      auto ktile = [&](auto first_tag, int kt) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char* sa = smem + cur * G2_STAGE_BYTES;
+        const char* sb = sa + G2_OPER_BYTES;
+        const char* na = smem + (cur ^ 1) * G2_STAGE_BYTES;
+        const char* nb = na + G2_OPER_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const char* xa = s == 0 ? sa : na;
+          const char* xb = s == 0 ? sb : nb;
+          const int xs = s == 0 ? 1 : 0;
+          if (s == 0) {
+            issue(pa(kt + 1), pb(kt + 1), cur ^ 1, 2);
+            issue(pa(kt + 1), pb(kt + 1), cur ^ 1, 3);
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(pa(kt + 2), pb(kt + 2), cur, 0);
+            issue(pa(kt + 2), pb(kt + 2), cur, 1);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[xs][j] = g8_frag(xb, 64 * wn + 32 * j, xs, lane);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if constexpr (FIRST) {
+                if (s == 0) {
+                  f32x16 zero;
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+                  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], zero, 0, 0, 0, 0, 0, 0);
+                } else {
+                  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+                }
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+              }
+            }
+            fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        cur ^= 1;
+      };
+      ktile(std::true_type{}, 0);
+      for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{}, kt);
+      // (the functor's loads only now: with 64 fragment registers next to the 128 accumulators the K loop has no room to carry them
+      // through its last K tile -- requested there, the kernel spilled)
+      epi.s_tile(row_w, col_l);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre0[q] = epi.s_prefetch(row_w + 8 * q + rr, col_l);
+      if (row_w + 128 > epi.s_rows()) g2s_epilogue<true>(acc, eb, row_w, col_l, pre0, epi);
+      else g2s_epilogue<false>(acc, eb, row_w, col_l, pre0, epi);
+      if (!more) break;
+      blk = nblk; bm = bm2; bn = bn2;
+      a_cur = a_nxt; b_cur = b_nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  epi.s_end(reinterpret_cast<float*>(smem + 2 * G2_STAGE_BYTES));
 }

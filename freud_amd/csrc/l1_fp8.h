@@ -226,6 +226,50 @@ struct EpiEnc8 {
     const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
   }
+  // ---- streaming form (gemm256s.h / gemm256_fp8.h): as EpiEnc's, with the operand scales undone (a power of two: exact on the
+  // bf16-rounded accumulator) and the second, e4m3 copy of the latent
+  static constexpr bool STREAM = true;
+  struct SPre {};
+  f32x4 sb0, sb1;
+  __device__ void s_begin() { l1 = 0.f; }
+  __device__ int64_t s_rows() const { return M; }
+  __device__ void s_tile(int, int col) {
+    sb0 = *reinterpret_cast<const f32x4*>(bias + col);
+    sb1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+    inv = scal8[S8_INV_ENC];
+    sc = scal8[S8_SC];
+  }
+  __device__ SPre s_prefetch(int, int) const { return SPre{}; }
+  template <bool PARTIAL>
+  __device__ void s_apply(int row, int col, f32x4 v0, f32x4 v1, const SPre&) {
+    bf16x8 o;
+    float cv[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cv[j] = fmaxf(bf16_round(v0[j] * inv) + sb0[j], 0.f);
+      cv[4 + j] = fmaxf(bf16_round(v1[j] * inv) + sb1[j], 0.f);
+      if (PARTIAL && row >= M) cv[j] = cv[4 + j] = 0.f;
+      l1 += cv[j] + cv[4 + j];
+      o[j] = (bf16_t)cv[j];
+      o[4 + j] = (bf16_t)cv[4 + j];
+    }
+    EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    const u32x2 q = {pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc), pack4_fp8(cv[4] * sc, cv[5] * sc, cv[6] * sc, cv[7] * sc)};
+    EPI_STORE(reinterpret_cast<u32x2*>(c8 + (int64_t)row * n_p + col), q);
+  }
+  __device__ void s_tile_end(int, int) {}
+  __device__ void s_end(float* scratch) {
+    const float v = wave_sum(l1);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += scratch[w];
+      l1_part[blockIdx.x] = s;
+    }
+  }
 };
 
 // dpre epilogue of the fp8 dc GEMM (SAE_PREC_FP8_BWD): dpre = (bf16(acc / (s_g s_w)) + 1/M) [c > 0], column sums for db --
@@ -275,4 +319,6 @@ struct EpiDpre8 {
       db_part[(int64_t)row_tile * n_p + col0_ + t] = s;
     }
   }
+  // (no streaming form: next to the fp8 kernel's 64 fragment registers the gate's prefetched latents do not fit without spills;
+  // SAE_PREC_FP8_BWD is opt-in and keeps the tile form of gemm256_fp8.h)
 };

@@ -208,6 +208,46 @@ struct EpiEnc {
     const float s = block_sum_256_lds(l1, scratch);
     if ((threadIdx.x & 255) == 0) l1_part[tile_id] = s;
   }
+  // ---- streaming form (gemm256s.h): the lane's 8 bias values per tile in registers, the L1 sum kept per thread over ALL the
+  // workgroup's tiles and left as ONE partial per workgroup (l1_part[blockIdx.x]; the host zeroes the other entries)
+  static constexpr bool STREAM = true;
+  struct SPre {};
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 sbp[4], l1p;          // the lane's 8 bias values as pairs (v_pk_add_f32), the L1 sum as a pair of partial sums
+  __device__ void s_begin() { l1p = f32x2{0.f, 0.f}; }
+  __device__ int64_t s_rows() const { return M; }
+  __device__ void s_tile(int, int col) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+    sbp[0] = f32x2{b0[0], b0[1]}; sbp[1] = f32x2{b0[2], b0[3]}; sbp[2] = f32x2{b1[0], b1[1]}; sbp[3] = f32x2{b1[2], b1[3]};
+  }
+  __device__ SPre s_prefetch(int, int) const { return SPre{}; }
+  // v: the accumulators ALREADY rounded to bf16 (exact as floats).  Packed fp32 adds for the bias and the L1 sum: this epilogue is
+  // bound by its vector-instruction count (28 per 8 latents here, 44 in the element-wise form)
+  template <bool PARTIAL>
+  __device__ void s_apply(int row, int col, f32x4 v0, f32x4 v1, const SPre&) {
+    f32x2 sv[4] = {f32x2{v0[0], v0[1]} + sbp[0], f32x2{v0[2], v0[3]} + sbp[1], f32x2{v1[0], v1[1]} + sbp[2], f32x2{v1[2], v1[3]} + sbp[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sv[k] = f32x2{fmaxf(sv[k][0], 0.f), fmaxf(sv[k][1], 0.f)};
+      if (PARTIAL && row >= M) sv[k] = f32x2{0.f, 0.f};
+      l1p += sv[k];
+    }
+    const bf16x8 o = {(bf16_t)sv[0][0], (bf16_t)sv[0][1], (bf16_t)sv[1][0], (bf16_t)sv[1][1],
+                      (bf16_t)sv[2][0], (bf16_t)sv[2][1], (bf16_t)sv[3][0], (bf16_t)sv[3][1]};
+    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+  }
+  __device__ void s_tile_end(int, int) {}
+  __device__ void s_end(float* scratch) {
+    const float v = wave_sum(l1p[0] + l1p[1]);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += scratch[w];
+      l1_part[blockIdx.x] = s;
+    }
+  }
 };
 
 // x_hat = bf16(c W^T); masked residual; dx_hat = bf16(2 alpha (x_hat - x) [x != -1] / count)
@@ -323,6 +363,52 @@ struct EpiDpre {
       db_part[(int64_t)row_tile * n_p + col0_ + t] = s;
     }
   }
+  // ---- streaming form (gemm256s.h): a wave owns 128 rows x 64 columns, i.e. exactly the rows of one db_part row; the lane's 8
+  // column sums over its 16 rows are added over the 8 lanes that share the columns (fixed order) and stored by lanes 0-7
+  static constexpr bool STREAM = true;
+  struct SPre { u32x4 cw; };          // eight latents as bf16 pairs
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 scp[4], invp;
+  __device__ void s_begin() {}
+  __device__ int64_t s_rows() const { return (int64_t)1 << 62; }      // (rows >= M carry c = 0: the gate already zeroes them)
+  __device__ void s_tile(int, int) {
+    invp = f32x2{scal[2], scal[2]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scp[k] = f32x2{0.f, 0.f};
+  }
+  __device__ SPre s_prefetch(int row, int col) const { return SPre{EPI_LOAD(reinterpret_cast<const u32x4*>(c + (int64_t)row * n_p + col))}; }
+  // the gate c > 0 on the bf16 BITS: the upper element of a pair is positive iff the dword, as a signed integer, exceeds 0xFFFF; the
+  // lower one iff the dword shifted left by 16 is positive (-0.0, which a max(x, 0) may leave, is negative as an integer)
+  template <bool PARTIAL>
+  __device__ void s_apply(int row, int col, f32x4 v0, f32x4 v1, const SPre& pre) {
+    f32x2 g[4] = {f32x2{v0[0], v0[1]} + invp, f32x2{v0[2], v0[3]} + invp, f32x2{v1[0], v1[1]} + invp, f32x2{v1[2], v1[3]} + invp};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cw = (int)pre.cw[k];
+      g[k] = f32x2{(cw << 16) > 0 ? g[k][0] : 0.f, cw > 0xFFFF ? g[k][1] : 0.f};
+      scp[k] += g[k];
+    }
+    const bf16x8 o = {(bf16_t)g[0][0], (bf16_t)g[0][1], (bf16_t)g[1][0], (bf16_t)g[1][1],
+                      (bf16_t)g[2][0], (bf16_t)g[2][1], (bf16_t)g[3][0], (bf16_t)g[3][1]};
+    EPI_STORE(reinterpret_cast<bf16x8*>(dpre + (int64_t)row * n_p + col), o);
+  }
+  __device__ void s_tile_end(int row_w, int col) {
+    f32x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = scp[j >> 1][j & 1];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (j < 4) lo[j] = v; else hi[j - 4] = v;
+    }
+    if ((threadIdx.x & 63) < 8) {
+      float* dst = db_part + (int64_t)(row_w / GEMM_BM) * n_p + col;
+      *reinterpret_cast<f32x4*>(dst) = lo;
+      *reinterpret_cast<f32x4*>(dst + 4) = hi;
+    }
+  }
+  __device__ void s_end(float*) {}
 };
 
 // split-K partial slab store for dW

@@ -207,6 +207,57 @@ struct EpiTopkEnc {
       *reinterpret_cast<unsigned int*>(tmax + (int64_t)(row0_ + t) * (n_p >> 6) + (col0_ >> 6)) = m[0] | (m[1] << 16);
     }
   }
+  // ---- streaming form (gemm256s.h, fp32 variant: the bias joins the fp32 accumulator before the ONE rounding).  Lane (rq = lane / 4,
+  // cp = lane % 4) owns columns 8 cp .. + 7 of each 32-column half j of its wave's 64 columns -- exactly one 64-column tile of
+  // tmax -- and rows rq + 16 q + 32 i.  Per row: max over the lane's 8 values of half 0, then of half 1, then over the 4 lanes
+  // of the row (two DPP quad swaps); lane cp == 0 stores the 16-bit maximum.
+  static constexpr bool STREAM = true;
+  static constexpr bool STREAM_F32 = true;
+  struct SPre {};
+  f32x4 sb[2][2];         // bias of the lane's columns: [half j][first / second four]
+  unsigned int smax[8];   // running maximum of row (i, q) over the two halves
+  __device__ void s_begin() {}
+  __device__ int64_t s_rows() const { return M; }
+  __device__ void s_tile(int row0, int col) {      // col = first column of the lane's 8 in half 0
+    partial_ = row0 + GEMM_BM > M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sb[j][0] = *reinterpret_cast<const f32x4*>(bias + col + 32 * j);
+      sb[j][1] = *reinterpret_cast<const f32x4*>(bias + col + 32 * j + 4);
+    }
+  }
+  __device__ void s_apply(int e, int row, int col, f32x4 v0, f32x4 v1) {     // e = 4 i + 2 j + q (compile-time constant)
+    const int j = (e >> 1) & 1, iq = 2 * (e >> 2) + (e & 1);
+    const s16x2 zero = {0, 0};
+    const f32x4 b0 = sb[j][0], b1 = sb[j][1];
+    s16x2 p[4];
+    p[0] = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v0[0] + b0[0], v0[1] + b0[1]}, bf16x2));
+    p[1] = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v0[2] + b0[2], v0[3] + b0[3]}, bf16x2));
+    p[2] = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v1[0] + b1[0], v1[1] + b1[1]}, bf16x2));
+    p[3] = __builtin_bit_cast(s16x2, __builtin_convertvector(f32x2{v1[2] + b1[2], v1[3] + b1[3]}, bf16x2));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = __builtin_elementwise_max(p[k], zero);
+    if (partial_ && row >= M) p[0] = p[1] = p[2] = p[3] = zero;
+    EPI_STORE(reinterpret_cast<u32x4*>(pre + (int64_t)row * n_p + col),
+              (u32x4{__builtin_bit_cast(unsigned int, p[0]), __builtin_bit_cast(unsigned int, p[1]),
+                     __builtin_bit_cast(unsigned int, p[2]), __builtin_bit_cast(unsigned int, p[3])}));
+    if (tmax) {
+      const u16x2 a = __builtin_elementwise_max(__builtin_bit_cast(u16x2, p[0]), __builtin_bit_cast(u16x2, p[1]));
+      const u16x2 b = __builtin_elementwise_max(__builtin_bit_cast(u16x2, p[2]), __builtin_bit_cast(u16x2, p[3]));
+      const unsigned int mm = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
+      unsigned int m1 = max(mm & 0xFFFFu, mm >> 16);
+      if (j == 0) {
+        smax[iq] = m1;
+      } else {
+        m1 = max(m1, smax[iq]);
+        m1 = max(m1, (unsigned int)__builtin_amdgcn_update_dpp((int)m1, (int)m1, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        m1 = max(m1, (unsigned int)__builtin_amdgcn_update_dpp((int)m1, (int)m1, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        if ((threadIdx.x & 3) == 0) tmax[(int64_t)row * (n_p >> 6) + (col >> 6)] = (unsigned short)m1;
+      }
+    }
+  }
+  __device__ void s_tile_end(int, int) {}
+  __device__ void s_end(float*) {}
 };
 
 // bias rounded to bf16 and kept as float (what the autocast addmm adds): once per step, n_p values

@@ -242,8 +242,8 @@ def _run_children(script, cfg_path, world, extra_env, timeout=900):
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()           # the exact children this test started
-    for pr, (so, se) in zip(procs, outs):
-        assert pr.returncode == 0, (so[-2000:], se[-4000:])
+    if any(pr.returncode != 0 for pr in procs):      # every rank's tail: the rank that reports is rarely the one that failed
+        raise AssertionError("\n".join(f"--- rank {r}: rc {pr.returncode}\n{so[-600:]}\n{se[-1500:]}" for r, (pr, (so, se)) in enumerate(zip(procs, outs))))
     return outs
 
 

@@ -11,6 +11,7 @@
 
 #include "gemm256w4.h"
 #include "../../freud_amd/csrc/l1_kernels.h"
+#include "../../freud_amd/csrc/gemm256s.h"
 
 struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias / ReLU)
 #ifdef KB_BF16EPI
@@ -29,6 +30,20 @@ struct EpiBf16 {          // plain bf16 store (the encoder epilogue without bias
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(out + (int64_t)row * ld + col));
   }
   __device__ void tile_end(float*) {}
+  // streaming form (gemm256s.h; mode 4)
+  static constexpr bool STREAM = true;
+  struct SPre {};
+  __device__ void s_begin() {}
+  __device__ void s_tile(int, int) {}
+  __device__ SPre s_prefetch(int, int) const { return SPre{}; }
+  __device__ int64_t s_rows() const { return (int64_t)1 << 62; }
+  template <bool PARTIAL>
+  __device__ void s_apply(int row, int col, f32x4 v0, f32x4 v1, const SPre&) {
+    bf16x8 o = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(out + (int64_t)row * ld + col));
+  }
+  __device__ void s_tile_end(int, int) {}
+  __device__ void s_end(float*) {}
 };
 
 #ifdef KB_A3
@@ -43,7 +58,8 @@ int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536, N = argc > 2 ? atoll(argv[2]) : 40960, K = argc > 3 ? atoll(argv[3]) : 1280;
   int kmajor = argc > 4 ? atoi(argv[4]) : 0;
   const int splits = argc > 5 ? atoi(argv[5]) : 1;
-  const bool compare = kmajor == 3;
+  const bool compare = kmajor == 3 || kmajor == 5;      // 5: the 8-wave tile form against the streaming form (mode 4)
+  const bool compare_stream = kmajor == 5;
   if (compare) kmajor = 0;
   bf16_t *A, *B, *C;
   float* slab = nullptr;
@@ -76,8 +92,19 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(256), G2_LDS_BYTES, 0, g, e);
   };
+  auto run_stream = [&](bf16_t* out) {
+    EpiBf16 e{out, N};
+    auto kern = gemm256s_bf16_kernel<EpiBf16>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G2S_LDS_BYTES));
+#ifndef KB_STREAM_GRID
+#define KB_STREAM_GRID 512
+#endif
+    hipLaunchKernelGGL(kern, dim3(KB_STREAM_GRID), dim3(512), G2S_LDS_BYTES, 0, g, e);
+  };
   auto run = [&]() {
-    if (mode == 2) {
+    if (mode == 4) {
+      run_stream(C);
+    } else if (mode == 2) {
       run_w4(C);
     } else if (!kmajor) {
       EpiBf16 e{C, N};
@@ -106,7 +133,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(C, 0, M * N * 2));
     CK(hipMemset(C2, 0xFF, M * N * 2));
     run();
-    run_w4(C2);
+    if (compare_stream) run_stream(C2); else run_w4(C2);
     CK(hipDeviceSynchronize());
     std::vector<unsigned short> c1((size_t)M * N), c2((size_t)M * N);
     CK(hipMemcpy(c1.data(), C, (size_t)M * N * 2, hipMemcpyDeviceToHost));
@@ -150,7 +177,14 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> hs(ntile * 4);
     CK(hipMemcpy(hs.data(), dbuf, ntile * 32, hipMemcpyDeviceToHost));
     double a = 0, b = 0, c = 0;
+    if (mode == 4) {       // streaming form: per WORKGROUP {tiles, K-loop cycles, epilogue cycles, whole-kernel cycles} (wave 0)
+      double tl = 0, lp = 0, ep = 0, tot = 0;
+      for (size_t i = 0; i < (size_t)KB_STREAM_GRID && i < ntile; ++i) { tl += hs[4 * i]; lp += hs[4 * i + 1]; ep += hs[4 * i + 2]; tot += hs[4 * i + 3]; }
+      printf("streaming form, per tile (shader cycles, wave 0): K loop %.0f (%.0f per K tile)  epilogue %.0f  other %.0f  -> shares %.1f %% / %.1f %% / %.1f %%\n",
+             lp / tl, lp / tl / g.ktiles, ep / tl, (tot - lp - ep) / tl, 100 * lp / tot, 100 * ep / tot, 100 * (tot - lp - ep) / tot);
+    }
     for (size_t i = 0; i < ntile; ++i) { a += hs[4 * i]; b += hs[4 * i + 1]; c += hs[4 * i + 2]; }
+    if (mode != 4)
     printf("per tile (s_memtime cycles, 100 MHz-independent counter units): prologue %.0f  K loop %.0f  epilogue %.0f  -> shares %.1f %% / %.1f %% / %.1f %%\n",
            a / ntile, b / ntile, c / ntile, 100 * a / (a + b + c), 100 * b / (a + b + c), 100 * c / (a + b + c));
   }
@@ -163,7 +197,7 @@ int main(int argc, char** argv) {
     printf("slab hash %016llx\n", hsh);
   }
   const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
-  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
+  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 4 ? "row-stream" : mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
          (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
   return 0;
 }
