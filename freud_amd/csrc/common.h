@@ -116,6 +116,18 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
       : "memory");
 }
 
+// A loop whose index is a TEMPLATE constant.  `#pragma unroll` gives up silently above LLVM's size threshold; the loop then stays
+// rolled and every register array it indexes goes to the stack (fwd_fused2.h's slot loop in round 5: 1.8 KB of scratch per lane after
+// a few added lines; topk_select_reg_kernel<44>: its key arrays, 1 KB per lane).
+#include <type_traits>
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // Balanced form of the fused d = 384 backward (bwd_fused.h): workgroup k takes quanta [k m, (k + 1) m) of the tile-major list of

@@ -32,17 +32,9 @@
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime / s_memrealtime around the tile loop per wave into a.stamps[wg][wave][8]
 // ([3] iterations, [4] loop cycles, [5] loop time in 10 ns ticks, [6] prologue cycles, [7] whole-kernel cycles).
 #ifndef FF2_PACKED
-#define FF2_PACKED 1         // tools/build_variant.sh A/B switch: 0 = round 4's element-wise latent arithmetic
+#define FF2_PACKED 0         // 1 = the packed form below: 91 instead of 111 vector instructions per iteration and NOT faster (profiles/r05_ab_fwd_packed_valu.txt)
 #endif
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
 
 template <typename T, bool PAD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a) {
@@ -247,10 +239,16 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     // 48 MFMA slots: EVEN slot i = decoder MFMA i / 2 of tile j-1 (m = 12 ks + 3 mb + dtl: accumulators rotate), ODD slot i =
     // encoder MFMA i / 2 of tile j+1 (a chain through one accumulator: interleaved with the decoder its dependent issue is
     // never back to back).  Fragments are requested >= 6 slots ahead.
-    // (static_for: the slot index is a template constant -- `#pragma unroll` gives up silently above LLVM's size threshold, and the
-    // loop then indexes every register array dynamically: 1.8 KB of scratch per lane, seen in round 5 after a few added lines)
+    // (FF2_PACKED: static_for -- the slot index as a template constant: `#pragma unroll` gives up silently above LLVM's size
+    // threshold, and with the packed form's few added lines the loop stayed rolled and indexed every register array dynamically,
+    // 1.8 KB of scratch per lane.  The shipped element-wise form keeps round 4's pragma loop: bit-identical code.)
+#if FF2_PACKED
     static_for<0, 48>([&](auto slot_tag) {
       constexpr int i = decltype(slot_tag)::value;
+#else
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+#endif
       // ---- fragment prefetch
       if ((i & 1) == 0 && i <= 40) ring[(i / 2 + 3) % RING] = enc_frag(SLOT_E, i / 2 + 3);         // encoder k = i/2 + 3 (slot i + 7)
       if (i == 42 || i == 44 || i == 46) ring[(i - 42) / 2] = enc_frag(SLOT_EN, (i - 42) / 2);      // k = 0..2 of the NEXT iteration
@@ -339,7 +337,11 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(i / 2) % RING], xfrag[i / 2], Snxt, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+#if FF2_PACKED
     });
+#else
+    }
+#endif
     l1_acc += l1_it + (l1_pk[0] + l1_pk[1]);
   };
   if (STAMP) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }

@@ -448,10 +448,11 @@ template <int MAXV>
 __device__ __forceinline__ int topk_count_ge(const u32x4 (&keys)[MAXV], unsigned T, int t, int* red) {
   const unsigned tp = T * 0x00010001u;
   unsigned c2 = 0;
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v)
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value;
 #pragma unroll
     for (int q = 0; q < 4; ++q) c2 += (((keys[v][q] | 0x80008000u) - tp) >> 15) & 0x00010001u;
+  });
   int c = (int)((c2 & 0xFFFFu) + (c2 >> 16));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
@@ -465,7 +466,7 @@ __device__ __forceinline__ int topk_count_ge(const u32x4 (&keys)[MAXV], unsigned
 __host__ __device__ __forceinline__ int vec_bits_t_offset(int n_p) { return ((n_p / 8 + 15) / 16) * 16; }
 constexpr int VEC_BITS_T_BYTES = 256 * 16;
 #ifndef SEL_OCC
-#define SEL_OCC 4        // waves per SIMD the compact AuxK select is compiled for
+#define SEL_OCC 3        // waves per SIMD the compact AuxK select is compiled for
 #endif
 template <int MAXV, bool COMPACT = false>
 __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
@@ -542,8 +543,9 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     // behind the table ([256 threads][16 bytes], zeros past the row's end) -- one 16-byte load instead of twelve predicated byte
     // loads (with their branches ~180 of the ~800 instructions this phase issued per thread; the phase is issue-bound)
     const u32x4 cbw = *reinterpret_cast<const u32x4*>(vec_bits + vec_bits_t_offset(n_p) + 16 * t);
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) cbits[v] = (cbw[v >> 2] >> (8 * (v & 3))) & 0xFFu;
+    static_for<0, MAXV>([&](auto v_tag_) {
+      constexpr int v = decltype(v_tag_)::value; cbits[v] = (cbw[v >> 2] >> (8 * (v & 3))) & 0xFFu;
+    });
   }
   auto cbits_of = [&](int v, int g) -> unsigned { return CBITS_AHEAD ? cbits[CBITS_AHEAD ? v : 0] : (g < nvec ? (unsigned)vec_bits[g] : 0u); };
   // Round 4: ALL of the thread's row loads are issued before the first one is used (MAXV <= 12).  With the load and its masking in
@@ -551,21 +553,21 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   // compact select (stamps: `-DSEL_STAMP`, bench.py --dbg 67).
   constexpr bool LOADS_AHEAD = MAXV <= 12;
   if (LOADS_AHEAD) {
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
+    static_for<0, MAXV>([&](auto v_tag_) {
+      constexpr int v = decltype(v_tag_)::value;
       const int g = v * 256 + t;
       u32x4 w = {0u, 0u, 0u, 0u};
       // (COMPACT: a non-zero byte implies g < nvec)
       if (CBITS_AHEAD ? cbits_of(v, g) != 0u : (g < nvec && (!COMPACT || cbits_of(v, g) != 0u))) w = __builtin_nontemporal_load(src + g);
       keys[v] = w;
-    }
+    });
   }
   // Compact select with the dead bits up front: a vector past the row's end has no dead bits and was not loaded, so the bound is
   // the block-uniform "any vector of this slot in the row" (a scalar branch) instead of a per-lane one (exec-mask save / restore
   // around every vector's masking).  (With NO branch at all hipcc spilled 186 registers instead of 40 and the kernel ran 60 % slower.)
   {
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v) {
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value;
     const int g = v * 256 + t;
     u32x4 w = {0u, 0u, 0u, 0u};
     unsigned cb = 0;
@@ -598,11 +600,12 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     }
     keys[v] = w;
     cand[v] = cb;
-  }
+  });
   }
   int ncand_l = 0;
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v) ncand_l += __popc(cand[v]);
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value; ncand_l += __popc(cand[v]);
+  });
   SEL_MARK();                                          // [1] row loaded and masked
   int ncand;
   (void)block_excl_scan_256(ncand_l, sc, &ncand);
@@ -610,9 +613,10 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   const int k = k_req < ncand ? k_req : ncand;     // where(dead, pre, -inf).topk(k_aux): k_aux <= num_dead by construction
   if (k <= 0) {
     if (write_dense) {
-#pragma unroll
-      for (int v = 0; v < MAXV; ++v)
+      static_for<0, MAXV>([&](auto v_tag_) {
+        constexpr int v = decltype(v_tag_)::value;
         if (v * 256 + t < nvec) dst[v * 256 + t] = u32x4{0u, 0u, 0u, 0u};
+      });
     }
     if (COMPACT)
       for (int g = t; g < cvec; g += 256) dst[g] = u32x4{0u, 0u, 0u, 0u};
@@ -639,14 +643,15 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     // packed largest (m1) and second largest (m2) key of the thread's even columns (low halves) and odd columns (high halves)
     typedef __attribute__((ext_vector_type(2))) unsigned short us2;
     us2 m1 = {0, 0}, m2 = {0, 0};
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v)
+    static_for<0, MAXV>([&](auto v_tag_) {
+      constexpr int v = decltype(v_tag_)::value;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const us2 b = __builtin_bit_cast(us2, keys[v][q]);
         m2 = __builtin_elementwise_max(m2, __builtin_elementwise_min(m1, b));
         m1 = __builtin_elementwise_max(m1, b);
       }
+    });
     // k <= 256: one value per lane (its maximum), the kw-th largest of 64 with kw = ceil(k / 4) <= 64;
     // k  > 256: four values per lane (two largest of each half: four different elements of the row), kw-th largest of 256
     const bool four = k > 256;
@@ -683,8 +688,8 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
       const int wv = t >> 6, lane = t & 63;
       unsigned int* seg = cand_pk + wv * TOPK_SEG_CAP;
       int wcount = 0;                                  // wave-uniform
-#pragma unroll
-      for (int v = 0; v < MAXV; ++v)
+      static_for<0, MAXV>([&](auto v_tag_) {
+        constexpr int v = decltype(v_tag_)::value;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const unsigned int w = keys[v][q];
@@ -705,6 +710,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
             }
           }
         }
+      });
       if (lane == 0) wave_cnt[wv] = wcount;
       topk_pad_segment<TOPK_SEG_CAP>(seg, wcount, lane);
       __syncthreads();
@@ -851,8 +857,8 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
         if (write_dense) {                             // the masked dense row for those who read it (validation, fallbacks)
           __syncthreads();
           const unsigned int thr = thr_pk;
-#pragma unroll
-          for (int v = 0; v < MAXV; ++v) {
+          static_for<0, MAXV>([&](auto v_tag_) {
+            constexpr int v = decltype(v_tag_)::value;
             const int g = v * 256 + t;
             if (g < nvec) {
               u32x4 o;
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
               }
               dst[g] = o;
             }
-          }
+          });
         }
         done = true;
       }
@@ -884,8 +890,8 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   if (COMPACT && npos <= k) {
     // no more positive dead latents than k_aux in this row: all of them are selected (and the zeros that fill the selection up
     // carry nothing) -- each thread stores its own positive candidates at their compact positions, nothing to rank or scan
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
+    static_for<0, MAXV>([&](auto v_tag_) {
+      constexpr int v = decltype(v_tag_)::value;
       const int g = v * 256 + t;
       if (g < nvec && cand[v] != 0u) {
         const int base = vec_rank[g];
@@ -895,7 +901,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
           if (((cand[v] >> e) & 1u) && key != 0) crow[base + __popc(cand[v] & ((1u << e) - 1u))] = key;
         }
       }
-    }
+    });
     return;
   }
   unsigned T = 0;
@@ -915,22 +921,24 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   // element equal to T (no boundary tie): only a row with more ties than it needs ranks them, one block scan per
   // vector-row (block-uniform branch).
   int tie_l = 0;
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v)
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const unsigned key = (keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
       tie_l += (key == T && ((cand[v] >> e) & 1u)) ? 1 : 0;
     }
+  });
   int tie_tot;
   (void)block_excl_scan_256(tie_l, sc, &tie_tot);
   const bool skip_zero = COMPACT && T == 0;          // zero-valued ties: nothing downstream of the compact row sees them
   const bool rank_ties = !skip_zero && tie_tot > need_ties;
   // ---- emit
   int sel_l = 0, tie_base = 0;
-  unsigned selmask[MAXV];
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v) {
+  // (the selection mask of a vector rides in bits 8-15 of its candidate word: a third per-vector array -- 44 registers at MAXV = 44 --
+  // was what pushed that instantiation over the register file)
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value;
     unsigned gm = 0, tm = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -954,27 +962,27 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
         }
       tm = keep;
     }
-    selmask[v] = gm | tm;
-    sel_l += __popc(selmask[v]);
-  }
+    cand[v] = (cand[v] & 0xFFu) | ((gm | tm) << 8);
+    sel_l += __popc(gm | tm);
+  });
   int sel_tot;
   int pos = block_excl_scan_256(sel_l, sc, &sel_tot);
-#pragma unroll
-  for (int v = 0; v < MAXV; ++v) {
+  static_for<0, MAXV>([&](auto v_tag_) {
+    constexpr int v = decltype(v_tag_)::value;
     const int g = v * 256 + t;
     if (g < nvec) {
       if (write_dense) {          // the masked dense row: only the inference / validation calls and the dense fallbacks read it
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const unsigned m = ((selmask[v] >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | ((selmask[v] >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
+          const unsigned m = (((cand[v] >> 8) >> (2 * q)) & 1u ? 0x0000FFFFu : 0u) | (((cand[v] >> 8) >> (2 * q + 1)) & 1u ? 0xFFFF0000u : 0u);
           o[q] = keys[v][q] & m;
         }
         dst[g] = o;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if ((selmask[v] >> e) & 1u) {
+        if (((cand[v] >> 8) >> e) & 1u) {
           const int col = 8 * g + e;
           const unsigned short key = (unsigned short)((keys[v][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
           if (pos < kcap) {
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
           if (COMPACT && key != 0) crow[vec_rank[g] + __popc(cand[v] & ((1u << e) - 1u))] = key;
         }
     }
-  }
+  });
   for (int j = sel_tot + t; j < kcap; j += 256) ti[j] = -1;
 #ifdef SEL_STAMP
   SEL_MARK();                                          // slow path done

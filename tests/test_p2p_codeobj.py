@@ -137,3 +137,41 @@ def test_statistics_push_orders_payload_before_epoch(disasm, key):
     _check_poll(ins, 1)
     ld = [k for k, i in enumerate(ins) if i.startswith(("global_load_dwordx2", "flat_load_dwordx2")) and "sc0" in i and "sc1" in i]
     assert len(ld) >= 3, "epoch poll + two payload loads, all system scope"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Register spills: no kernel of the shipped code object may touch scratch memory, with ONE documented
+# exception -- topk_select_reg_kernel<44, true> (the compact AuxK select of dictionaries above 24 576 latents: 176 key
+# registers + candidate words per thread; round 5 took its key arrays off the stack, 1072 -> 292 bytes of scratch per lane).
+# A spill that creeps into a hot kernel (round 5: a few added lines pushed fwd_fused2's slot loop over LLVM's unroll threshold
+# and every accumulator array went to the stack) fails here, on the build host, instead of showing up as a slow GPU run.
+# ---------------------------------------------------------------------------------------------------------------------
+SCRATCH_ALLOWED = {"_Z22topk_select_reg_kernelILi44ELb1EEvPKDF16bPDF16bPiPfPKhPKiiiiilPtiS6_S8_S6_S8_S8_": 400}
+
+
+def test_no_kernel_spills_to_scratch():
+    if not os.path.exists(LIB):
+        pytest.fail(f"{LIB} missing: build first")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    tmp = tempfile.mkdtemp(prefix="freud_codeobj_")
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(LIB, so)
+        subprocess.run([OBJDUMP, "--offloading", so], check=True, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f][0]
+        r = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(tmp, co)], check=True, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
+        counts, cur = {}, None
+        for line in r.stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                continue
+            if cur and re.search(r"\bscratch_(load|store)", line):
+                counts[cur] = counts.get(cur, 0) + 1
+        assert len(r.stdout) > 1_000_000, "disassembly suspiciously short"
+        bad = {k: v for k, v in counts.items() if v > SCRATCH_ALLOWED.get(k, 0)}
+        assert not bad, f"kernels with scratch (spill) instructions: {bad}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

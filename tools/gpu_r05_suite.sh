@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5: the whole GPU suite on the current build + the AuxK benches the select-kernel changes touch
+O=gpurun_out/r05_suite; mkdir -p $O
+timeout 3000 python -m pytest tests -m gpu -q -x > $O/gputest.txt 2>&1; echo "rc=$?" >> $O/gputest.txt
+parse='
+import sys,re,json
+t=sys.stdin.read()
+k=json.loads(re.search(r"level-2 profile\): (\{.*?\})", t).group(1))
+m=re.search(r"\"ms_per_step\": ([0-9.]+)", t).group(1)
+print(" ".join("%s %.3f" % (n, v) for n, v in k.items() if v > 0.25 and n != "fwd_bwd_total"), "step", m)'
+{
+for rep in 1 2; do
+  echo -n "[C3 31% dead] "; python bench.py --variant topk --d 768 --n 24576 --k 64 --steps 30 --warmup 5 --dead-threshold 1e5 --no-cpu-baseline --breakdown 2>&1 | grep -E "per-kernel|ms_per_step" | tr '\n' ' ' | python -c "$parse"
+  echo -n "[TopK d1280 n40960 k32, 4000 dead] "; python bench.py --variant topk --d 1280 --n 40960 --k 32 --steps 20 --warmup 5 --dead-threshold 1e15 --dead-latents 4000 --no-cpu-baseline --breakdown 2>&1 | grep -E "per-kernel|ms_per_step" | tr '\n' ' ' | python -c "$parse"
+done
+} > $O/auxk.txt 2>&1
+tail -4 $O/gputest.txt; cat $O/auxk.txt
