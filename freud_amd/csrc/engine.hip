@@ -2147,10 +2147,22 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
         hipLaunchKernelGGL((topk_select_reg_kernel<12, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
                            c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
                            (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd, c->dead_cols);
-      else
-        hipLaunchKernelGGL((topk_select_reg_kernel<44, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
+      else if (n_p <= 2048 * 44) {
+        // dictionaries above 24 576 latents (round 5): copy the dead columns into the compact rows, then the GENERAL select in
+        // place on those rows -- <12> for up to 24 576 dead latents, <44> beyond; the device-side count picks (topk_kernels.h:
+        // compact_mode).  The one-kernel form needed 44 key vectors per thread: 7.8 ms per step at n = 40 960 with 4000 dead.
+        hipLaunchKernelGGL((topk_select_reg_kernel<12, true>), dim3((unsigned)Mp), dim3(256), 0, s, c->pre, c->aux_dense,
                            c->aux_idx, (float*)nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 0,
-                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd, c->dead_cols);
+                           (const unsigned char*)nullptr, c->vec_rank, c->vec_bits, c->tkd, c->dead_cols, 1);
+        hipLaunchKernelGGL((topk_select_reg_kernel<12>), dim3((unsigned)Mp), dim3(256), 0, s, c->aux_dense, c->aux_dense,
+                           c->aux_idx, (float*)nullptr, (const unsigned char*)nullptr, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 1,
+                           (const unsigned char*)nullptr, (const int*)nullptr, (const unsigned char*)nullptr, c->tkd, (const int*)nullptr, 2);
+        hipLaunchKernelGGL((topk_select_reg_kernel<44>), dim3((unsigned)Mp), dim3(256), 0, s, c->aux_dense, c->aux_dense,
+                           c->aux_idx, (float*)nullptr, (const unsigned char*)nullptr, c->tk + 1, 0, c->k_aux_cap, n, n_p, M, vo, 1,
+                           (const unsigned char*)nullptr, (const int*)nullptr, (const unsigned char*)nullptr, c->tkd, (const int*)nullptr, 2);
+      } else {
+        return fail(SAE_ERR_INVALID, "the compact AuxK path serves dictionaries up to %d latents", 2048 * 44);
+      }
     } else if (aux) {
       launch_select(c->aux_dense, c->aux_idx, c->aux_vals, nullptr, c->dead, c->tk + 1, 0, c->k_aux_cap);
     }

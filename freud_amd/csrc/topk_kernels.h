@@ -478,7 +478,17 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
                                                                const int* __restrict__ vec_rank = nullptr,
                                                                const unsigned char* __restrict__ vec_bits = nullptr,
                                                                const int* __restrict__ tkd = nullptr,
-                                                               const int* __restrict__ dead_cols = nullptr) {
+                                                               const int* __restrict__ dead_cols = nullptr,
+                                                               int compact_mode = 0) {
+  // compact_mode (round 5; dictionaries above 24 576 latents, where the COMPACT instantiation would need 44 key vectors per thread
+  // -- 176 registers + candidate words, the last kernel of the code object that spilled, and 7.8 ms per step at n = 40 960):
+  //   1  (COMPACT instantiation) only COPY the row's values at the dead columns into the compact row and return;
+  //   2  (general instantiation) select IN PLACE on such compact rows: the row is tkd[TKD_NDP] entries long (pitch n_p), its first
+  //      tkd[TKD_ND] entries are candidates; write_dense leaves the masked compact row the AuxK GEMMs read.  An instantiation whose
+  //      MAXV does not fit the row -- or is larger than it needs -- returns at once: the host launches <12> and <44> back to back
+  //      and the device-side count decides (no host synchronisation).
+  // The selection is the one the COMPACT path makes: top k_aux of the dead latents by value, ties by lowest column (the compact
+  // index keeps the column order); zero-valued fill-ins are written as the zeros they are.
   __shared__ int red[4];
   __shared__ int sc[4];
   const int t = threadIdx.x;
@@ -499,7 +509,13 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
   if (only_flagged && !only_flagged[row]) return;     // the tile-driven kernel already selected this row
   const int k_req = k_ptr ? *k_ptr : k_fixed;
   if (k_ptr && k_req <= 0) return;      // AuxK pass without dead latents: nothing downstream reads its outputs (block-uniform)
-  const int nvec = n_p >> 3;                       // 16-byte vectors in the row
+  int nvec = n_p >> 3;                             // 16-byte vectors in the row
+  if (!COMPACT && compact_mode == 2) {
+    nvec = tkd[4] >> 3;
+    n = tkd[0];
+    if (nvec > MAXV * 256 || (MAXV > 12 && nvec <= 12 * 256)) return;      // (block-uniform) the other instantiation's row
+    if (k_ptr && *k_ptr >= n) return;      // no more dead latents than k_aux: the copy IS the selection (every dead latent is taken)
+  }
   const u32x4* src = reinterpret_cast<const u32x4*>(pre + row * n_p);
   u32x4* dst = reinterpret_cast<u32x4*>(dense + row * n_p);
   int* ti = top_idx + row * kcap;
@@ -516,9 +532,10 @@ __global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void to
     return;
   }
   unsigned short* crow = reinterpret_cast<unsigned short*>(dense + row * n_p);
-  if (COMPACT && k_req >= tkd[0]) {
+  if (COMPACT && (k_req >= tkd[0] || compact_mode == 1)) {
     // no more dead latents than k_aux = d/2 (the usual state of a healthy run): the AuxK selection takes EVERY dead latent,
     // so the compact row is just the row's values at the dead columns (zeros stay zeros) -- no selection, no barrier
+    // (compact_mode 1: the copy is all this launch is for; the general instantiation selects on the compact rows afterwards)
     const unsigned short* prow = reinterpret_cast<const unsigned short*>(pre + row * n_p);
     for (int r = t; r < 8 * cvec; r += 256) {
       const int j = dead_cols[r];

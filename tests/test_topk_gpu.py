@@ -305,7 +305,12 @@ def test_sparse_dacts_matches_dense_ddense():
 
 
 @pytest.mark.parametrize("d,n,n_dead", [(768, 2048, 100), (768, 2048, 700), (384, 1024, 1024), (1280, 1536, 900),
-                                         (384, 1152, 1152)])      # n_p = 9 x 128: the compact width must not pass n_p
+                                         (384, 1152, 1152),       # n_p = 9 x 128: the compact width must not pass n_p
+                                         # dictionaries above 24 576 latents (round 5): the dead columns are COPIED into compact rows and
+                                         # the general select runs in place on them (topk_kernels.h: compact_mode) --
+                                         (384, 32768, 100),       # ... fewer dead latents than k_aux = 192: the copy is the selection
+                                         (384, 32768, 3000),      # ... a real selection among 3000 dead latents: <12> on the compact rows
+                                         (384, 40960, 28000)])    # ... more than 24 576 dead latents: <44> on the compact rows
 def test_auxk_compact_dead_set_matches_gather_path_and_oracle(d, n, n_dead):
     """AuxK as dense GEMMs over the compacted dead latents (topk_aux.h, the default) against the gather kernels it replaces
     (debug_flags 76 switches the compaction off) and against the oracle under the engine's tie rule: fewer dead latents
