@@ -1396,12 +1396,12 @@ static int p2p_selftest_body(sae_ctx* c) {
   return SAE_OK;
 }
 // The ranks enter the self-test right after the hand-shake that exchanged their handles, i.e. within milliseconds of each other:
-// a peer whose flags do not arrive within 20 s never will (mappings that do not reach the other device), and the caller falls back
+// a peer whose flags do not arrive within 40 s never will (mappings that do not reach the other device), and the caller falls back
 // to another exchange that much sooner than after the run-time limit (FREUD_P2P_TIMEOUT_MS, 120 s: a step may wait for a peer
 // that writes a checkpoint).
 static int p2p_selftest(sae_ctx* c) {
   const unsigned long long keep = c->p2p_timeout_ticks;
-  const unsigned long long limit = 2000000000ull;            // 20 s of the 100 MHz counter
+  const unsigned long long limit = 4000000000ull;            // 40 s of the 100 MHz counter
   if (c->p2p_timeout_ticks > limit) c->p2p_timeout_ticks = limit;
   const int rc = p2p_selftest_body(c);
   c->p2p_timeout_ticks = keep;

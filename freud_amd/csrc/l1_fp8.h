@@ -253,7 +253,11 @@ struct EpiEnc8 {
       o[j] = (bf16_t)cv[j];
       o[4 + j] = (bf16_t)cv[4 + j];
     }
+    // (timing experiment of round 5, `-DFP8_SKIP_BF16`: no bf16 copy of the latent -- the upper bound of what a single latent store buys:
+    // encoder 7.38 -> 6.64 ms at C5, profiles/r05_fp8_single_store_bound.txt; as a run-time flag it cost this kernel 6 spill instructions)
+#ifndef FP8_SKIP_BF16
     EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+#endif
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     const u32x2 q = {pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc), pack4_fp8(cv[4] * sc, cv[5] * sc, cv[6] * sc, cv[7] * sc)};
     EPI_STORE(reinterpret_cast<u32x2*>(c8 + (int64_t)row * n_p + col), q);

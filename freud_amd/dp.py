@@ -76,6 +76,15 @@ def setup(eng, dist, rank: int, world: int, device, mode: str = "auto", payload:
             ok, err, blob = False, e, b""
         blobs = [None] * world
         dist.all_gather_object(blobs, blob)
+        # The self-test inside p2p_init waits a bounded time for its peers.  Ranks that load the engine's code object for the first
+        # time can be seconds apart (round 5: one of the first eight-process runs on a cold box failed here): every rank first runs
+        # a kernel of the library (the parameter checksum) and THEN meets the others at a barrier, so that they enter together.
+        try:
+            if hasattr(eng, "param_checksum"):
+                eng.param_checksum()
+        except Exception:                   # noqa: BLE001 -- a warm-up only
+            pass
+        dist.barrier()
         if ok and all(len(b) == len(blob) and len(b) > 0 for b in blobs):
             try:
                 eng.p2p_init(blobs, rank, world)     # maps the peers + self-test exchange (collective, times out instead of hanging)

@@ -202,7 +202,7 @@ int sae_dist_set_payload(sae_ctx* ctx, int dtype);
  *                       payload, a strided 2-D block, fp64 statistics, the statistics push -- over the SAME addresses with a
  *                       different rank-dependent pattern each time, checked on the device, so that a stale cached peer line, a
  *                       flag overtaking its data or a wrong mapping shows as wrong sums BEFORE the first step; a peer that
- *                       cannot be reached makes it FAIL after min(FREUD_P2P_TIMEOUT_MS, 20 s) (default 120000: a liveness bound of the run's steps)
+ *                       cannot be reached makes it FAIL after min(FREUD_P2P_TIMEOUT_MS, 40 s) (default 120000: a liveness bound of the run's steps)
  *                       instead of hanging.  Afterwards sae_forward_backward / sae_step run the data-parallel protocol
  *                       through the peer exchange; sae_dist_world() == world.  FREUD_P2P_FINEGRAINED=1 (read by sae_create)
  *                       puts the three peer-read buffers in fine-grained memory (a peer never caches their lines non-coherently, so
