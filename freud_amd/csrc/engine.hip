@@ -137,6 +137,9 @@ struct sae_ctx {
   bool use_fused_fwd = false;
   int fwd_variant = 2;          // fused forward: 2 = fwd_fused2.h (decoder split along d), 1 = fwd_fused.h (FREUD_FWD=1: A/B, stamps)
   bf16_t *xb = nullptr, *c = nullptr, *dxh = nullptr, *dpre = nullptr;
+  // generic L1 backward (round 5): dx_hat^T and x^T, [d_p][M_p] -- the weight-gradient GEMM's d-side operand K-contiguous, so that its
+  // fragments come by ds_read_b128 instead of twice as many transposing reads (null: the k-major x k-major form)
+  bf16_t *dxhT = nullptr, *xT = nullptr;
   float *slab = nullptr, *db_part = nullptr, *l1_part = nullptr, *sq_part = nullptr, *scal = nullptr;
   double* gn_part = nullptr;
   float* cn_part = nullptr;
@@ -494,7 +497,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
 extern "C" void sae_destroy(sae_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);   // teardown: nothing useful can be done about a failure here
-  void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh,
+  void* ptrs[] = {c->P,    c->Mom,     c->Var,     c->G,       c->Wb,   c->Wt,      c->xb,    c->c, c->dxh, c->dxhT, c->xT,
                   c->dpre, c->slab,    c->db_part, c->l1_part, c->sq_part, c->scal, c->gn_part, c->masked, c->cn_part, c->cnt_part,
                   c->We_b, c->Wd_b, c->xs, c->pre, c->dense, c->aux_dense, c->de_b, c->dh_b, c->e, c->dh, c->e2_part,
                   c->a2_part, c->dbd_part, c->ds_part, c->tkf, c->top_idx, c->aux_idx, c->tk, c->tv_part, c->nfsf, c->dead, c->dbe_fx,
@@ -692,6 +695,13 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
   ALLOC(c->c, Mp * c->n_p * 2 + 4096);   // + a dummy line the fused forward parks its first two stores on
   ALLOC(c->dxh, Mp * c->d_p * 2);
   ALLOC(c->dpre, Mp * c->n_p * 2);
+  // (opt-in, FREUD_DW_ROWA=1: measured SLOWER in the engine -- C4 weight gradient 9.70 -> 10.75 ms, profiles/r05_ab_dw_row_a.txt --
+  // although the stand-alone shape on random dense operands ran 10 % faster, profiles/r05_kbench_dw_row_a.txt)
+  if (!c->use_fused_bwd && !g_force_gemm128 && c->d_p % 256 == 0 && c->n_p % 256 == 0 && Mp % 64 == 0 &&
+      getenv("FREUD_DW_ROWA") && atoi(getenv("FREUD_DW_ROWA")) == 1) {
+    ALLOC(c->dxhT, Mp * c->d_p * 2);
+    ALLOC(c->xT, Mp * c->d_p * 2);
+  }
   ALLOC(c->slab, (int64_t)slab_splits * c->nW * 4);
   ALLOC(c->db_part, db_rows * c->n_p * 4);
   ALLOC(c->l1_part, (Mp / 128) * (c->n_p / 128) * 4);
@@ -1710,6 +1720,11 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
       ev_end(c, KID_DEC_FWD, s);
       if (rc) return rc;
     }
+    if (need_backward && c->dxhT) {
+      hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(Mp / 64), d_p / 64), dim3(256), 0, s, c->dxh, c->dxhT, Mp, d_p);
+      hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(Mp / 64), d_p / 64), dim3(256), 0, s, c->xb_cur, c->xT, Mp, d_p);
+      HIP_TRY(hipGetLastError());
+    }
     return SAE_OK;
   }
   {  // c = relu(x W + b)
@@ -1740,7 +1755,12 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     ev_end(c, KID_DEC_FWD, s);
     if (rc) return rc;
   }
-  (void)need_backward;
+  if (need_backward && c->dxhT) {
+    // the weight-gradient GEMM's d-side operands K-contiguous: dx_hat^T and x^T, 2 x (M_p x d_p) bf16 read + written (section 4)
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(Mp / 64), d_p / 64), dim3(256), 0, s, c->dxh, c->dxhT, Mp, d_p);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)(Mp / 64), d_p / 64), dim3(256), 0, s, c->xb_cur, c->xT, Mp, d_p);
+    HIP_TRY(hipGetLastError());
+  }
   return SAE_OK;
 }
 
@@ -1855,6 +1875,18 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
       // all-reduced there and copied back into its strided place on the communication stream (two passes over 52 MB per chunk
       // at C4 against re-reading two 5.4 GB streams per row chunk).  Host-driven exchange: row chunks (the callback's contract
       // is a contiguous range of the gradient buffer).
+      // dW = dx_hat^T c + x^T dpre (rows r0.. of d).  Round 5 experiment (FREUD_DW_ROWA=1, off by default): with transposed copies of
+      // the d-side operands (forward_impl) the A operand is row-major -- [d_p][M_p], K = the batch rows contiguous -- and its fragments
+      // come by ds_read_b128 instead of twice as many ds_read_b64_tr_b16.  The stand-alone shape on random dense operands ran 10.6
+      // against 11.7 ms (tools/kbench mode 6); in the engine, on the real latent (half zeros) the k-major x k-major form with its
+      // k-half ring is FASTER: 9.70 against 10.75 ms at C4 (profiles/r05_ab_dw_row_a.txt).  Kept as a switch for that record.
+      auto launch_dw = [&](GemmArgs g, const EpiSlab& e, int r0) -> int {
+        if (c->dxhT) {
+          g.A0 = c->dxhT + (int64_t)r0 * Mp; g.A1 = c->xT + (int64_t)r0 * Mp; g.lda = Mp;
+          return launch_gemm<OP_ROW, OP_KMAJOR>(g, e, s);
+        }
+        return launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+      };
       const bool col_staged = c->dist && c->dp_world > 0 && !c->p2p && c->dw_col_chunks > 1 && c->cfg.debug_flags != 82;
       if (col_staged && !c->col_stage) {
         hipError_t e_ = hipMalloc((void**)&c->col_stage, (size_t)c->nW * 4);
@@ -1884,7 +1916,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           if (nbm256 * nct >= 255) g.tail_tiles = g.tail_pieces = 0;      // (a full chunk: one round, nothing to split)
           EpiSlab e{};
           e.slab = c->p2p ? c->G + col0 : stage; e.slab_stride = 0; e.ld = c->p2p ? n_p : cols; e.tail = c->dw_tail;
-          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+          rc = launch_dw(g, e, 0);
           if (rc) return rc;
           if (g.tail_tiles > 0)
             hipLaunchKernelGGL(reduce_tail_kernel, dim3(g.tail_tiles, 16), dim3(256), 0, s, c->dw_tail, e.slab, e.ld, nbm256, nct,
@@ -1906,7 +1938,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           g.splits = c->dw_col_splits > g.ktiles ? g.ktiles : c->dw_col_splits;
           EpiSlab e{};
           e.slab = c->slab + col0; e.slab_stride = c->nW; e.ld = n_p;
-          rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+          rc = launch_dw(g, e, 0);
           if (rc) return rc;
           if (c->p2p) {
             hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3(512), dim3(256), 0, s, c->slab, c->nW, g.splits, n_p, d_p, col0, cols, c->G,
@@ -1945,7 +1977,7 @@ static int fwd_bwd_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
           g.tail_pieces = c->dw_tail_tiles > 0 ? c->dw_tail_pieces : 0;
           e.slab = c->G; e.slab_stride = 0; e.tail = c->dw_tail;
         }
-        rc = launch_gemm<OP_KMAJOR, OP_KMAJOR>(g, e, s);
+        rc = launch_dw(g, e, r0);
         if (rc) return rc;
         if (direct && g.tail_tiles > 0)
           hipLaunchKernelGGL(reduce_tail_kernel, dim3(g.tail_tiles, 16), dim3(256), 0, s, c->dw_tail, c->G, n_p, d_p / 256, n_p / 256,

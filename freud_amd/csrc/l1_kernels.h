@@ -411,6 +411,31 @@ struct EpiDpre {
   __device__ void s_end(float*) {}
 };
 
+// out[C][R] = in[R][C]^T (bf16; R, C multiples of 64): the weight-gradient GEMM's d-side operands dx_hat and x as [d_p][M_p] (round 5),
+// so that its A fragments are K-contiguous.  One 64x64 tile per workgroup through LDS: 16-byte loads along C, 16-byte stores along R.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t R, int C) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];      // 144-byte rows (16-byte aligned)
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i, rr = idx >> 3, ch = idx & 7;            // row of the tile, 16-byte chunk of its 64 columns
+    *reinterpret_cast<u32x4*>(&tile[rr][8 * ch]) = *reinterpret_cast<const u32x4*>(in + (r0 + rr) * C + c0 + 8 * ch);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i, cc = idx >> 3, ch = idx & 7;            // column of the tile = output row, 8 consecutive input rows
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[8 * ch + e][cc];
+    u32x4 o = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+               (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    *reinterpret_cast<u32x4*>(out + (int64_t)(c0 + cc) * R + r0 + 8 * ch) = o;
+  }
+}
+
 // split-K partial slab store for dW
 struct EpiSlab {
   float* slab;          // [splits][rows][ld]

@@ -72,7 +72,10 @@ int main(int argc, char** argv) {
   for (int64_t off = 0; off < N * K; off += (int64_t)h.size()) CK(hipMemcpy(B + off, h.data(), (size_t)std::min<int64_t>(h.size(), N * K - off) * 2, hipMemcpyHostToDevice));
   GemmArgs g{};
   g.A0 = A; g.B0 = B; g.splits = splits;
-  if (kmajor != 1) {      // C[M][N] = A[M][K] B[N][K]^T
+  if (kmajor == 6) {      // mixed (experiment): A row-major [M][K] (K contiguous), B k-major [K][N]; weight-gradient shape with the d-side operand transposed
+    g.lda = K; g.ldb = N; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
+    CK(hipMalloc(&slab, (size_t)splits * M * N * 4));
+  } else if (kmajor != 1) {      // C[M][N] = A[M][K] B[N][K]^T
     g.lda = K; g.ldb = K; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
   } else {                // weight-gradient shape: C[M][N] = sum_k A[k][M] B[k][N], K rows
     g.lda = M; g.ldb = N; g.nbm = (int)(M / 256); g.nbn = (int)(N / 256); g.ktiles0 = g.ktiles = (int)(K / 64);
@@ -106,6 +109,13 @@ int main(int argc, char** argv) {
       run_stream(C);
     } else if (mode == 2) {
       run_w4(C);
+    } else if (mode == 6) {
+      EpiSlabK e{};
+      e.slab = slab; e.slab_stride = M * N; e.ld = (int)N;
+      auto kern = gemm256_bf16_kernel<OP_ROW, OP_KMAJOR, EpiSlabK>;
+      constexpr int lds = epi_deep_a_ring<EpiSlabK>::value ? G2_A3_LDS_BYTES : G2_LDS_BYTES;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3(g.nbm * g.nbn * g.splits), dim3(512), lds, 0, g, e);
     } else if (!kmajor) {
       EpiBf16 e{C, N};
 #ifdef KB_PERSIST
@@ -197,7 +207,7 @@ int main(int argc, char** argv) {
     printf("slab hash %016llx\n", hsh);
   }
   const double t = ms / 5 * 1e-3, flops = 2.0 * M * N * K;
-  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 4 ? "row-stream" : mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
+  printf("%s M=%lld N=%lld K=%lld splits=%d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", mode == 6 ? "row x kmajor" : mode == 4 ? "row-stream" : mode == 2 ? "row-w4" : (kmajor ? "kmajor" : "row"), (long long)M, (long long)N,
          (long long)K, splits, t * 1e3, flops / t / 1e12, flops / t / 2.5e15 * 100);
   return 0;
 }
