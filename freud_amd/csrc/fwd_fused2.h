@@ -396,6 +396,19 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   static_assert(128 * FF_DXH_PITCH <= FF_FIXED_LDS, "the dx_hat staging must fit the idle LDS");
   char* stg = smem;                                              // [128 rows][784 B]
   constexpr bool X_VIA_LDS = !PAD && sizeof(T) == 2;
+#ifndef FF2_X_FROM_FRAGS
+#define FF2_X_FROM_FRAGS 1     // tools/build_variant.sh A/B switch: 0 = round 4's reload of x from global memory
+#endif
+  constexpr bool X_FROM_FRAGS = FF2_X_FROM_FRAGS && X_VIA_LDS && std::is_same<T, bf16_t>::value;
+  if (X_FROM_FRAGS && vec_ok && reinterpret_cast<const void*>(a.x) == reinterpret_cast<const void*>(a.xb)) {
+    // Round 5: bf16 activations used in place (a.x == a.xb) are still in this wave's B-fragment registers from the prologue -- lane
+    // (arow, ah) holds x[m0 + arow][16 kk + 8 ah .. + 7] in xfrag[kk] -- so the staging image is filled from REGISTERS: no second read of
+    // the 96 KB of x per workgroup (long evicted from L2 by the latent stream) and no memory latency at the head of the epilogue.
+    char* srow_w = stg + (32 * w + arow) * FF_DXH_PITCH + 16 * ah;
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) *reinterpret_cast<bf16x8*>(srow_w + 32 * kk) = xfrag[kk];
+    __syncthreads();
+  } else
   if (X_VIA_LDS && vec_ok) {     // the wave's 32 x rows are one contiguous 24 KiB block: 24 coalesced 16-byte loads per lane
     const char* xblk = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.x) + m0 * FF_D);
 #pragma unroll

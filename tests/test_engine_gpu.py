@@ -459,3 +459,50 @@ def test_folded_weight_preparation_keeps_the_reference_state_at_every_observatio
     # and the column norms: un-normalised right after an update, 1 after update + forward
     assert np.abs(np.linalg.norm(new[0], axis=0) - 1).max() > 1e-6
     assert np.abs(np.linalg.norm(new[2], axis=0) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", ["l1", "l1_fp8", "topk"])
+def test_streaming_gemms_equal_the_tile_form(case, monkeypatch):
+    """Round 5: the K = d GEMMs of the generic paths run in the streaming form of csrc/gemm256s.h wherever a launch has >= 2048
+    tiles of 256x256 (encoder, dpre, TopK encoder, fp8 encoder); FREUD_GEMM_STREAM=0 keeps gemm256.h's tile form.  Same products in
+    the same order: the latent (bf16 bits) and the weight gradient must be IDENTICAL between the two, reductions over a tile (L1
+    partial sums, db column sums) associate differently and agree to fp32 round-off.  Shape: d = 256, n = 32 768, M = 4096 rows =
+    16 x 128 tiles, with a ragged last row block (M = 4000 of M_p = 4096: the PARTIAL instantiation of the streaming epilogue)."""
+    from freud_amd.engine import SaeEngine
+    d, n, M = 256, 32768, 4000
+    g = torch.Generator().manual_seed(5)
+    x = ((torch.relu(torch.randn(M, 48, generator=g)) * 0.2) @ torch.randn(48, d, generator=g)).to(torch.bfloat16).cuda()
+    outs = []
+    for stream in ("1", "0"):
+        monkeypatch.setenv("FREUD_GEMM_STREAM", stream)
+        if case == "topk":
+            eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=32, auxk_alpha=0.0)
+            eng.set_topk_options(1e12, M)
+            We = (torch.rand(n, d, generator=torch.Generator().manual_seed(2)) * 2 - 1) / d ** 0.5
+            eng.set_params({"encoder.weight": We.numpy(), "encoder.bias": (0.01 * torch.randn(n, generator=torch.Generator().manual_seed(3))).numpy(),
+                            "W_dec": (We / We.norm(dim=1, keepdim=True)).numpy(), "b_dec": np.zeros(d, np.float32)})
+        else:
+            eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e3,
+                            precision="fp8" if case == "l1_fp8" else "bf16")
+            W = torch.randn(d, n, generator=torch.Generator().manual_seed(2))
+            W /= W.norm(dim=0, keepdim=True)
+            eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": (0.01 * torch.randn(n, generator=torch.Generator().manual_seed(3))).numpy()})
+        eng.forward_backward(x)
+        torch.cuda.synchronize()
+        if case == "topk":
+            idx = eng.debug_read(3, M * 32).copy()
+            grads = eng.debug_read(2, 2 * n * d + n + d).copy()
+            outs.append((idx, grads, eng.metrics().copy()))
+        else:
+            latent = eng.debug_read(0, M * n).copy()
+            grads = eng.debug_read(2, d * n + n).copy()
+            outs.append((latent, grads, eng.metrics().copy()))
+        eng.close()
+    (a0, g0, m0), (a1, g1, m1) = outs
+    assert np.array_equal(a0, a1)                                     # latent bits / selected indices
+    if case == "topk":
+        assert np.array_equal(g0, g1)                                 # the whole sparse backward follows from identical pre-activations
+    else:
+        assert np.array_equal(g0[: d * n], g1[: d * n])               # dW: same c, same dpre, same GEMM
+        np.testing.assert_allclose(g0[d * n:], g1[d * n:], rtol=2e-5, atol=1e-7)       # db: column sums in another order
+    np.testing.assert_allclose(m0[:4], m1[:4], rtol=2e-5)
