@@ -517,7 +517,7 @@ def main():
         st = eng.debug_read(5, (M // 128) * 32).reshape(-1, 8)
         st = st[st[:, 3] > 0]
         per = st[:, :3] / st[:, 3:4]
-        if per.sum() > 0:      # (the per-phase stamps exist in fwd_fused.h only)
+        if per.sum() > 0 and os.environ.get("FREUD_FWD", "2") == "1":      # (the per-phase stamps exist in fwd_fused.h only)
             print("fwd stamps (cycles/iteration, median over waves): decoder gaps 0-11 %.0f | decoder gaps 12-23 (+barrier, DMA) %.0f | "
                   "encoder gaps 24-47 %.0f | total %.0f" % (*np.median(per, 0), np.median(per.sum(1))), file=sys.stderr)
         print("fwd in-kernel clock %.0f MHz (median), loop cycles/iteration %.0f" %
@@ -525,6 +525,11 @@ def main():
         print("fwd per-workgroup cycles (median): prologue %.0f | loop %.0f | epilogue %.0f | whole %.0f" %
               (np.median(st[:, 6]), np.median(st[:, 4]), np.median(st[:, 7] - st[:, 6] - st[:, 4]), np.median(st[:, 7])),
               file=sys.stderr)
+        if os.environ.get("FREUD_FWD", "2") != "1":      # fwd_fused2.h keeps epilogue phase stamps in slots 0-2
+            ep = st[:, 7] - st[:, 6] - st[:, 4]
+            print("fwd epilogue phases (median cycles): last half iteration + latent drain %.0f | x staged %.0f | residual arithmetic %.0f | "
+                  "dx_hat publication + stores + sums %.0f" % (np.median(st[:, 0]), np.median(st[:, 1]), np.median(st[:, 2]),
+                                                                np.median(ep - st[:, 0] - st[:, 1] - st[:, 2])), file=sys.stderr)
     if args.dbg == 66 and rank == 0:     # clock stamps of the fused backward
         full = None
         for grid in ((n // 128 + (1 if n % 128 else 0)) * 10, 256):      # uniform at C2: 24 x 10 (too small a buffer for the balanced form: refused); balanced: 256

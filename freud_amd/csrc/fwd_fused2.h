@@ -31,6 +31,9 @@
 
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime / s_memrealtime around the tile loop per wave into a.stamps[wg][wave][8]
 // ([3] iterations, [4] loop cycles, [5] loop time in 10 ns ticks, [6] prologue cycles, [7] whole-kernel cycles).
+#ifndef FF2_EPI_PACKED
+#define FF2_EPI_PACKED 0     // 1 = the packed residual arithmetic below: 5.5 instead of ~9.5 instructions per element and NOT faster by its own stamps (16.2 k against 15.1-15.9 k cycles, profiles/r05_fwd_epilogue.txt)
+#endif
 #ifndef FF2_PACKED
 #define FF2_PACKED 0         // 1 = the packed form below: 91 instead of 111 vector instructions per iteration and NOT faster (profiles/r05_ab_fwd_packed_valu.txt)
 #endif
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   const bool row_ok = mrow < a.M;
   char* cst = smem + FF_RING_BYTES;                             // two pair buffers [128 rows][128 B]
   float* bias_s = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
-  unsigned long long clk_k0 = 0, clk_t0 = 0, clk_r0 = 0;
+  unsigned long long clk_k0 = 0, clk_t0 = 0, clk_r0 = 0, clk_t1 = 0;
   if (STAMP) clk_k0 = __builtin_amdgcn_s_memtime();
 
   bf16x8 xfrag[24];
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   }
   if (STAMP) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    clk_t1 = t1;
     if (lane == 0) {
       unsigned long long* o = a.stamps + ((int64_t)wg * 4 + w) * 8;
       o[0] = o[1] = o[2] = 0; o[3] = (unsigned long long)a.ntiles; o[4] = t1 - clk_t0; o[5] = r1 - clk_r0; o[6] = clk_t0 - clk_k0;
@@ -381,15 +385,28 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
                                   reinterpret_cast<u32x4*>(cdrain + (int64_t)(8 * p) * a.n_p + 64 * ((a.ntiles >> 1) - 1)));
     }
   }
+  // Everything but this wave's four youngest vector-memory operations -- the latent stores just above -- must be done: the LDS-DMA
+  // pieces of the loop's last iterations still write ring slots that the epilogue's staging image overlays.  (Round 4 waited for
+  // vmcnt(0) here and again inside __syncthreads: a drain of those stores with the matrix pipe idle.)
+#ifndef FF2_TAIL_V1
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+#endif
 
+  unsigned long long clk_e0 = 0, clk_e1 = 0, clk_e2 = 0;
+  if (STAMP) clk_e0 = __builtin_amdgcn_s_memtime();      // final half iteration + drain of the last latent pair done
   // ---- epilogue: x_hat^T accumulators -> residual / dx_hat / squared-error sums.
   // acc[4 dtl + mb][r] <-> d = 96 w + 32 dtl + (r&3) + 8 (r>>2) + 4 h, row 128 wg + 32 mb + arow: every wave needs all 128 x
   // rows (for its d-slice), so the whole [128 x 384] x block is staged in the (now idle) rings, transformed in place into
   // dx_hat by the four waves, and leaves as coalesced 16-byte stores.
   float sq = 0.f, plain = 0.f, nmask = 0.f;
   float msq = 0.f;               // lean epilogue: squared error of the MASKED entries (masked MSE numerator = plain - msq)
+  f32x2_t plain2 = {0.f, 0.f};   // packed form of the lean epilogue: the squared-error sum of the even / odd elements
   typedef __attribute__((ext_vector_type(4))) T Tx4;
   const bool vec_ok = (a.d == FF_D) && ((reinterpret_cast<uintptr_t>(a.x) & (sizeof(T) * 4 - 1)) == 0);
   constexpr int FF_DXH_PITCH = FF_D * 2 + 16;                    // 784 B
@@ -424,6 +441,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     }
     __syncthreads();
   }
+  if (STAMP) clk_e1 = __builtin_amdgcn_s_memtime();      // x staged (and published)
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int64_t grow = (int64_t)wg * FF_BM + 32 * mb + arow;   // global activation row of this lane in row block mb
@@ -447,6 +465,56 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
           // of 13 (keep / rmask selects, the count and the second squared-error sum are gone from the common path); with no
           // masked entry the sums are the same additions in the same order, with some they differ by fp32 round-off
           // (-DFF2_EPI_V1 = round 3's form).
+#if FF2_EPI_PACKED
+          if constexpr (std::is_same<T, bf16_t>::value) {
+            // Round 5: the same in PAIRS.  The stamps of this phase (bench.py --dbg 65) read 15.6-16.9 k cycles per workgroup, two
+            // thirds of the epilogue, for ~9.5 instructions per element on ONE wave per SIMD (every instruction, scalar ones
+            // included, is an issue slot of that wave) -- and cycles outside the tile loop count one for one (staging x from the
+            // fragment registers: -4 k cycles = -1.6 % of the kernel).  Per PAIR now: one v_cvt_pk rounds both accumulators, two
+            // shifts each bring x_hat and x to fp32, e = x_hat - x, plain += e e and 2 e as ONE packed instruction each (inline
+            // asm: hipcc scalarises them), one v_cvt_pk for the output; the -1.0 test is a packed 16-bit minimum of x ^ 0xBF80BF80
+            // per pair and two compares per GROUP instead of a compare and a scalar OR per element.  The squared-error sum runs in
+            // two chains (even / odd elements): fp32 round-off against the element-wise form.
+            typedef __attribute__((ext_vector_type(2))) unsigned short us2_t;
+            us2_t mz = {0xFFFFu, 0xFFFFu};
+            uint2 ow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint2 xw = __builtin_bit_cast(uint2, xv[k]);
+#pragma unroll
+              for (int pp = 0; pp < 2; ++pp) {
+                const unsigned xd = pp ? xw.y : xw.x;
+                const unsigned rb = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                    f32x2_t{acc[4 * dtl + mb][4 * k + 2 * pp], acc[4 * dtl + mb][4 * k + 2 * pp + 1]}, bf16x2));
+                const f32x2_t rf = {__uint_as_float(rb << 16), __uint_as_float(rb & 0xFFFF0000u)};
+                const f32x2_t xf = {__uint_as_float(xd << 16), __uint_as_float(xd & 0xFFFF0000u)};
+                f32x2_t e2, d2;
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rf), "v"(xf));
+                asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(plain2) : "v"(e2));
+                asm("v_pk_add_f32 %0, %1, %1" : "=v"(d2) : "v"(e2));
+                const unsigned ob = __builtin_bit_cast(unsigned, __builtin_convertvector(d2, bf16x2));
+                if (pp) ow[k].y = ob; else ow[k].x = ob;
+                mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xd ^ 0xBF80BF80u));
+              }
+            }
+            if (__builtin_amdgcn_ballot_w64(mz[0] == 0 || mz[1] == 0) != 0ull) {      // wave-uniform, almost never taken
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if ((float)xv[k][q] == -1.0f) {
+                    const float em = bf16_round(acc[4 * dtl + mb][4 * k + q]) - (float)xv[k][q];
+                    nmask += 1.0f;
+                    msq = __builtin_fmaf(em, em, msq);
+                    unsigned& od = (q >> 1) ? ow[k].y : ow[k].x;
+                    od &= (q & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+                  }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(srow + (dbase + 8 * k) * 2) = ow[k];
+            continue;
+          }
+#endif
           bool any_m = false;
           bf16x4 o[4];
           float e[16];
@@ -514,6 +582,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       }
     }
   }
+  if (STAMP) clk_e2 = __builtin_amdgcn_s_memtime();      // residual arithmetic done, dx_hat in the staging image (not yet published)
   __syncthreads();
   {   // the wave's 32 rows of dx_hat are one contiguous 24 KiB block: 24 fully coalesced 16-byte stores per lane
     char* gblk = reinterpret_cast<char*>(a.dxh + m0 * FF_D);
@@ -523,6 +592,26 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       *reinterpret_cast<u32x4*>(gblk + off) = *reinterpret_cast<const u32x4*>(stg + (32 * w + r) * FF_DXH_PITCH + cb);
     }
   }
+  plain += plain2[0] + plain2[1];
+#ifndef FF2_TAIL_V1
+  // Round 5: the four block sums in ONE exchange -- wave sums, one LDS-only barrier, thread 0 adds the four waves' values in
+  // block_sum_256's order (bit-identical) -- through the bias ring (idle since the tile loop; the staging image above is still being
+  // read by the dx_hat stores).  Round 4's tail stood behind a __syncthreads (= a drain of the 24 dx_hat stores per lane) and took four
+  // block sums of two more such barriers each: the stamps count the epilogue's cycles one for one (-DFF2_TAIL_V1 = that form).
+#ifndef FF2_EPI_V1
+  if (!PAD && vec_ok) sq = plain - msq;          // (vec_ok is block-uniform)
+#endif
+  float* red = reinterpret_cast<float*>(smem + FF_FIXED_LDS);
+  {
+    const float v0 = wave_sum(l1_acc), v1 = wave_sum(sq), v2 = wave_sum(plain), v3 = wave_sum(nmask);
+    if (lane == 0) *reinterpret_cast<f32x4*>(red + 4 * w) = f32x4{v0, v1, v2, v3};
+  }
+  lds_barrier();
+  const float l1s = ((red[0] + red[4]) + red[8]) + red[12];
+  const float sqs = ((red[1] + red[5]) + red[9]) + red[13];
+  const float pls = ((red[2] + red[6]) + red[10]) + red[14];
+  const float nms = ((red[3] + red[7]) + red[11]) + red[15];
+#else
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
   const float l1s = block_sum_256(l1_acc, red);
@@ -532,7 +621,15 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   const float sqs = block_sum_256(sq, red + 8);
   const float pls = block_sum_256(plain, red + 16);
   const float nms = block_sum_256(nmask, red + 24);
-  if (STAMP && lane == 0) a.stamps[((int64_t)wg * 4 + w) * 8 + 7] = __builtin_amdgcn_s_memtime() - clk_k0;
+#endif
+  if (STAMP && lane == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)wg * 4 + w) * 8;
+    const unsigned long long te = __builtin_amdgcn_s_memtime();
+    o[7] = te - clk_k0;
+    // epilogue phases (bench.py --dbg 65): [0] loop end -> final half iteration + latent drain, [1] x staging, [2] residual arithmetic;
+    // what is left of the epilogue = dx_hat publication + stores + sums: whole - prologue - loop - [0] - [1] - [2]
+    o[0] = clk_e0 - clk_t1; o[1] = clk_e1 - clk_e0; o[2] = clk_e2 - clk_e1;
+  }
   if (t == 0) {
     a.cnt_part[wg] = nms;
     a.l1_part[wg] = l1s;
