@@ -49,13 +49,28 @@ PEAK_FP8_TFLOPS = 5000.0    # dense MFMA fp8 (v_mfma_f32_32x32x64_f8f6f4), same 
 MEASURED_MFMA_LOOP_TFLOPS = 1700.0
 
 
-def make_inputs(M, d, n, seed, dtype, kind="lowrank"):
+def to_activation_dtype(x32, dtype, guard=True):
+    """fp32 -> the dtype the activations reach the engine in, the way the loader delivers fp32 shards (freud_amd/csrc/host_convert.c:5-7):
+    round to nearest even, and a value that is not -1.0 but would ROUND to it goes to the neighbouring 16-bit value instead -- the
+    reference takes its padding mask on the fp32 values (x != -1.0, train_sae.py:431), so only real padding may read -1.0.  Without the
+    guard N(0,1)-like data rounded to bf16 hits -1.0 in about 0.1 % of its entries and every block of the batch takes the engine's
+    masked-entry path, which a batch from the loader never does (`--raw-cast` = that, as a diagnostic)."""
+    x = x32.to(dtype)
+    if guard and dtype in (torch.bfloat16, torch.float16):
+        hit = (x == -1.0) & (x32 != -1.0)
+        if bool(hit.any()):
+            ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # spacing just below 1.0 (twice that above)
+            x = torch.where(hit, torch.where(x32 > -1.0, torch.full_like(x, -1.0 + ulp), torch.full_like(x, -1.0 - 2 * ulp)), x)
+    return x
+
+
+def make_inputs(M, d, n, seed, dtype, kind="lowrank", guard=True):
     g = torch.Generator().manual_seed(seed)
     if kind == "lowrank":      # SURVEY.md §8(d): low-rank, learnable
         z = torch.relu(torch.randn(M, 64, generator=g)) * 0.1
-        x = (z @ torch.randn(64, d, generator=g)).to(dtype)
+        x = to_activation_dtype(z @ torch.randn(64, d, generator=g), dtype, guard)
     elif kind == "normal":
-        x = torch.randn(M, d, generator=g).to(dtype)
+        x = to_activation_dtype(torch.randn(M, d, generator=g), dtype, guard)
     else:                      # "zeros": clock diagnostic only (DVFS: the chip holds a higher clock on trivial operands)
         x = torch.zeros(M, d, dtype=dtype)
     torch.manual_seed(0)
@@ -180,6 +195,8 @@ def main():
     ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
+    ap.add_argument("--raw-cast", action="store_true",
+                    help="diagnostic: synthetic fp32 cast to the activation dtype WITHOUT the loader's -1.0 guard (see to_activation_dtype)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "fp8bwd"],
@@ -226,7 +243,7 @@ def main():
 
     M, d, n = args.rows, args.d, args.n
     dtype = getattr(torch, args.x_dtype)
-    x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype, kind=args.data)
+    x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype, kind=args.data, guard=not args.raw_cast)
     x = x_cpu.cuda()
     total_steps, base_lr = 100000, 4e-4
 
@@ -483,7 +500,7 @@ def main():
         "metric": f"SAE train activations/sec (d={d} dict {n // d}x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_s": args.spinup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)",
+        "data": ("synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)") + (" (raw cast; diagnostic)" if args.raw_cast else ""),
         "config": {"workload": f"Whisper-{model_name} d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM"
                                + (" (BASELINE configs[1])" if (d, n, M) == (384, 3072, 65536) else ""),
@@ -525,6 +542,10 @@ def main():
         print("fwd per-workgroup cycles (median): prologue %.0f | loop %.0f | epilogue %.0f | whole %.0f" %
               (np.median(st[:, 6]), np.median(st[:, 4]), np.median(st[:, 7] - st[:, 6] - st[:, 4]), np.median(st[:, 7])),
               file=sys.stderr)
+        if len(st) == (M // 128) * 4 and M // 128 > 256:      # workgroups 0-255 start together (one per CU), the rest as CUs come free
+            r1, r2 = st[: 256 * 4], st[256 * 4:]
+            print("fwd prologue / whole, first 256 workgroups: %.0f / %.0f | the others: %.0f / %.0f" %
+                  (np.median(r1[:, 6]), np.median(r1[:, 7]), np.median(r2[:, 6]), np.median(r2[:, 7])), file=sys.stderr)
         if os.environ.get("FREUD_FWD", "2") != "1":      # fwd_fused2.h keeps epilogue phase stamps in slots 0-2
             ep = st[:, 7] - st[:, 6] - st[:, 4]
             print("fwd epilogue phases (median cycles): last half iteration + latent drain %.0f | x staged %.0f | residual arithmetic %.0f | "

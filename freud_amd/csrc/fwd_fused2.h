@@ -31,8 +31,11 @@
 
 // STAMP: diagnostic build (bench.py --dbg 65): s_memtime / s_memrealtime around the tile loop per wave into a.stamps[wg][wave][8]
 // ([3] iterations, [4] loop cycles, [5] loop time in 10 ns ticks, [6] prologue cycles, [7] whole-kernel cycles).
+#ifndef FF2_KO
+#define FF2_KO 0
+#endif
 #ifndef FF2_EPI_PACKED
-#define FF2_EPI_PACKED 0     // 1 = the packed residual arithmetic below: 5.5 instead of ~9.5 instructions per element and NOT faster by its own stamps (16.2 k against 15.1-15.9 k cycles, profiles/r05_fwd_epilogue.txt)
+#define FF2_EPI_PACKED 1     // 1 = the packed residual arithmetic of the no-mask path (v_pk_add / v_pk_fma on pairs)
 #endif
 #ifndef FF2_PACKED
 #define FF2_PACKED 0         // 1 = the packed form below: 91 instead of 111 vector instructions per iteration and NOT faster (profiles/r05_ab_fwd_packed_valu.txt)
@@ -417,17 +420,46 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #define FF2_X_FROM_FRAGS 1     // tools/build_variant.sh A/B switch: 0 = round 4's reload of x from global memory
 #endif
   constexpr bool X_FROM_FRAGS = FF2_X_FROM_FRAGS && X_VIA_LDS && std::is_same<T, bf16_t>::value;
+  // Round 5 (found by knock-outs, profiles/r05_fwd_residual_knockouts.txt): the residual arithmetic below took 15.8 k cycles per workgroup
+  // with the -1.0 test in it and 8.4 k without -- not for the test's instructions (keeping them in the vector unit changed nothing) but for
+  // the BRANCH behind it: `if (any lane met a -1.0)` per group of 16 elements ends a basic block, so each of the 12 groups waited for its own
+  // LDS reads and its own dependent chain instead of overlapping with its neighbours (one wave per SIMD: nobody else fills the gaps).  So the
+  // test moves to where x is staged -- every 16-bit x of the block passes through some lane's registers there exactly once: x ^ bits(-1.0) is
+  // zero for a masked entry, a packed unsigned minimum carries it -- one flag per wave rides on the staging barrier, and the block takes
+  // either the arithmetic with no test and no branch (one basic block), or, if any of its 128 x 384 entries is masked, the per-group form.
+  // Same additions in the same order either way.  (-DFF2_PRESCAN=0 = the per-group test always.)
+#ifndef FF2_PRESCAN
+#define FF2_PRESCAN 1
+#endif
+  typedef __attribute__((ext_vector_type(2))) unsigned short us2_t;
+  constexpr unsigned MASK_BITS2 = std::is_same<T, bf16_t>::value ? 0xBF80BF80u : 0xBC00BC00u;     // -1.0 twice, bf16 / fp16
+  unsigned* mflag = reinterpret_cast<unsigned*>(smem + FF_FIXED_LDS + 64);                         // bias ring: idle since the tile loop
+  bool blk_masked = true;
   if (X_FROM_FRAGS && vec_ok && reinterpret_cast<const void*>(a.x) == reinterpret_cast<const void*>(a.xb)) {
     // Round 5: bf16 activations used in place (a.x == a.xb) are still in this wave's B-fragment registers from the prologue -- lane
     // (arow, ah) holds x[m0 + arow][16 kk + 8 ah .. + 7] in xfrag[kk] -- so the staging image is filled from REGISTERS: no second read of
     // the 96 KB of x per workgroup (long evicted from L2 by the latent stream) and no memory latency at the head of the epilogue.
     char* srow_w = stg + (32 * w + arow) * FF_DXH_PITCH + 16 * ah;
+    us2_t mz = {0xFFFFu, 0xFFFFu};
 #pragma unroll
-    for (int kk = 0; kk < 24; ++kk) *reinterpret_cast<bf16x8*>(srow_w + 32 * kk) = xfrag[kk];
+    for (int kk = 0; kk < 24; ++kk) {
+      *reinterpret_cast<bf16x8*>(srow_w + 32 * kk) = xfrag[kk];
+      if (FF2_PRESCAN) {
+        const u32x4 xw = __builtin_bit_cast(u32x4, xfrag[kk]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xw[c] ^ MASK_BITS2));
+      }
+    }
+    if (FF2_PRESCAN) {
+      const bool wany = __builtin_amdgcn_ballot_w64((mz[0] == 0) | (mz[1] == 0)) != 0ull;
+      if (lane == 0) mflag[w] = wany ? 1u : 0u;
+    }
     __syncthreads();
+    if (FF2_PRESCAN) { const u32x4 f = *reinterpret_cast<const u32x4*>(mflag); blk_masked = (f[0] | f[1] | f[2] | f[3]) != 0u; }
   } else
   if (X_VIA_LDS && vec_ok) {     // the wave's 32 x rows are one contiguous 24 KiB block: 24 coalesced 16-byte loads per lane
     const char* xblk = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.x) + m0 * FF_D);
+    us2_t mz = {0xFFFFu, 0xFFFFu};
 #pragma unroll
     for (int p0 = 0; p0 < 24; p0 += 8) {
       u32x4 xr[8];
@@ -437,11 +469,22 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       for (int pc = 0; pc < 8; ++pc) {
         const int off = (p0 + pc) * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
         *reinterpret_cast<u32x4*>(stg + (32 * w + r) * FF_DXH_PITCH + cb) = xr[pc];
+        if (FF2_PRESCAN) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xr[pc][c] ^ MASK_BITS2));
+        }
       }
     }
+    if (FF2_PRESCAN) {
+      const bool wany = __builtin_amdgcn_ballot_w64((mz[0] == 0) | (mz[1] == 0)) != 0ull;
+      if (lane == 0) mflag[w] = wany ? 1u : 0u;
+    }
     __syncthreads();
+    if (FF2_PRESCAN) { const u32x4 f = *reinterpret_cast<const u32x4*>(mflag); blk_masked = (f[0] | f[1] | f[2] | f[3]) != 0u; }
   }
   if (STAMP) clk_e1 = __builtin_amdgcn_s_memtime();      // x staged (and published)
+  auto residual = [&](auto notest_tag) {
+  constexpr bool NOTEST = decltype(notest_tag)::value;
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int64_t grow = (int64_t)wg * FF_BM + 32 * mb + arow;   // global activation row of this lane in row block mb
@@ -459,62 +502,80 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
           xv[k] = X_VIA_LDS ? *reinterpret_cast<const Tx4*>(srow + (dbase + 8 * k) * 2) : *reinterpret_cast<const Tx4*>(xrow + dbase + 8 * k);
 #ifndef FF2_EPI_V1
         if (!PAD) {
-          // Round 4: the lean form.  Masked entries (x == -1.0 exactly) are rare, so the 16 elements are first run WITHOUT the
-          // mask -- e = bf16(x_hat) - x, plain += e e (one fma), dx_hat = bf16(2 e) -- and the wave looks once (a ballot) whether
-          // any lane met a -1.0; only then the masked elements are taken out again.  Per element 7 vector instructions instead
-          // of 13 (keep / rmask selects, the count and the second squared-error sum are gone from the common path); with no
-          // masked entry the sums are the same additions in the same order, with some they differ by fp32 round-off
-          // (-DFF2_EPI_V1 = round 3's form).
+          // The lean form (round 4; round 5: which of its two halves runs is decided per BLOCK while x is staged, see X_FROM_FRAGS above).
+          // Without masked entries: e = bf16(x_hat) - x, plain += e e (one fma), dx_hat = bf16(2 e) -- 6 vector instructions per element
+          // instead of round 3's 13 (-DFF2_EPI_V1).  With: the same plus four selects / adds per element.  Both keep plain and the masked
+          // entries' squared error (msq) and leave the masked MSE numerator as plain - msq.
+          // (FF2_KO: knock-outs of this phase for the stamp builds of round 5 -- results become wrong: 1 = no squared-error chain,
+          //  2 = no stores of dx_hat into the staging image, 4 = no -1.0 test, 8 = x taken as zero instead of read from LDS)
+          if constexpr (NOTEST && X_VIA_LDS) {      // the block holds no masked entry (scanned while x was staged): no test, no branch
 #if FF2_EPI_PACKED
-          if constexpr (std::is_same<T, bf16_t>::value) {
-            // Round 5: the same in PAIRS.  The stamps of this phase (bench.py --dbg 65) read 15.6-16.9 k cycles per workgroup, two
-            // thirds of the epilogue, for ~9.5 instructions per element on ONE wave per SIMD (every instruction, scalar ones
-            // included, is an issue slot of that wave) -- and cycles outside the tile loop count one for one (staging x from the
-            // fragment registers: -4 k cycles = -1.6 % of the kernel).  Per PAIR now: one v_cvt_pk rounds both accumulators, two
-            // shifts each bring x_hat and x to fp32, e = x_hat - x, plain += e e and 2 e as ONE packed instruction each (inline
-            // asm: hipcc scalarises them), one v_cvt_pk for the output; the -1.0 test is a packed 16-bit minimum of x ^ 0xBF80BF80
-            // per pair and two compares per GROUP instead of a compare and a scalar OR per element.  The squared-error sum runs in
-            // two chains (even / odd elements): fp32 round-off against the element-wise form.
-            typedef __attribute__((ext_vector_type(2))) unsigned short us2_t;
-            us2_t mz = {0xFFFFu, 0xFFFFu};
-            uint2 ow[4];
+            if constexpr (std::is_same<T, bf16_t>::value) {
+              // The same in PAIRS (switch, measured in round 5: profiles/r05_fwd_epilogue.txt): one v_cvt_pk rounds both accumulators, two
+              // shifts each bring x_hat and x to fp32, e = x_hat - x, plain += e e and 2 e as ONE packed instruction each (inline asm:
+              // hipcc scalarises them), one v_cvt_pk for the output.  The squared-error sum runs in two chains (even / odd elements):
+              // fp32 round-off against the element-wise form.
+              uint2 ow[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const uint2 xw = __builtin_bit_cast(uint2, xv[k]);
+              for (int k = 0; k < 4; ++k) {
+                const uint2 xw = __builtin_bit_cast(uint2, xv[k]);
 #pragma unroll
-              for (int pp = 0; pp < 2; ++pp) {
-                const unsigned xd = pp ? xw.y : xw.x;
-                const unsigned rb = __builtin_bit_cast(unsigned, __builtin_convertvector(
-                    f32x2_t{acc[4 * dtl + mb][4 * k + 2 * pp], acc[4 * dtl + mb][4 * k + 2 * pp + 1]}, bf16x2));
-                const f32x2_t rf = {__uint_as_float(rb << 16), __uint_as_float(rb & 0xFFFF0000u)};
-                const f32x2_t xf = {__uint_as_float(xd << 16), __uint_as_float(xd & 0xFFFF0000u)};
-                f32x2_t e2, d2;
-                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rf), "v"(xf));
-                asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(plain2) : "v"(e2));
-                asm("v_pk_add_f32 %0, %1, %1" : "=v"(d2) : "v"(e2));
-                const unsigned ob = __builtin_bit_cast(unsigned, __builtin_convertvector(d2, bf16x2));
-                if (pp) ow[k].y = ob; else ow[k].x = ob;
-                mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xd ^ 0xBF80BF80u));
+                for (int pp = 0; pp < 2; ++pp) {
+                  const unsigned xd = pp ? xw.y : xw.x;
+                  const unsigned rb = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                      f32x2_t{acc[4 * dtl + mb][4 * k + 2 * pp], acc[4 * dtl + mb][4 * k + 2 * pp + 1]}, bf16x2));
+                  const f32x2_t rf = {__uint_as_float(rb << 16), __uint_as_float(rb & 0xFFFF0000u)};
+                  const f32x2_t xf = {__uint_as_float(xd << 16), __uint_as_float(xd & 0xFFFF0000u)};
+                  f32x2_t e2, d2;
+                  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e2) : "v"(rf), "v"(xf));
+                  asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(plain2) : "v"(e2));
+                  asm("v_pk_add_f32 %0, %1, %1" : "=v"(d2) : "v"(e2));
+                  const unsigned ob = __builtin_bit_cast(unsigned, __builtin_convertvector(d2, bf16x2));
+                  if (pp) ow[k].y = ob; else ow[k].x = ob;
+                }
               }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(srow + (dbase + 8 * k) * 2) = ow[k];
+              continue;
             }
-            if (__builtin_amdgcn_ballot_w64(mz[0] == 0 || mz[1] == 0) != 0ull) {      // wave-uniform, almost never taken
+#endif
+            bf16x4 o[4];
 #pragma unroll
-              for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                  if ((float)xv[k][q] == -1.0f) {
-                    const float em = bf16_round(acc[4 * dtl + mb][4 * k + q]) - (float)xv[k][q];
-                    nmask += 1.0f;
-                    msq = __builtin_fmaf(em, em, msq);
-                    unsigned& od = (q >> 1) ? ow[k].y : ow[k].x;
-                    od &= (q & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-                  }
-            }
+              for (int q = 0; q < 4; ++q) {
+                const float xf = (FF2_KO & 8) ? 0.0f : (float)xv[k][q];
+                const float e = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
+                if (!(FF2_KO & 1)) plain = __builtin_fmaf(e, e, plain);
+                o[k][q] = (bf16_t)(e + e);
+              }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(srow + (dbase + 8 * k) * 2) = ow[k];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(srow + (dbase + 8 * k) * 2) = o[k];
             continue;
           }
-#endif
+#ifndef FF2_MASK_BRANCHY
+          // A block WITH masked entries (real padding; or 16-bit data that did not come through the loader's guard, host_convert.c:5-7,
+          // and hits -1.0 by rounding: N(0,1) rounded to bf16 does so in 0.14 % of its entries, i.e. in three of four 16 x 64 groups):
+          // selects, no branch -- four more instructions per element than the form above.  Round 4's form (-DFF2_MASK_BRANCHY) asked the
+          // wave per group of 16 whether any lane met a -1.0 and then took the entries out one by one under exec masks: right when that is
+          // rare, 17.7 k cycles for this phase on the bench's own data before its generator got the loader's guard.
+          bf16x4 o[4];
+          unsigned nm_i = 0u;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float xf = (FF2_KO & 8) ? 0.0f : (float)xv[k][q];
+              const float e = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
+              const bool mk = !(FF2_KO & 4) && (xf == -1.0f);
+              const float em = mk ? e : 0.0f, ek = mk ? 0.0f : e;
+              if (!(FF2_KO & 1)) plain = __builtin_fmaf(e, e, plain);
+              msq = __builtin_fmaf(em, em, msq);
+              nm_i += mk ? 1u : 0u;
+              o[k][q] = (bf16_t)(ek + ek);
+            }
+          nmask += (float)nm_i;
+#else
           bool any_m = false;
           bf16x4 o[4];
           float e[16];
@@ -522,10 +583,10 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float xf = (float)xv[k][q];
+              const float xf = (FF2_KO & 8) ? 0.0f : (float)xv[k][q];
               e[4 * k + q] = bf16_round(acc[4 * dtl + mb][4 * k + q]) - xf;
-              plain = __builtin_fmaf(e[4 * k + q], e[4 * k + q], plain);
-              any_m |= (xf == -1.0f);
+              if (!(FF2_KO & 1)) plain = __builtin_fmaf(e[4 * k + q], e[4 * k + q], plain);
+              if (!(FF2_KO & 4)) any_m |= (xf == -1.0f);
               o[k][q] = (bf16_t)(e[4 * k + q] + e[4 * k + q]);
             }
           if (__builtin_amdgcn_ballot_w64(any_m) != 0ull) {        // wave-uniform, almost never taken
@@ -538,6 +599,12 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
                   msq = __builtin_fmaf(e[4 * k + q], e[4 * k + q], msq);
                   o[k][q] = (bf16_t)0.0f;
                 }
+          }
+#endif
+          if (FF2_KO & 2) {        // (keep the values alive without the LDS stores)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(o[k]));
+            continue;
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(srow + (dbase + 8 * k) * 2) = o[k];
@@ -582,6 +649,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       }
     }
   }
+  };
+  if (X_VIA_LDS && FF2_PRESCAN && !blk_masked) residual(std::true_type{}); else residual(std::false_type{});
   if (STAMP) clk_e2 = __builtin_amdgcn_s_memtime();      // residual arithmetic done, dx_hat in the staging image (not yet published)
   __syncthreads();
   {   // the wave's 32 rows of dx_hat are one contiguous 24 KiB block: 24 fully coalesced 16-byte stores per lane

@@ -114,6 +114,35 @@ def test_eval_and_latent_colmax_match_oracle(d, n, M, generic):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,where", [(torch.bfloat16, (5 * 128 + 77, 201)), (torch.bfloat16, (0, 0)), (torch.bfloat16, (2047, 383)),
+                                         (torch.float16, (9 * 128 + 3, 130))])
+def test_one_masked_entry_in_one_block_of_many(dtype, where):
+    """The fused forward looks for -1.0 entries while it stages its 128 x 384 block of x and takes the arithmetic without the mask when the
+    block holds none (fwd_fused2.h, round 5): ONE masked entry in one block of sixteen must still be found (count = M d - 1 exactly), left out
+    of the masked MSE and zeroed in dx_hat.  x is small (1e-3) so that the masked entry's own error (about 1) would double the MSE
+    and dominate the gradients if it were not taken out; losses / gradients against the oracle (train_sae.py:421-453, autoencoder.py:8-16)."""
+    d, n, M = 384, 3072, 2048
+    g = torch.Generator().manual_seed(77)
+    W = torch.randn(d, n, generator=g) / d ** 0.5
+    b = 0.01 * torch.randn(n, generator=g)
+    x = (1e-3 * torch.randn(M, d, generator=g)).to(dtype)
+    assert int((x == -1.0).sum()) == 0
+    x[where[0], where[1]] = -1.0
+    eng = _engine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="adam", recon_alpha=1e4)
+    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    eng.forward_backward(x.cuda())
+    graw = eng.debug_read(2, d * n + n)
+    eng.optimizer_step(4e-4)
+    m = eng.metrics()
+    out = O.l1_train_step(x.float(), W.clone(), b.clone(), O.OptState(), recon_alpha=1e4, lr=4e-4, clip_thresh=1.0, optimizer="adam")
+    assert m[4] == float(M * d - 1)
+    assert m[0] == pytest.approx(out["reconstruction_loss"].item(), rel=1e-3)
+    assert m[2] == pytest.approx(out["mse"].item(), rel=1e-3)
+    assert _rel(graw[: d * n], out["dW"].numpy().ravel()) < 5e-3
+    assert _rel(graw[d * n:], out["db"].numpy()) < 1e-2
+    eng.close()
+
+
 @pytest.mark.parametrize("d,n,M,dtype,opt,generic", [
     (384, 3072, 1024, torch.float32, "radam", False),
     (384, 3072, 1024, torch.float32, "radam", True),       # generic three-GEMM backward on the same case

@@ -220,3 +220,29 @@ sys.exit(0 if (os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0) else 4)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+
+
+def test_bench_activations_follow_the_loaders_guard():
+    """bench.py's synthetic activations reach the engine the way a batch from the loader does: fp32 -> bf16 by the same rule as
+    libfreud_host.so (round to nearest even; what is not -1.0 never reads -1.0, host_convert.c:5-7) -- bit for bit on N(0, 0.6)
+    values (which hit -1.0 by rounding in about one entry of a thousand without the guard) and on the -1.0 neighbours; real
+    padding (-1.0 in fp32) stays -1.0.  The reference takes its mask on the fp32 values (train_sae.py:431)."""
+    import numpy as np
+    import bench
+    from freud_amd.loader import _host_lib
+    lib = _host_lib()
+    g = torch.Generator().manual_seed(5)
+    x32 = torch.cat([0.6 * torch.randn(400000, generator=g),
+                     torch.tensor(np.array([0xBF800000, 0xBF800001, 0xBF7FFFFF, 0xBF808000, 0xBF7F8000, 0xBF807FFF, 0xBF7F8001],
+                                           dtype=np.uint32).view(np.float32))])
+    raw = x32.to(torch.bfloat16)
+    assert int(((raw == -1.0) & (x32 != -1.0)).sum()) > 100        # the case the guard exists for
+    got = bench.to_activation_dtype(x32, torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    ref = np.zeros(x32.numel(), np.uint16)
+    src = np.ascontiguousarray(x32.numpy())
+    lib.freud_f32_to_bf16(src.ctypes.data, ref.ctypes.data, src.size)
+    assert np.array_equal(got, ref)
+    assert int((got == 0xBF80).sum()) == 1 and got[400000] == 0xBF80
+    h = bench.to_activation_dtype(x32, torch.float16)
+    assert int(((h == -1.0) & (x32 != -1.0)).sum()) == 0 and float(h[400000]) == -1.0
+    assert (h.float() - x32).abs().max() <= 2.0 ** -10
