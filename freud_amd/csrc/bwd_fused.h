@@ -104,23 +104,36 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // the workgroup's segments: one (column tile, step range, slab piece) in the uniform form; in the balanced form one per column
   // tile its quanta touch (usually one, two for the workgroups that straddle a tile boundary)
+  // (Round 5: the prologue's loads are issued TOGETHER -- the workgroup-number table entry and this thread's share of the forward's
+  // count partials -- and waited for once.  As written before, the table entry, then each count partial in turn, were a load and an
+  // `s_waitcnt vmcnt(0)` each: three memory latencies in a row before the first W^T fragment was requested.)
   int qa = 0, qe = 1, wgk = 0;
+  unsigned long long clk_k0 = 0;
+  if (a.clk) clk_k0 = __builtin_amdgcn_s_memtime();
+  int wgk_raw = (int)blockIdx.x;
+  if (a.bal_m > 0 && a.wg_map) wgk_raw = (int)a.wg_map[blockIdx.x];
+  double cnt_m = 0;
+  if (a.cnt_part) {
+    for (int i0 = t; i0 < a.n_cnt; i0 += 1024) {           // four independent loads per trip (512 partials at C2: one trip, two live)
+      float cv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cv[u] = a.cnt_part[min(i0 + 256 * u, a.n_cnt - 1)];     // (clamped, not predicated: no branch, no wait between them)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cnt_m += i0 + 256 * u < a.n_cnt ? (double)cv[u] : 0.0;  // the same additions in the same order as one partial per trip
+    }
+  }
   if (a.bal_m > 0) {
-    wgk = __builtin_amdgcn_readfirstlane(a.wg_map ? (int)a.wg_map[blockIdx.x] : (int)blockIdx.x);
+    wgk = __builtin_amdgcn_readfirstlane(wgk_raw);
     qa = wgk * a.bal_m;
     qe = qa + a.bal_m < 32 * a.ntiles ? qa + a.bal_m : 32 * a.ntiles;
   }
-  unsigned long long clk_k0 = 0;
-  if (a.clk) clk_k0 = __builtin_amdgcn_s_memtime();
   int n0 = 0, nw = 0;                     // first dictionary column of the workgroup / of this wave (per segment)
   // With an unscaled dx_hat everything is computed in units of 1/scale: dpre' = dc' + (1/M)/scale, and the
   // epilogue multiplies the dW slab and db by scale = alpha/count.
   float scal1, scal2;
   if (a.cnt_part) {
     double* redc = reinterpret_cast<double*>(smem + BF_STAGE_BYTES);      // stage 1 is idle until the loop's first hand-over
-    double m = 0;
-    for (int i = t; i < a.n_cnt; i += 256) m += (double)a.cnt_part[i];
-    m = wave_sum_d(m);
+    double m = wave_sum_d(cnt_m);
     if (lane == 0) redc[w] = m;
     __syncthreads();
     const double count = (double)a.M * a.d - ((redc[0] + redc[1]) + (redc[2] + redc[3]));

@@ -58,11 +58,23 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 
   bf16x8 xfrag[24];
   {
+#ifdef FF2_KO_XSAME      // knock-out (results wrong): every workgroup reads block 0's x -- the prologue with x served by the L2 instead of HBM
+    const bf16_t* xp = a.xb + (int64_t)(32 * w + arow) * FF_D + 8 * ah;
+#else
     const bf16_t* xp = a.xb + mrow * FF_D + 8 * ah;
+#endif
+#ifdef FF2_KO_XLOAD      // knock-out (results wrong): the same 24 KB per wave as fully coalesced 16-byte loads -- does the access pattern cost?
+    const bf16_t* xc = a.xb + m0 * FF_D + lane * 8;
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xc + 512 * kk);
+#else
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
+#endif
   }
+#ifdef FF2_BIAS_V1
   if (t < 2 * FF_BN) bias_s[t] = a.bias[t];
+#endif
   // ring slot 3 and the staging image are read (times zero / as zeros) by the first iteration's decoder phase
   for (int i = t; i < FF_WT_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
   for (int i = t; i < FF_CST_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(cst)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -95,6 +107,13 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   for (int q = 0; q < 3; ++q)                       // prologue: W^T tiles 0, 1, 2 into slots 0, 1, 2
 #pragma unroll
     for (int p = 0; p < 3; ++p) dma_pair(p, q <= last ? q : last, q);
+#ifndef FF2_BIAS_V1
+  // The first two tiles' biases by LDS-DMA like every later pair's (round 5).  As `bias_s[t] = a.bias[t]` this was a load, an
+  // `s_waitcnt vmcnt(0)` and an LDS write in wave 0 -- behind that wave's 24 x loads: it sat out a whole memory latency before it issued
+  // its share of the W^T tiles, and the other three waves waited for it at the barrier (the disassembly showed it; -DFF2_BIAS_V1 = that form).
+  static_assert(2 * FF_BN == 64, "one 4-byte piece per lane of wave 0");
+  if (w == 0) glds4(a.bias, (unsigned)(lane * 4), (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + FF_FIXED_LDS)));
+#endif
 #pragma unroll
   for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(xfrag[kk]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
