@@ -56,35 +56,21 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   unsigned long long clk_k0 = 0, clk_t0 = 0, clk_r0 = 0, clk_t1 = 0;
   if (STAMP) clk_k0 = __builtin_amdgcn_s_memtime();
 
+#ifndef FF2_PRESCAN
+#define FF2_PRESCAN 1
+#endif
+#ifndef FF2_SCAN_EARLY
+#define FF2_SCAN_EARLY 1     // the -1.0 scan of x used in place: 1 = here in the prologue, as the fragments arrive (under the memory latency);
+#endif                       // 0 = while the staging image is filled (first form of round 5: +1.3 k cycles in the epilogue)
+  typedef __attribute__((ext_vector_type(2))) unsigned short us2_t;
+  constexpr unsigned MASK_BITS2 = std::is_same<T, bf16_t>::value ? 0xBF80BF80u : 0xBC00BC00u;     // -1.0 twice, bf16 / fp16
+  constexpr bool SCAN_EARLY = FF2_PRESCAN && FF2_SCAN_EARLY && !PAD && std::is_same<T, bf16_t>::value;
+  bool wany_early = false;     // (wave-uniform) some 16-bit word of this wave's 32 x 384 block of a.xb reads -1.0
+
   bf16x8 xfrag[24];
-  {
-#ifdef FF2_KO_XSAME      // knock-out (results wrong): every workgroup reads block 0's x -- the prologue with x served by the L2 instead of HBM
-    const bf16_t* xp = a.xb + (int64_t)(32 * w + arow) * FF_D + 8 * ah;
-#else
-    const bf16_t* xp = a.xb + mrow * FF_D + 8 * ah;
-#endif
-#ifdef FF2_KO_XLOAD      // knock-out (results wrong): the same 24 KB per wave as fully coalesced 16-byte loads -- does the access pattern cost?
-    const bf16_t* xc = a.xb + m0 * FF_D + lane * 8;
-#pragma unroll
-    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xc + 512 * kk);
-#else
-#pragma unroll
-    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
-#endif
-  }
 #ifdef FF2_BIAS_V1
   if (t < 2 * FF_BN) bias_s[t] = a.bias[t];
 #endif
-  // ring slot 3 and the staging image are read (times zero / as zeros) by the first iteration's decoder phase
-  for (int i = t; i < FF_WT_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
-  for (int i = t; i < FF_CST_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(cst)[i] = u32x4{0u, 0u, 0u, 0u};
-
-  f32x16 acc[12];                       // acc[4 dtl + mb]: rows d = 96 w + 32 dtl + ..., columns = row block mb
-#pragma unroll
-  for (int i = 0; i < 12; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
   // ---- LDS-DMA plan of a W^T tile (as in fwd_fused.h)
   unsigned voff_t[6], loff_t[6];
 #pragma unroll
@@ -114,6 +100,44 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   static_assert(2 * FF_BN == 64, "one 4-byte piece per lane of wave 0");
   if (w == 0) glds4(a.bias, (unsigned)(lane * 4), (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + FF_FIXED_LDS)));
 #endif
+  {
+#ifdef FF2_KO_XSAME      // knock-out (results wrong): every workgroup reads block 0's x -- the prologue with x served by the L2 instead of HBM
+    const bf16_t* xp = a.xb + (int64_t)(32 * w + arow) * FF_D + 8 * ah;
+#else
+    const bf16_t* xp = a.xb + mrow * FF_D + 8 * ah;
+#endif
+#ifdef FF2_KO_XLOAD      // knock-out (results wrong): the same 24 KB per wave as fully coalesced 16-byte loads -- does the access pattern cost?
+    const bf16_t* xc = a.xb + m0 * FF_D + lane * 8;
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xc + 512 * kk);
+#else
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) xfrag[kk] = *reinterpret_cast<const bf16x8*>(xp + 16 * kk);
+#endif
+  }
+  // ring slot 3 and the staging image are read (times zero / as zeros) by the first iteration's decoder phase
+  for (int i = t; i < FF_WT_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(smem + 3 * FF_WT_BYTES)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = t; i < FF_CST_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(cst)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  f32x16 acc[12];                       // acc[4 dtl + mb]: rows d = 96 w + 32 dtl + ..., columns = row block mb
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // x AFTER the LDS-DMA pieces (round 5): the compiler counts only the loads it sees, so with the x loads youngest its vmcnt waits for the
+  // fragments are exact, and the -1.0 scan below runs on each fragment as it arrives, under the latency of the ones behind it
+  // (the W^T pieces are older and mostly L2 hits: they have landed by then).  Used only if a.x == a.xb.
+  if (SCAN_EARLY) {
+    us2_t mz = {0xFFFFu, 0xFFFFu};
+#pragma unroll
+    for (int kk = 0; kk < 24; ++kk) {
+      const u32x4 xw = __builtin_bit_cast(u32x4, xfrag[kk]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xw[c] ^ MASK_BITS2));
+    }
+    wany_early = __builtin_amdgcn_ballot_w64((mz[0] == 0) | (mz[1] == 0)) != 0ull;
+  }
 #pragma unroll
   for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(xfrag[kk]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -447,11 +471,6 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
   // zero for a masked entry, a packed unsigned minimum carries it -- one flag per wave rides on the staging barrier, and the block takes
   // either the arithmetic with no test and no branch (one basic block), or, if any of its 128 x 384 entries is masked, the per-group form.
   // Same additions in the same order either way.  (-DFF2_PRESCAN=0 = the per-group test always.)
-#ifndef FF2_PRESCAN
-#define FF2_PRESCAN 1
-#endif
-  typedef __attribute__((ext_vector_type(2))) unsigned short us2_t;
-  constexpr unsigned MASK_BITS2 = std::is_same<T, bf16_t>::value ? 0xBF80BF80u : 0xBC00BC00u;     // -1.0 twice, bf16 / fp16
   unsigned* mflag = reinterpret_cast<unsigned*>(smem + FF_FIXED_LDS + 64);                         // bias ring: idle since the tile loop
   bool blk_masked = true;
   if (X_FROM_FRAGS && vec_ok && reinterpret_cast<const void*>(a.x) == reinterpret_cast<const void*>(a.xb)) {
@@ -463,14 +482,14 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #pragma unroll
     for (int kk = 0; kk < 24; ++kk) {
       *reinterpret_cast<bf16x8*>(srow_w + 32 * kk) = xfrag[kk];
-      if (FF2_PRESCAN) {
+      if (FF2_PRESCAN && !SCAN_EARLY) {
         const u32x4 xw = __builtin_bit_cast(u32x4, xfrag[kk]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) mz = __builtin_elementwise_min(mz, __builtin_bit_cast(us2_t, xw[c] ^ MASK_BITS2));
       }
     }
     if (FF2_PRESCAN) {
-      const bool wany = __builtin_amdgcn_ballot_w64((mz[0] == 0) | (mz[1] == 0)) != 0ull;
+      const bool wany = SCAN_EARLY ? wany_early : __builtin_amdgcn_ballot_w64((mz[0] == 0) | (mz[1] == 0)) != 0ull;
       if (lane == 0) mflag[w] = wany ? 1u : 0u;
     }
     __syncthreads();

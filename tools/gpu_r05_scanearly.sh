@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5: fused forward -- the -1.0 scan of x in the prologue (current) against in the staging phase of the epilogue (scanlate)
+O=gpurun_out/r05_scanearly; mkdir -p $O
+export FREUD_SAE_ALLOW_OLD_LIB=1
+timeout 1800 python -m pytest tests/test_engine_gpu.py tests/test_train_gpu.py tests/test_resume_gpu.py -m gpu -x -q > $O/tests.txt 2>&1; echo "rc=$?" >> $O/tests.txt
+for i in 1 2 3; do
+  for lib in current build/ab/libfreud_sae_scanlate.so; do
+    if [ $lib = current ]; then unset FREUD_SAE_LIB; else export FREUD_SAE_LIB=$lib; fi
+    echo "== $lib"; python bench.py --no-cpu-baseline --steps 50 --warmup 10 --dbg 65 2>&1 | grep -E "^fwd (per-workgroup|prologue|epilogue)"
+  done
+done > $O/stamps.txt 2>&1
+tail -3 $O/tests.txt; cat $O/stamps.txt
