@@ -478,7 +478,7 @@ def main():
     try:
         if args.variant == "l1" and args.precision == "bf16" and (M, d, n) == (65536, 384, 3072):
             import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]   # newest round's pass
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))[-1]   # newest round's pass
             with open(latest) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
             traffic_source = (f"profiles/{os.path.basename(latest)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
