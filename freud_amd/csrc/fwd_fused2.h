@@ -499,12 +499,12 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     const char* xblk = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.x) + m0 * FF_D);
     us2_t mz = {0xFFFFu, 0xFFFFu};
 #pragma unroll
-    for (int p0 = 0; p0 < 24; p0 += 8) {
-      u32x4 xr[8];
+    for (int p0 = 0; p0 < 24; p0 += 4) {      // (four in flight, not eight: the registers are the accumulators' at this point)
+      u32x4 xr[4];
 #pragma unroll
-      for (int pc = 0; pc < 8; ++pc) xr[pc] = *reinterpret_cast<const u32x4*>(xblk + (p0 + pc) * 1024 + lane * 16);
+      for (int pc = 0; pc < 4; ++pc) xr[pc] = *reinterpret_cast<const u32x4*>(xblk + (p0 + pc) * 1024 + lane * 16);
 #pragma unroll
-      for (int pc = 0; pc < 8; ++pc) {
+      for (int pc = 0; pc < 4; ++pc) {
         const int off = (p0 + pc) * 1024 + lane * 16, r = off / (FF_D * 2), cb = off - r * (FF_D * 2);
         *reinterpret_cast<u32x4*>(stg + (32 * w + r) * FF_DXH_PITCH + cb) = xr[pc];
         if (FF2_PRESCAN) {
@@ -521,8 +521,24 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     if (FF2_PRESCAN) { const u32x4 f = *reinterpret_cast<const u32x4*>(mflag); blk_masked = (f[0] | f[1] | f[2] | f[3]) != 0u; }
   }
   if (STAMP) clk_e1 = __builtin_amdgcn_s_memtime();      // x staged (and published)
+  // (vec_ok is a run-time, block-uniform flag: tested inside the loops it ends a basic block per group of 16 elements -- every group waits
+  // for its own LDS reads -- and has the scalar path's 16 column indices computed ahead of each branch.  The no-mask instantiation knows it
+  // is true, so its 12 groups are ONE basic block; the other instantiation keeps the test (three instantiations -- vec_ok as a tag too --
+  // cost 32 spilled accumulators at the head of the epilogue).)
   auto residual = [&](auto notest_tag) {
-  constexpr bool NOTEST = decltype(notest_tag)::value;
+  constexpr bool NOTEST = decltype(notest_tag)::value;      // (implies vec_ok: the scan that clears a block runs only on the vector path)
+  // x of group (mb, dtl) out of the staging image.  The groups are software-pipelined by hand: group g + 1's four 8-byte reads are issued
+  // before group g's arithmetic and a scheduling barrier closes each group -- left to itself in one basic block hipcc hoists all 48 reads
+  // and spills 55 registers; fenced per group without the look-ahead every group waits for its own reads.
+  constexpr bool FENCE = NOTEST && X_VIA_LDS;                             // a scheduling barrier between the groups
+  constexpr bool PIPE = FENCE && std::is_same<T, bf16_t>::value;          // ... and the look-ahead (fp16 activations: 3 spilled registers with it)
+  Tx4 xq[2][4];
+  auto xload = [&](int g, Tx4 (&dst)[4]) {
+    const char* sr = stg + (32 * (g / 3) + arow) * FF_DXH_PITCH + (96 * w + 32 * (g % 3) + 4 * ah) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = *reinterpret_cast<const Tx4*>(sr + 16 * k);
+  };
+  if constexpr (PIPE) xload(0, xq[0]);
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int64_t grow = (int64_t)wg * FF_BM + 32 * mb + arow;   // global activation row of this lane in row block mb
@@ -533,11 +549,17 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #pragma unroll
     for (int dtl = 0; dtl < 3; ++dtl) {
       const int dbase = 96 * w + 32 * dtl + 4 * ah;
-      if (vec_ok) {
+      if (NOTEST || vec_ok) {
+        const int g = 3 * mb + dtl;
+        if constexpr (FENCE) {
+          if (g > 0) __builtin_amdgcn_sched_barrier(0);
+          if (PIPE && g + 1 < 12) xload(g + 1, xq[(g + 1) & 1]);
+        }
         Tx4 xv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          xv[k] = X_VIA_LDS ? *reinterpret_cast<const Tx4*>(srow + (dbase + 8 * k) * 2) : *reinterpret_cast<const Tx4*>(xrow + dbase + 8 * k);
+          xv[k] = PIPE ? xq[g & 1][k]
+                       : (X_VIA_LDS ? *reinterpret_cast<const Tx4*>(srow + (dbase + 8 * k) * 2) : *reinterpret_cast<const Tx4*>(xrow + dbase + 8 * k));
 #ifndef FF2_EPI_V1
         if (!PAD) {
           // The lean form (round 4; round 5: which of its two halves runs is decided per BLOCK while x is staged, see X_FROM_FRAGS above).
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     }
   }
   };
-  if (X_VIA_LDS && FF2_PRESCAN && !blk_masked) residual(std::true_type{}); else residual(std::false_type{});
+  if (X_VIA_LDS && FF2_PRESCAN && vec_ok && !blk_masked) residual(std::true_type{}); else residual(std::false_type{});
   if (STAMP) clk_e2 = __builtin_amdgcn_s_memtime();      // residual arithmetic done, dx_hat in the staging image (not yet published)
   __syncthreads();
   {   // the wave's 32 rows of dx_hat are one contiguous 24 KiB block: 24 fully coalesced 16-byte stores per lane

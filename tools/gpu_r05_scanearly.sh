@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: fused forward -- the -1.0 scan of x in the prologue (current) against in the staging phase of the epilogue (scanlate)
+# round 5: fused forward -- current build against scanlate (= the build of commit 0114179: scan while staging, residual groups each their own basic block)
 O=gpurun_out/r05_scanearly; mkdir -p $O
 export FREUD_SAE_ALLOW_OLD_LIB=1
 timeout 1800 python -m pytest tests/test_engine_gpu.py tests/test_train_gpu.py tests/test_resume_gpu.py -m gpu -x -q > $O/tests.txt 2>&1; echo "rc=$?" >> $O/tests.txt
