@@ -1733,7 +1733,6 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     g.nbm = (int)(Mp / 128); g.nbn = n_p / 128; g.ktiles0 = g.ktiles = d_p / 64; g.splits = 1;
     EpiEnc e{};
     e.c = c->c; e.bias = b; e.l1_part = c->l1_part; e.M = M; e.n_p = n_p; e.nbn = g.nbn;
-    e.skip_store = c->cfg.debug_flags == 70;
     // (streaming form: one L1 partial per WORKGROUP in l1_part[0 .. grid); finalize_losses sums the whole per-tile range, so the
     // rest of it is zeroed -- 4 bytes per 128x128 tile)
     if (gemm_streams<OP_ROW, OP_ROW, EpiEnc>(g)) HIP_TRY(hipMemsetAsync(c->l1_part, 0, (size_t)g.nbm * g.nbn * 4, s));
@@ -2136,7 +2135,7 @@ static int topk_fwd_bwd(sae_ctx* c, const T* x, int64_t M, hipStream_t s, bool b
     hipLaunchKernelGGL(round_bias_kernel, dim3((n_p + 255) / 256), dim3(256), 0, s, be, c->be_r, n_p);
     EpiTopkEnc e{};
     e.pre = c->pre; e.bias = c->be_r; e.M = M; e.n_p = n_p;
-    e.tmax = tile_select ? c->tile_max : nullptr;
+    e.tmax = c->tile_max;      // (always written: a null test per s_apply call would split the streaming epilogue into basic blocks)
     ev_begin(c, KID_TK_ENC, s);
     rc = launch_gemm<OP_ROW, OP_ROW>(g, e, s);
     ev_end(c, KID_TK_ENC, s);

@@ -157,6 +157,11 @@ __global__ __launch_bounds__(256) void finalize_count_kernel(const unsigned int*
 #define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 // ... and the matching read of such a stream inside an epilogue (dpre GEMM reading the latent: 7.6 -> 7.1 ms)
 #define EPI_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#ifdef EPI_KO_SKIP_STORE
+#define EPI_ENC_STORE(ptr, val) asm volatile("" :: "v"(val))      // knock-out build: the encoder's latent is computed and dropped
+#else
+#define EPI_ENC_STORE(ptr, val) EPI_STORE(ptr, val)
+#endif
 
 // GEMM epilogues (row-major over the fp32 tile, 4 consecutive columns per call).  Two phases per thread and tile:
 // prefetch(row, col) -> Pre issues every global LOAD the element needs (all of a thread's 16 prefetches are in flight
@@ -170,7 +175,8 @@ struct EpiEnc {
   float* l1_part;       // [tiles]
   int64_t M;
   int n_p, nbn;
-  int skip_store;       // timing experiment (debug_flags 70): no latent store -- results become wrong
+  // (the timing experiment "no latent store" -- round 2's `bench.py --dbg 70` -- is a BUILD switch since round 5: -DEPI_KO_SKIP_STORE.  As a
+  // run-time member it put a branch around the store of every s_apply call, i.e. a basic-block boundary per 8 latents in the epilogue.)
   float l1;
   int tile_id;
   __device__ void tile_begin(int row0, int col0, int) {
@@ -189,7 +195,7 @@ struct EpiEnc {
       l1 += cv;
       o[j] = (bf16_t)cv;
     }
-    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
+    EPI_ENC_STORE(reinterpret_cast<bf16x4*>(c + (int64_t)row * n_p + col), o);
   }
   static constexpr bool WIDE8 = true;                 // gemm256.h: eight columns per thread, 16-byte latent stores
   __device__ void apply8(int row, int col, f32x4 v0, f32x4 v1, const Pre& p0, const Pre& p1) {
@@ -202,7 +208,7 @@ struct EpiEnc {
       o[j] = (bf16_t)c0;
       o[4 + j] = (bf16_t)c1;
     }
-    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+    EPI_ENC_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
   }
   __device__ void tile_end(float* scratch) {
     const float s = block_sum_256_lds(l1, scratch);
@@ -234,7 +240,7 @@ struct EpiEnc {
     }
     const bf16x8 o = {(bf16_t)sv[0][0], (bf16_t)sv[0][1], (bf16_t)sv[1][0], (bf16_t)sv[1][1],
                       (bf16_t)sv[2][0], (bf16_t)sv[2][1], (bf16_t)sv[3][0], (bf16_t)sv[3][1]};
-    if (!skip_store) EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
+    EPI_ENC_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
   }
   __device__ void s_tile_end(int, int) {}
   __device__ void s_end(float* scratch) {

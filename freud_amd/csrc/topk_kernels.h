@@ -241,7 +241,8 @@ struct EpiTopkEnc {
     EPI_STORE(reinterpret_cast<u32x4*>(pre + (int64_t)row * n_p + col),
               (u32x4{__builtin_bit_cast(unsigned int, p[0]), __builtin_bit_cast(unsigned int, p[1]),
                      __builtin_bit_cast(unsigned int, p[2]), __builtin_bit_cast(unsigned int, p[3])}));
-    if (tmax) {
+    {   // (no `if (tmax)` and no lane predicate on the store below: either is a branch per call, i.e. a basic-block boundary per 8 latents;
+        //  the engine always passes the tile-maximum buffer, and the four lanes of a quad store the same value to the same address)
       const u16x2 a = __builtin_elementwise_max(__builtin_bit_cast(u16x2, p[0]), __builtin_bit_cast(u16x2, p[1]));
       const u16x2 b = __builtin_elementwise_max(__builtin_bit_cast(u16x2, p[2]), __builtin_bit_cast(u16x2, p[3]));
       const unsigned int mm = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
@@ -252,7 +253,7 @@ struct EpiTopkEnc {
         m1 = max(m1, smax[iq]);
         m1 = max(m1, (unsigned int)__builtin_amdgcn_update_dpp((int)m1, (int)m1, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
         m1 = max(m1, (unsigned int)__builtin_amdgcn_update_dpp((int)m1, (int)m1, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-        if ((threadIdx.x & 3) == 0) tmax[(int64_t)row * (n_p >> 6) + (col >> 6)] = (unsigned short)m1;
+        tmax[(int64_t)row * (n_p >> 6) + (col >> 6)] = (unsigned short)m1;
       }
     }
   }
