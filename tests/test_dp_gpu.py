@@ -219,32 +219,84 @@ def _free_port():
     return p
 
 
-def _run_children(script, cfg_path, world, extra_env, timeout=900):
+def _run_children_once(script, cfg_path, world, extra_env, timeout=420):
+    """Start `world` ranks of `script` on GPU 0 and wait for them.  Output goes to files (no pipe to fill up while nobody reads); the
+    wait polls ALL ranks: when one exits with an error the others get 30 s to follow and are then stopped, and when the time is up
+    every rank still alive is made to dump its Python stacks (faulthandler, SIGABRT) -- a failure reports every rank's tail, because
+    the rank that reports is rarely the one that failed, and a hang says where each rank stood."""
     import os
+    import signal
     import subprocess
     import sys
+    import tempfile
+    import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = _free_port()
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="freud_dp_children_")
+    procs, files = [], []
     for r in range(world):
-        env = dict(os.environ, FREUD_ROOT=root, **extra_env)
+        env = dict(os.environ, FREUD_ROOT=root, PYTHONFAULTHANDLER="1", **extra_env)
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
             env.pop(k, None)
-        if world > 1:      # both ranks on GPU 0: the exchange runs between two processes that share the device
+        if world > 1:      # all ranks on GPU 0: the exchange runs between processes that share the device
             env.update(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, script, cfg_path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                      text=True))
-    outs = []
+        fo, fe = open(os.path.join(logdir, f"rank{r}.out"), "w"), open(os.path.join(logdir, f"rank{r}.err"), "w")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen([sys.executable, script, cfg_path], env=env, stdout=fo, stderr=fe, text=True))
+    deadline = time.time() + timeout
+    why = None
     try:
-        for pr in procs:
-            outs.append(pr.communicate(timeout=timeout))
+        while True:
+            rcs = [pr.poll() for pr in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            now = time.time()
+            if any(rc not in (None, 0) for rc in rcs) and why is None:
+                why = "a rank exited with an error; the others were given 30 s"
+                deadline = min(deadline, now + 30)
+            if now > deadline:
+                why = why or f"still running after {timeout} s"
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.send_signal(signal.SIGABRT)          # the exact children this test started
+                time.sleep(5)
+                break
+            time.sleep(0.1)
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()           # the exact children this test started
-    if any(pr.returncode != 0 for pr in procs):      # every rank's tail: the rank that reports is rarely the one that failed
-        raise AssertionError("\n".join(f"--- rank {r}: rc {pr.returncode}\n{so[-600:]}\n{se[-1500:]}" for r, (pr, (so, se)) in enumerate(zip(procs, outs))))
+        for pr in procs:
+            pr.wait()
+        for fo, fe in files:
+            fo.close()
+            fe.close()
+    outs = []
+    for r in range(world):
+        with open(os.path.join(logdir, f"rank{r}.out")) as f1, open(os.path.join(logdir, f"rank{r}.err")) as f2:
+            outs.append((f1.read(), f2.read()))
+    if why is not None or any(pr.returncode != 0 for pr in procs):
+        raise AssertionError((why or "a rank failed") + "\n" +
+                             "\n".join(f"--- rank {r}: rc {pr.returncode}\n{so[-600:]}\n{se[-3000:]}" for r, (pr, (so, se)) in enumerate(zip(procs, outs))))
     return outs
+
+
+# what a start-up failure of the BOX looks like (several processes initialising one GPU / one rendezvous port at once), as opposed to a
+# failure of the code under test: such a run is repeated once, with the first attempt's report kept on stderr
+_INFRA_PATTERNS = ("Address already in use", "Connection refused", "Connection reset", "hipErrorNoDevice", "hipErrorOutOfMemory",
+                   "hipErrorInvalidDevice", "no ROCm-capable device", "HSA_STATUS_ERROR_OUT_OF_RESOURCES", "failed to initialize",
+                   "DistNetworkError", "DistStoreError")
+
+
+def _run_children(script, cfg_path, world, extra_env, timeout=420):
+    import sys
+    try:
+        return _run_children_once(script, cfg_path, world, extra_env, timeout)
+    except AssertionError as e:
+        if not any(p in str(e) for p in _INFRA_PATTERNS):
+            raise
+        print("first attempt failed at start-up, repeating once:\n" + str(e)[-4000:], file=sys.stderr)
+        return _run_children_once(script, cfg_path, world, extra_env, timeout)
 
 
 @pytest.mark.parametrize("case,payload,overlap", [
