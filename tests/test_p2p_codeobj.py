@@ -148,10 +148,7 @@ def test_statistics_push_orders_payload_before_epoch(disasm, key):
 # threshold and every accumulator array went to the stack, 1.8 KB per lane) fails here, on the build host, instead of showing up as
 # a slow GPU run.
 # ---------------------------------------------------------------------------------------------------------------------
-# The one exception is a DIAGNOSTIC instantiation, never launched by a training step: the fused forward with in-kernel clock stamps
-# (STAMP = true, `bench.py --dbg 65`) parks one value on the stack before its tile loop and reads it back three times in the epilogue --
-# nothing inside the loop.  The shipped instantiations of the same kernel (and everything else) stay at zero.
-SCRATCH_ALLOWED = {"_Z22fwd_fused2_d384_kernelIDF16bLb0ELb1EEv12FwdFusedArgs": 4}
+SCRATCH_ALLOWED = {}
 
 
 def test_no_kernel_spills_to_scratch():
