@@ -1017,7 +1017,17 @@ __global__ __launch_bounds__(OPTC_THREADS) void optimizer_l1_cols_kernel(float* 
   float* pn = optc_smem;                              // [d_p][OPTC_COLS] updated weights of this workgroup's columns
   float* red = pn + d_p * OPTC_COLS;                  // [nslab][8][OPTC_COLS]
   float* den = red + nslab * 8 * OPTC_COLS;           // [OPTC_COLS]
-  const int col0 = blockIdx.x * OPTC_COLS;
+  // Column block of this workgroup, XCD-major (round 5): a workgroup touches 64-byte pieces of fp32 rows (16 columns) and 32-byte pieces of the
+  // bf16 copy, i.e. half / a quarter of a 128-byte line, and workgroup b runs on XCD b % 8 -- with column block = blockIdx the other half of
+  // every line was fetched (and written back) by ANOTHER XCD's L2.  Now XCD x owns the contiguous column blocks [x ncb / 8, (x + 1) ncb / 8)
+  // and neighbours in a line are dispatched 8 block indices apart, i.e. together.  (-DOPTC_NO_XCD_MAP = the old numbering; n_p is a
+  // multiple of 128, so ncb is a multiple of 8.)
+#ifndef OPTC_NO_XCD_MAP
+  const int cblk = bias_block ? 0 : ((int)blockIdx.x & 7) * (ncb >> 3) + ((int)blockIdx.x >> 3);
+#else
+  const int cblk = blockIdx.x;
+#endif
+  const int col0 = cblk * OPTC_COLS;
   const int tx = t % OPTC_TPR, ty = t / OPTC_TPR;      // update / Wb mapping: columns 4 tx .. 4 tx + 3, rows ty + 128 i
   // the loads of the update first: they do not depend on the clip coefficient
   f32x4 dn = {1.f, 1.f, 1.f, 1.f};
