@@ -36,13 +36,21 @@ __global__ __launch_bounds__(1024) void dead_compact_kernel(const long long* __r
   // global memory was a chain of dependent round trips in this one-workgroup kernel
   unsigned long long dbits[2] = {0ull, 0ull};
   const bool inreg = per <= 128;
-#pragma unroll 8
-  for (int i = c0; i < c0 + per && i < n_p; ++i) {
-    const bool dd = i < n && (double)nfsf[i] > threshold;
-    dead[i] = dd;
-    did_fire[i] = 0.f;
-    cnt += dd;
-    if (dd && inreg) dbits[(i - c0) >> 6] |= 1ull << ((i - c0) & 63);
+  // (eight counters per trip from clamped addresses, all in flight before the first is used: as a plain loop with its two exit tests per
+  // element every load was waited for on its own -- 24 memory latencies in a row per thread of this one-workgroup kernel at n = 24 576)
+  for (int i0 = c0; i0 < c0 + per && i0 < n_p; i0 += 8) {       // per and n_p are multiples of 8
+    long long fv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fv[u] = nfsf[i0 + u < n ? i0 + u : n - 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u;
+      const bool dd = i < n && (double)fv[u] > threshold;
+      dead[i] = dd;
+      did_fire[i] = 0.f;
+      cnt += dd;
+      if (dd && inreg) dbits[(i - c0) >> 6] |= 1ull << ((i - c0) & 63);
+    }
   }
   int inc = cnt;
 #pragma unroll
