@@ -1410,12 +1410,34 @@ __global__ __launch_bounds__(1024) void topk_finalize_kernel(const double* __res
   const bool have_aux = a2_part != nullptr && tk[0] > 0;     // with no dead latent the AuxK kernels did not run
 #pragma unroll 8      // (one workgroup: eight trips' loads in flight, same order of the sums)
   for (int i = threadIdx.x; i < n_tv; i += 1024) a += tv_part[i];
-#pragma unroll 8
-  for (int64_t i = threadIdx.x; i < Mp; i += 1024) {
-    b += (double)e2_part[i];
-    if (have_aux) c += (double)a2_part[i];
-    if (m2_part) m += (double)m2_part[i];
-  }
+  // (the two run-time switches as template tags, eight trips' loads in flight: tested per trip they were a branch and a wait per load --
+  // 64 trips per thread at M = 65 536, 38 us with AuxK active in this one-workgroup kernel.  Same order of the sums.)
+  auto rows = [&](auto aux_tag, auto multi_tag) {
+    constexpr bool AUX = decltype(aux_tag)::value, MULTI = decltype(multi_tag)::value;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < Mp; i += 8 * 1024) {
+      float ev[8], av[8], mv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ev[u] = e2_part[i + u * 1024];
+        av[u] = AUX ? a2_part[i + u * 1024] : 0.f;
+        mv[u] = MULTI ? m2_part[i + u * 1024] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        b += (double)ev[u];
+        if (AUX) c += (double)av[u];
+        if (MULTI) m += (double)mv[u];
+      }
+    }
+    for (; i < Mp; i += 1024) {
+      b += (double)e2_part[i];
+      if (AUX) c += (double)a2_part[i];
+      if (MULTI) m += (double)m2_part[i];
+    }
+  };
+  if (have_aux) { if (m2_part) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+  else          { if (m2_part) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
   a = wave_sum_d(a);
   b = wave_sum_d(b);
   c = wave_sum_d(c);
