@@ -5,7 +5,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define P2P_HD __host__ __device__ __forceinline__
 #else
 #define P2P_HD inline

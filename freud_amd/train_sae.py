@@ -339,8 +339,8 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
     try:
         val_ds_T = int(MemoryMappedActivationDataLoader(val_folder, whisper_config["layer_name"], 1).dataset.tensor_shape[-2])
         max_rows = max(max_rows, val_ds_T)
-    except Exception:
-        pass
+    except (OSError, KeyError, IndexError, ValueError):
+        pass        # no (readable) validation shard: validate() will say so itself when it is reached
     if autoencoder_variant == "l1":
         cfg = L1AutoEncoderConfig.from_dict(autoencoder_config)
         n_dict = get_n_dict_components(feat_dim, cfg.expansion_factor, cfg.n_dict_components)
