@@ -96,6 +96,83 @@ def cpu_baseline(x, W, b, steps, lr):
                       f"batch, torch-CPU bf16-autocast restatement of train_sae.py:429-451, {dt:.3f} s/step"}
 
 
+def latent_nonzero_frac(eng, M, n, device):
+    """Fraction of non-zero entries in the bf16 latent the last forward left in HBM (the operand content the power-managed clock
+    responds to: an over-fitted single batch ends with a much sparser latent than the first steps of a run)."""
+    ptr, ld = eng.latent_buffer()
+
+    class _Alias:
+        __cuda_array_interface__ = {"shape": (M, int(ld)), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
+
+    c = torch.as_tensor(_Alias(), device=device)[:, :n]
+    return float(torch.count_nonzero(c).item()) / (M * n)
+
+
+def data_sensitivity(M, d, n, dtype, W, b, device_id, steps=20, warmup=5, spinup=0.5):
+    """How much of the headline is its data (SURVEY 8d asks for the N(0,1) line next to the low-rank one).  Each
+    leg is a FRESH engine context timed the driver's way (spin-up on its own step, `warmup` untimed steps, `steps` timed), outside the
+    headline's timed region: `lowrank` = the headline's batch again (the like-for-like reference of the other legs), `normal` = pure
+    N(0,1) activations, `rotate4` = four resident low-rank batches in rotation (no batch is over-fitted), `raw_cast` = the low-rank
+    batch cast to bf16 WITHOUT the loader's -1.0 guard (0.1 % of its entries then read as padding and every block takes the masked
+    path), `fresh_weights` = the clocks are spun up on a SEPARATE context and the timed steps are steps 3.. of a run from the
+    orthogonal initialisation (dense latent, nothing fitted yet)."""
+    from freud_amd.engine import SaeEngine
+    dev = torch.device("cuda", device_id)
+    lr = 4e-4
+
+    def fresh_engine():
+        e = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer="radam", recon_alpha=1e4, clip_thresh=1.0,
+                      device_id=device_id)
+        e.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+        return e
+
+    def spin(e, xs, seconds):
+        t0, i = time.perf_counter(), 0
+        while True:
+            for _ in range(20):
+                e.step(xs[i % len(xs)], lr)
+                i += 1
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= seconds:
+                return
+
+    def leg(xs, fresh=False):
+        xs = [x.to(dev) for x in xs]
+        e = fresh_engine()
+        if fresh:
+            other = fresh_engine()
+            spin(other, xs, spinup)
+            other.close()
+            wu = 2
+        else:
+            spin(e, xs, spinup)
+            wu = warmup
+        for i in range(wu):
+            e.step(xs[i % len(xs)], lr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            e.step(xs[(wu + i) % len(xs)], lr)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        m = e.metrics()
+        out = {"ms_per_step": ms, "step_mfma_frac": 10.0 * M * d * n / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+               "latent_nonzero_frac": latent_nonzero_frac(e, M, n, dev), "recon": float(m[0]), "l1": float(m[1])}
+        e.close()
+        return out
+
+    low = [make_inputs(M, d, n, 1000 + 7919 * j, dtype, "lowrank")[0] for j in range(4)]
+    res = {"lowrank": leg(low[:1]),
+           "normal": leg([make_inputs(M, d, n, 1000, dtype, "normal")[0]]),
+           "rotate4": leg(low),
+           "raw_cast": leg([make_inputs(M, d, n, 1000, dtype, "lowrank", guard=False)[0]]),
+           "fresh_weights": leg(low[:1], fresh=True),
+           "how": f"each leg: fresh context, {spinup} s spin-up on its own step, {warmup} untimed + {steps} timed steps, outside the "
+                  "headline's timed region; fresh_weights: spin-up on a separate context, 2 untimed + timed steps from the orthogonal "
+                  "initialisation; latent_nonzero_frac of the leg's last forward"}
+    return res
+
+
 def pcie_inclusive_sample(d, n, files=320, batch_files=40, T=1500, epochs=6):
     """The same train step fed by the activation loader from fp32 shards in the collector's format (host page cache -> gather
     threads, fp32 -> bf16 -> pinned ring -> HBM): what a real `--config` run gets when the batch is NOT resident.  A bounded
@@ -162,6 +239,61 @@ def pcie_inclusive_sample(d, n, files=320, batch_files=40, T=1500, epochs=6):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher's environment: spawn the N ranks as CHILD processes (one per GPU, the
+    launcher's variables set the way torch.distributed.run sets them), relay rank 0's single JSON line, exit non-zero if any rank
+    does.  This parent makes no HIP call (torch.cuda.device_count() does not initialise the GPU on this image) and execs nothing."""
+    import socket
+    import subprocess
+    share = os.environ.get("FREUD_BENCH_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); nothing was measured.  (Tests of the N > 1 control flow on a "
+              "one-GPU box: FREUD_BENCH_SHARE_GPU=1.)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as cap:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FREUD_BENCH_LAUNCHER="bench.py (self-launched ranks)")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=cap if r == 0 else sys.stderr))
+        rcs = [None] * n
+        while any(rc is None for rc in rcs):
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = pr.poll()
+            if any(rc not in (None, 0) for rc in rcs):      # a rank died: the others would wait in a collective for ever --
+                for r, pr in enumerate(procs):              # stop exactly the processes started here
+                    if rcs[r] is None:
+                        pr.terminate()
+                        try:
+                            rcs[r] = pr.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            pr.kill()
+                            rcs[r] = pr.wait()
+                break
+            time.sleep(0.05)
+        cap.seek(0)
+        out0 = cap.read()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if bad or len(lines) != 1:
+        sys.stderr.write(out0 or "")
+        print(f"bench.py: self-launched run failed: exit codes by rank {rcs}, {len(lines)} JSON line(s) from rank 0", file=sys.stderr)
+        return next((rc for _, rc in bad), 1) or 1
+    line = json.loads(lines[0])
+    if line.get("n_gpus") != n:
+        print(f"bench.py: rank 0 reported n_gpus={line.get('n_gpus')} for --gpus {n}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +327,9 @@ def main():
     ap.add_argument("--gemm128", action="store_true", help="A/B timing: keep the generic GEMMs on the 128x128 kernel")
     ap.add_argument("--data", default="lowrank", choices=["lowrank", "normal", "zeros"],
                     help="synthetic activation distribution (lowrank = the reported workload; zeros = clock diagnostic)")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="this many resident synthetic batches (different seeds) taken in rotation; 1 = the headline's single batch")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the data_sensitivity legs of the default N=1 line")
     ap.add_argument("--raw-cast", action="store_true",
                     help="diagnostic: synthetic fp32 cast to the activation dtype WITHOUT the loader's -1.0 guard (see to_activation_dtype)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel timing-experiment flags (invalidates results)")
@@ -203,11 +338,16 @@ def main():
                     help="fp8 = BASELINE configs[4]: e4m3 encoder / decoder GEMMs (L1 only); fp8bwd: the dpre GEMM of the backward too")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: become one (the parent touches no GPU) -- `--gpus N` can never print an n_gpus: 1 line
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`, or unset WORLD_SIZE and "
+                         "let bench.py spawn the ranks itself")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the train step)"
     # FREUD_BENCH_SHARE_GPU=1 (tests): every rank on GPU 0 with gloo as the host channel -- two RCCL ranks cannot share a device,
     # the engine's own peer exchange can (tests/test_dp_gpu.py), so the N > 1 control flow of this file runs on a one-GPU box
@@ -245,6 +385,8 @@ def main():
     dtype = getattr(torch, args.x_dtype)
     x_cpu, W, b = make_inputs(M, d, n, seed=1000 + rank, dtype=dtype, kind=args.data, guard=not args.raw_cast)
     x = x_cpu.cuda()
+    xs = [x] + [make_inputs(M, d, n, seed=1000 + rank + 7919 * j, dtype=dtype, kind=args.data, guard=not args.raw_cast)[0].cuda()
+                for j in range(1, max(args.rotate, 1))]
     total_steps, base_lr = 100000, 4e-4
 
     def attempt(mode_override=None):
@@ -291,6 +433,7 @@ def main():
         lr_of = lambda i: base_lr * (1 + math.cos(math.pi * i / total_steps)) / 2
 
         def one_step(i):
+            x = xs[i % len(xs)]
             if use_dist and args.dp_host:
                 eng.batch_stats(x)
                 dist.all_reduce(eng.stats_tensor())
@@ -305,8 +448,8 @@ def main():
         if args.spinup > 0:                      # clock spin-up (see the module docstring); not part of W or K
             t_spin = time.perf_counter()
             while True:
-                for _ in range(20):
-                    one_step(0)
+                for j in range(20):
+                    one_step(j)                  # (with --rotate the spin-up rotates too; the index only chooses batch and LR)
                 torch.cuda.synchronize()
                 elapsed = time.perf_counter() - t_spin
                 if use_dist:                     # every rank must leave after the same number of (collective) steps
@@ -466,6 +609,14 @@ def main():
                        "step WITHOUT any exchange, same process and GPU, K steps after W warm-up (max over ranks); "
                        "exposed_exchange_ms = ms_per_step - plain_ms_per_step",
             }
+        if use_dist and world > 1:
+            # the rank count as RCCL itself reports it (a one-element sum over torch.distributed's nccl backend = RCCL), so that a
+            # line can never claim more ranks than exchanged data -- north_star names RCCL; with gloo as host channel (the shared-GPU
+            # test mode) the count is gloo's and says so
+            one = torch.ones(1, device=ctrl_dev, dtype=torch.int32)
+            dist.all_reduce(one)
+            dp_timing["ranks_counted_by_collective"] = int(one.item())
+            dp_timing["collective_backend"] = "rccl (torch.distributed nccl backend)" if dist.get_backend() == "nccl" else dist.get_backend()
         if rank == 0 and (args.breakdown or args.precision != "bf16"):
             print("per-kernel ms (HIP events, level-2 profile):", json.dumps(breakdown), file=sys.stderr)
         if rank != 0 or not (args.breakdown or args.precision != "bf16"):
@@ -500,7 +651,8 @@ def main():
         "metric": f"SAE train activations/sec (d={d} dict {n // d}x)", "value": value, "unit": "activations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_s": args.spinup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-        "data": ("synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)") + (" (raw cast; diagnostic)" if args.raw_cast else ""),
+        "data": ("synthetic" if args.data == "lowrank" else f"synthetic ({args.data}; diagnostic)") + (" (raw cast; diagnostic)" if args.raw_cast else "")
+                + (f" ({len(xs)} resident batches in rotation)" if len(xs) > 1 else ""),
         "config": {"workload": f"Whisper-{model_name} d={d} dict {n // d}x (n={n}) L1 SAE train step, M={M} rows/GPU/step, "
                                f"RAdam+cosine, x {args.x_dtype} resident in HBM"
                                + (" (BASELINE configs[1])" if (d, n, M) == (384, 3072, 65536) else ""),
@@ -518,6 +670,13 @@ def main():
         "fwd_bwd_ms": fb_ms / max(fb_cnt, 1),
         "loss": {"recon": float(metrics[0]), "l1": float(metrics[1]), "grad_norm": float(metrics[3])},
     }
+    if os.environ.get("FREUD_BENCH_LAUNCHER"):
+        out["config"]["launcher"] = os.environ["FREUD_BENCH_LAUNCHER"]
+    if args.variant == "l1" and args.precision == "bf16":
+        try:
+            out["latent_nonzero_frac"] = latent_nonzero_frac(eng, M, n, torch.device("cuda", local_rank))
+        except Exception as e:              # noqa: BLE001 -- an extra
+            out["latent_nonzero_frac"] = None
     if breakdown:
         out["kernel_ms"] = breakdown
     if dp_timing:
@@ -608,11 +767,54 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     eng.close()
+    if (rank == 0 and world == 1 and not use_dist and not args.no_sensitivity and not args.no_cpu_baseline and args.variant == "l1"
+            and args.precision == "bf16" and args.dbg == 0):
+        try:
+            out["data_sensitivity"] = data_sensitivity(M, d, n, dtype, W, b, local_rank)
+        except Exception as e:              # noqa: BLE001 -- an extra; must never cost the bench line
+            out["data_sensitivity"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.no_pcie_sample and not args.no_cpu_baseline and args.variant == "l1" and args.precision == "bf16":
         try:
             out["pcie_inclusive"] = pcie_inclusive_sample(d, n)
         except Exception as e:              # noqa: BLE001 -- an extra; must never cost the bench line
             out["pcie_inclusive"] = {"error": str(e)[:200]}
+    # N > 1: the OTHER carrier's number next to the headline's (north_star names RCCL; the peer exchange is auto's first choice): a short
+    # leg on a fresh context after everything else is in `out`.  It runs under a watchdog thread: a carrier that hangs (RCCL can; the
+    # engine's own exchange times out by itself) costs this leg, never the line -- rank 0 prints the line without it and every rank leaves.
+    other = {"p2p": "rccl", "rccl": "p2p"}.get(dp_mode) if (use_dist and world > 1 and dp_timing is not None) else None
+    if (other and dp_fallback is None and os.environ.get("FREUD_BENCH_OTHER_CARRIER", "1") != "0"
+            and (other != "rccl" or dist.get_backend() == "nccl")):
+        import threading
+        eng.close()
+        limit = float(os.environ.get("FREUD_BENCH_OTHER_CARRIER_TIMEOUT", "180"))
+
+        def give_up():
+            if rank == 0:
+                dp_timing["other_carrier"] = {"carrier": other, "error": f"no result within {limit:.0f} s; leg abandoned"}
+                out["dp_timing"] = dp_timing
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
+        saved_leg = (args.steps, args.warmup, args.spinup)
+        args.steps, args.warmup, args.spinup = min(args.steps, 20), min(args.warmup, 5), min(args.spinup, 0.5)
+        try:
+            e2, _, dt2, mode2, ok2, _ = attempt(other)
+            good = bool(ok2) and mode2 == other and dt2 > 0
+            dp_timing["other_carrier"] = {"carrier": mode2, "healthy": bool(ok2), "steps": args.steps,
+                                          "ms_per_step": dt2 / args.steps * 1e3 if good else None,
+                                          "value": M * world * args.steps / dt2 if good else None}
+            if mode2 == "rccl":
+                dp_timing["other_carrier"]["ranks_in_engine_communicator"] = e2.dist_world()
+            e2.close()
+        except BaseException as e:          # noqa: BLE001 -- an extra leg; the headline stands without it
+            dp_timing["other_carrier"] = {"carrier": other, "error": str(e)[:200]}
+        finally:
+            args.steps, args.warmup, args.spinup = saved_leg
+            dog.cancel()
+        out["dp_timing"] = dp_timing
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

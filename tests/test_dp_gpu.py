@@ -700,3 +700,27 @@ def test_bench_with_a_broken_peer_exchange_falls_back_and_says_so():
     assert d["n_gpus"] == 2 and d["config"]["dp"].startswith("host-driven"), d["config"]["dp"]
     assert "fallback" in d["config"]["dp"] and "differs from the gloo all-reduce" in d["config"]["dp"], d["config"]["dp"]
     assert np.isfinite(d["loss"]["recon"])
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO rank environment: the process becomes the launcher -- it touches no
+    GPU, starts two child ranks with the launcher's variables, relays rank 0's single line -- so that the command can never print an
+    `n_gpus: 1` line for `--gpus 2`.  (Both ranks on GPU 0 here: FREUD_BENCH_SHARE_GPU=1.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FREUD_BENCH_SHARE_GPU"] = "1"
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "4", "--rows", "8192",
+                         "--no-cpu-baseline", "--spinup", "0"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and "self-launched" in d["config"]["launcher"]
+    assert d["config"]["dp"].startswith("in-engine peer exchange"), d["config"]["dp"]
+    t = d["dp_timing"]
+    assert t["ranks_counted_by_collective"] == 2 and t["collective_backend"] == "gloo", t
+    assert d["value"] == pytest.approx(8192 * 2 / (d["ms_per_step"] * 1e-3), rel=1e-6)

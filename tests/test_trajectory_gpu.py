@@ -1,0 +1,176 @@
+"""Fifty-step parity trajectories of the HIP engine (through the C ABI) against the CPU oracle: what SURVEY.md section 8(c) states as
+the band for a 30-step run -- per-step losses rtol 1e-2, final weights rel-L2 <= 1e-3 -- held over FIFTY optimizer steps on five
+rotating batches (reference loop: /root/reference/src/scripts/train_sae.py:421-453).  The single-step and 3-7-step tests elsewhere
+cannot bound a SYSTEMATIC difference: the engine keeps the tied weight gradient in fp32 where CPU autocast rounds both GEMM outputs
+to bf16 (bwd_fused.h:1-12), so the Adam moments see slightly different gradients at every step; only a long run shows whether that
+stays inside the band or accumulates.
+
+  * L1 at the headline shape d=384, n=3072 (fused kernels), M=3000 (two files of 1500 frames), RAdam + cosine over the whole run,
+    planted -1.0 entries in every batch;
+  * TopK on batches that are tie-free BY CONSTRUCTION (each row is a sum of k dictionary atoms with amplitudes well above the
+    cross-talk of the other latents: the k-th and (k+1)-th pre-activation stay > 2^-6 apart in relative terms along the whole
+    oracle trajectory -- asserted at every step), so that the index SETS must be identical at every one of the fifty steps;
+  * fp8 (e4m3 encoder / decoder GEMMs; not a reference mode) against its own fp8 oracle at the band above AND against the bf16
+    oracle: the drift of fp8 training from the reference's arithmetic is reported and held to a stated bound.
+The measured drifts are printed (pytest -s) and recorded in DESIGN.md section 2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+STEPS, NB = 50, 5
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def _l1_batches(d, M, seed, dtype=torch.bfloat16, planted=40):
+    g = torch.Generator().manual_seed(seed)
+    mix = torch.randn(64, d, generator=g)
+    xs = []
+    for _ in range(NB):
+        x = ((torch.relu(torch.randn(M, 64, generator=g)) * 0.1) @ mix).to(dtype)
+        x.view(-1)[torch.randint(0, x.numel(), (planted,), generator=g)] = -1.0       # padding entries (l1autoencoder.py:29-36)
+        xs.append(x)
+    return xs
+
+
+def _run_l1(d, n, M, precision, opt, base_lr, oracle_precisions, seed=11):
+    """Engine and oracle(s) side by side for STEPS steps.  Returns per-step relative loss differences and the final states."""
+    from freud_amd.engine import SaeEngine
+    g = torch.Generator().manual_seed(seed)
+    if precision == "bf16":
+        W = torch.empty(d, n)
+        torch.nn.init.orthogonal_(W, generator=g)                                     # l1autoencoder.py:63
+    else:
+        W = torch.randn(d, n, generator=g) / d ** 0.5
+    b = torch.zeros(n)
+    xs = _l1_batches(d, M, seed + 1)
+    xd = [x.cuda() for x in xs]
+    alpha = 1e4
+    eng = SaeEngine(variant="l1", d_model=d, n_dict=n, max_rows=M, optimizer=opt, recon_alpha=alpha, precision=precision)
+    eng.set_params({"decoder.weight": W.numpy(), "encoder_bias": b.numpy()})
+    orc = {p: (W.clone(), b.clone(), O.OptState()) for p in oracle_precisions}
+    diffs = {p: [] for p in oracle_precisions}
+    for i in range(STEPS):
+        lr = O.lr_at(i, base_lr, "cosine", STEPS)
+        eng.step(xd[i % NB], lr)
+        m = eng.metrics()
+        for p, (Wo, bo, st) in orc.items():
+            out = O.l1_train_step(xs[i % NB].float(), Wo, bo, st, recon_alpha=alpha, lr=lr, clip_thresh=1.0, optimizer=opt, precision=p)
+            diffs[p].append([abs(m[0] / out["reconstruction_loss"].item() - 1), abs(m[1] / out["l1_loss"].item() - 1),
+                             abs(m[3] / out["grad_norm"].item() - 1)])
+    params = eng.get_params()
+    step, m1, m2 = eng.get_opt_state()
+    eng.close()
+    assert step == STEPS
+    return {p: np.array(v) for p, v in diffs.items()}, params, (m1, m2), orc, (W, xs)
+
+
+def test_l1_fifty_step_trajectory_at_the_headline_shape():
+    d, n, M = 384, 3072, 3000
+    diffs, params, (m1, m2), orc, (W0, _) = _run_l1(d, n, M, "bf16", "radam", 4e-4, ["bf16"])
+    Wo, bo, st = orc["bf16"]
+    dl = diffs["bf16"]
+    w_rel = _rel(params["decoder.weight"], Wo.numpy())
+    moved = _rel(Wo.numpy(), O.normalize_columns(W0.clone()).numpy())     # (against the first forward's unit-norm columns)
+    print(f"\nL1 50 steps: max rel diff recon {dl[:, 0].max():.2e} l1 {dl[:, 1].max():.2e} gnorm {dl[:, 2].max():.2e}; "
+          f"final W rel-L2 {w_rel:.2e} (weights moved {moved:.2e} from the initialisation); "
+          f"m_W {_rel(m1['decoder.weight'], st.exp_avg['decoder.weight'].numpy()):.2e} "
+          f"v_W {_rel(m2['decoder.weight'], st.exp_avg_sq['decoder.weight'].numpy()):.2e} "
+          f"b {_rel(params['encoder_bias'], bo.numpy()):.2e}")
+    assert moved > 0.05                                   # the run goes somewhere: the weights change by far more than the band
+    assert dl[:, :2].max() < 1e-2 and dl[:, 2].max() < 1e-2, dl.max(0)          # trajectory losses rtol 1e-2
+    assert w_rel < 1e-3                                                         # weights rel-L2 <= 1e-3
+    assert _rel(m1["decoder.weight"], st.exp_avg["decoder.weight"].numpy()) < 2e-2
+    assert _rel(m2["decoder.weight"], st.exp_avg_sq["decoder.weight"].numpy()) < 2e-2
+    assert _rel(m1["encoder_bias"], st.exp_avg["encoder_bias"].numpy()) < 2e-2
+    assert _rel(params["encoder_bias"], bo.numpy()) < 2e-2
+
+
+def test_fp8_fifty_step_trajectory_tracks_its_oracle_and_the_bf16_arithmetic():
+    """d=1280, n=2560, M=512 (every padded dimension a multiple of 256, the fp8 GEMMs' own kernels).  Against the fp8 oracle the
+    run is held to the trajectory band; against the bf16 oracle -- the reference's arithmetic -- the drift is what fp8 costs: stated
+    here as losses within 3e-2 at every step and final weights within 2e-2 rel-L2 of a run that moved them by > 5e-2."""
+    d, n, M = 1280, 2560, 512
+    diffs, params, _, orc, (W0, _) = _run_l1(d, n, M, "fp8", "adam", 4e-4, ["fp8", "bf16"], seed=23)
+    w8, w16 = _rel(params["decoder.weight"], orc["fp8"][0].numpy()), _rel(params["decoder.weight"], orc["bf16"][0].numpy())
+    moved = _rel(orc["bf16"][0].numpy(), O.normalize_columns(W0.clone()).numpy())
+    d8, d16 = diffs["fp8"], diffs["bf16"]
+    print(f"\nfp8 50 steps: vs fp8 oracle max rel diff recon {d8[:, 0].max():.2e} l1 {d8[:, 1].max():.2e} gnorm {d8[:, 2].max():.2e}, "
+          f"final W rel-L2 {w8:.2e}; vs bf16 oracle recon {d16[:, 0].max():.2e} l1 {d16[:, 1].max():.2e} gnorm {d16[:, 2].max():.2e}, "
+          f"final W rel-L2 {w16:.2e}; weights moved {moved:.2e}")
+    assert moved > 0.05
+    assert d8.max() < 1e-2 and w8 < 2e-3, (d8.max(0), w8)
+    assert d16[:, :2].max() < 3e-2 and w16 < 2e-2, (d16.max(0), w16)
+
+
+def _topk_case(d, n, k, B, T, seed):
+    """Rows that are sums of k dictionary atoms (the initial, unit-norm W_dec rows) with amplitudes 1.0 ... 0.7 (+-5 %) -- the k
+    wanted latents read ~3 a_j, every other latent only the cross-talk of k random directions (~3 sqrt(k / d)): the boundary between
+    the k-th and the (k+1)-th pre-activation is wide open and stays so while the dictionary trains."""
+    g = torch.Generator().manual_seed(seed)
+    We = torch.randn(n, d, generator=g) / d ** 0.5
+    Wd = We.clone()
+    Wd /= Wd.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps                 # topkautoencoder.py:66-68
+    P = {"encoder.weight": We, "encoder.bias": torch.zeros(n), "W_dec": Wd, "b_dec": torch.zeros(d)}
+    amps = torch.linspace(1.0, 0.7, k)
+    xs = []
+    for _ in range(NB):
+        M = B * T
+        idx = torch.stack([torch.randperm(n, generator=g)[:k] for _ in range(M)])
+        a = amps[None, :] * (1 + 0.05 * torch.randn(M, k, generator=g))
+        x = torch.einsum("mk,mkd->md", a, Wd[idx]) * 3.0
+        xs.append(x.reshape(B, T, d).to(torch.bfloat16).float())
+    return P, xs
+
+
+@pytest.mark.parametrize("d,n,k,B,T", [(384, 1024, 4, 2, 64), (768, 3072, 8, 2, 128)])
+def test_topk_fifty_step_trajectory_on_tie_free_batches(d, n, k, B, T):
+    from freud_amd.engine import SaeEngine
+    KEYS = ["encoder.weight", "encoder.bias", "W_dec", "b_dec"]
+    P, xs = _topk_case(d, n, k, B, T, 0)
+    P0 = {kk: v.clone() for kk, v in P.items()}
+    M = B * T
+    eng = SaeEngine(variant="topk", d_model=d, n_dict=n, max_rows=M, optimizer="adam", k=k, auxk_alpha=0.03125)
+    eng.set_topk_options(1e6, T)                             # configs/train/tiny_topk.json:13: no latent gets there in 50 x M frames
+    eng.set_params({kk: v.numpy() for kk, v in P.items()})
+    xd = [x.cuda() for x in xs]
+    st = O.OptState()
+    nfsf = torch.zeros(n, dtype=torch.int64)
+    worst, min_gap, set_mismatch = np.zeros(2), 1.0, 0
+    for i in range(STEPS):
+        x = xs[i % NB]
+        lr = O.lr_at(i, 1e-3, "linear", STEPS, 5)            # linear schedule with warm-up: the first step runs at lr = 0
+        eng.step(xd[i % NB], lr)
+        m = eng.metrics()
+        idx = np.sort(eng.debug_read(3, M * k).reshape(M, k).astype(np.int64), 1)
+        f = O.topk_forward(x, P["encoder.weight"], P["encoder.bias"], P["W_dec"], P["b_dec"], k, stable_ties=True)
+        srt = f["pre"].float().reshape(M, n).sort(dim=1, descending=True).values
+        min_gap = min(min_gap, float(((srt[:, k - 1] - srt[:, k]) / srt[:, k - 1]).min()))
+        out = O.topk_train_step(x, P, st, k=k, lr=lr, clip_thresh=1.0, optimizer="adam", stable_ties=True)
+        set_mismatch += int((idx != np.sort(out["top_indices"].reshape(M, k).numpy(), 1)).any(1).sum())
+        worst = np.maximum(worst, [abs(m[0] / out["fvu"].item() - 1), abs(m[3] / out["grad_norm"].item() - 1)])
+        fired = torch.zeros(n, dtype=torch.bool)
+        fired[out["fire_indices"].reshape(-1)] = True
+        nfsf += M                                            # train_sae.py:443-446
+        nfsf[fired] = 0
+    p = eng.get_params()
+    rels = {kk: _rel(p[kk], P[kk].numpy()) for kk in KEYS}
+    moved = _rel(P["encoder.weight"].numpy(), P0["encoder.weight"].numpy())
+    print(f"\nTopK d={d} n={n} k={k} 50 steps: min relative gap at the k-th place {min_gap:.3f}; rows with a differing index set "
+          f"{set_mismatch} of {STEPS * M}; max rel diff fvu {worst[0]:.2e} gnorm {worst[1]:.2e}; final rel-L2 "
+          + " ".join(f"{kk} {v:.2e}" for kk, v in rels.items()) + f"; encoder weights moved {moved:.2e}")
+    assert min_gap > 2.0 ** -6, "the construction did not keep the boundary open: not a tie-free trajectory"
+    assert set_mismatch == 0
+    assert worst[0] < 1e-2 and worst[1] < 1e-2, worst
+    assert moved > 0.02
+    assert rels["encoder.weight"] < 1e-3 and rels["W_dec"] < 1e-3, rels
+    assert rels["encoder.bias"] < 2e-2 and rels["b_dec"] < 2e-2, rels
+    assert np.array_equal(eng.get_topk_state(), nfsf.numpy())
+    eng.close()
