@@ -587,10 +587,10 @@ def main():
         if use_dist:
             # the exchange's own time per step, from HIP events on the stream it runs on (level-2 profile of n_diag extra steps after
             # the timed region; a peer-exchange kernel's time INCLUDES its wait for the slowest rank): max and min over the ranks
-            xs, xn = kt.get("dp_exchange", (0.0, 0))
+            ex_ms, xn = kt.get("dp_exchange", (0.0, 0))
             ss, sn = kt.get("dp_stats_exchange", (0.0, 0))
             compute = sum(v[0] for k, v in kt.items() if k not in ("dp_exchange", "dp_stats_exchange", "fwd_bwd_total"))
-            loc = torch.tensor([xs / n_diag, ss / n_diag, compute / n_diag], device=ctrl_dev, dtype=torch.float64)
+            loc = torch.tensor([ex_ms / n_diag, ss / n_diag, compute / n_diag], device=ctrl_dev, dtype=torch.float64)
             hi, lo = loc.clone(), loc.clone()
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -705,7 +705,20 @@ def main():
             r1, r2 = st[: 256 * 4], st[256 * 4:]
             print("fwd prologue / whole, first 256 workgroups: %.0f / %.0f | the others: %.0f / %.0f" %
                   (np.median(r1[:, 6]), np.median(r1[:, 7]), np.median(r2[:, 6]), np.median(r2[:, 7])), file=sys.stderr)
-        if os.environ.get("FREUD_FWD", "2") != "1":      # fwd_fused2.h keeps epilogue phase stamps in slots 0-2
+        if os.environ.get("FREUD_FF2_WAITSTAMP") == "1":      # -DFF2_WAITSTAMP builds: the hand-over of every iteration, per wave
+            it = st[:, 3:4]
+            wv = st[:, :3] / it
+            print("fwd hand-over per iteration (cycles, median over waves | p90 | max): own DMA + staging write waited for %.0f | %.0f | %.0f ; "
+                  "barrier (the other waves) %.0f | %.0f | %.0f ; barrier exit -> next hand-over %.0f | %.0f | %.0f" %
+                  (np.median(wv[:, 0]), np.percentile(wv[:, 0], 90), wv[:, 0].max(), np.median(wv[:, 1]), np.percentile(wv[:, 1], 90), wv[:, 1].max(),
+                   np.median(wv[:, 2]), np.percentile(wv[:, 2], 90), wv[:, 2].max()), file=sys.stderr)
+            byw = wv.reshape(-1, 4, 3)
+            print("  by wave 0..3 (median): DMA wait %s ; barrier %s" %
+                  (np.median(byw[:, :, 0], 0).round().tolist(), np.median(byw[:, :, 1], 0).round().tolist()), file=sys.stderr)
+            # the slowest wave gates the CU: per workgroup, the spread of the waves' arrival = max over waves of the barrier wait
+            print("  per workgroup: max over its waves of the barrier wait %.0f (median), min %.0f" %
+                  (np.median(byw[:, :, 1].max(1)), np.median(byw[:, :, 1].min(1))), file=sys.stderr)
+        elif os.environ.get("FREUD_FWD", "2") != "1":      # fwd_fused2.h keeps epilogue phase stamps in slots 0-2
             ep = st[:, 7] - st[:, 6] - st[:, 4]
             print("fwd epilogue phases (median cycles): last half iteration + latent drain %.0f | x staged %.0f | residual arithmetic %.0f | "
                   "dx_hat publication + stores + sums %.0f" % (np.median(st[:, 0]), np.median(st[:, 1]), np.median(st[:, 2]),

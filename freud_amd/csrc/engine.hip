@@ -32,6 +32,7 @@ static thread_local int g_device = 0;  // device of the context the current call
 #include "topk_kernels.h"
 #include "topk_sparse.h"
 #include "topk_aux.h"
+#include "eval_fp32.h"
 
 #ifndef G2_PERSIST_STATIC
 #define G2_PERSIST_STATIC 512      // resident workgroups of the big static 256x256 GEMM launches (0: one workgroup per tile)
@@ -263,6 +264,13 @@ struct sae_ctx {
   short* bal_map = nullptr;
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
+  // fp32 evaluation forward (eval_fp32.h; sae_set_eval_precision): buffers sized lazily for the largest evaluation batch seen
+  int eval_prec = 0;            // 0 = the training kernels' arithmetic (bf16 operands, fp32 accumulate), 1 = fp32 end to end
+  bool last_fwd_e32 = false;    // the last forward was an fp32 evaluation: its per-feature maxima live in e32_colmax
+  int64_t e32_rows = 0;
+  float *e32_x = nullptr, *e32_pre = nullptr, *e32_sel = nullptr, *e32_xhat = nullptr;
+  double* e32_part = nullptr;
+  int* e32_colmax = nullptr;
   int64_t step = 0;
   int64_t last_M = 0, last_M_p = 0;
   int last_dtype = 0;
@@ -514,6 +522,8 @@ extern "C" void sae_destroy(sae_ctx* c) {
   if (c->p2p_status_host) (void)hipHostFree(c->p2p_status_host);
   if (c->col_stage) (void)hipFree(c->col_stage);
   if (c->bal_map) (void)hipFree(c->bal_map);
+  for (void* p : {(void*)c->e32_x, (void*)c->e32_pre, (void*)c->e32_sel, (void*)c->e32_xhat, (void*)c->e32_part, (void*)c->e32_colmax})
+    if (p) (void)hipFree(p);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : {c->ev_x, c->ev_stats, c->ev_done})
@@ -1597,17 +1607,10 @@ static int launch_gemm8(const Gemm8Args& g, const Epi& epi, hipStream_t s) {
   return SAE_OK;
 }
 
-template <typename T> static constexpr bool x_dtype_is_bf16() { return false; }
-template <> constexpr bool x_dtype_is_bf16<bf16_t>() { return true; }
-
-template <typename T>
-static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream_t s, bool need_backward) {
-  const int d = c->d, d_p = c->d_p, n_p = c->n_p;
-  const float alpha = (float)c->cfg.recon_alpha;
+// The in-place column normalisation every L1 forward starts with (l1autoencoder.py:71-73), and the bf16 copies of the result.
+static void prep_weights_l1(sae_ctx* c, hipStream_t s) {
+  const int d_p = c->d_p, n_p = c->n_p;
   float* W = c->P;
-  float* b = c->P + c->nW;
-
-  ev_begin(c, KID_PREP_W, s);
   if (c->wn_pending && !c->wn_fwd_seen) {
     // the update of the last training step already wrote Wb / Wt for the normalised weights (optimizer_l1_cols_kernel): this
     // forward IS the reference's in-place normalisation -- no kernel
@@ -1620,6 +1623,20 @@ static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream
     hipLaunchKernelGGL(normalize_cast_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->cn_part, d_p / 32, c->Wb,
                        c->Wt, d_p, n_p);
   }
+}
+
+template <typename T> static constexpr bool x_dtype_is_bf16() { return false; }
+template <> constexpr bool x_dtype_is_bf16<bf16_t>() { return true; }
+
+template <typename T>
+static int forward_impl(sae_ctx* c, const T* x, int64_t M, int64_t Mp, hipStream_t s, bool need_backward) {
+  const int d = c->d, d_p = c->d_p, n_p = c->n_p;
+  const float alpha = (float)c->cfg.recon_alpha;
+  float* W = c->P;
+  float* b = c->P + c->nW;
+
+  ev_begin(c, KID_PREP_W, s);
+  prep_weights_l1(c, s);
   if (c->fp8) hipLaunchKernelGGL(fp8_cast_w_kernel, dim3(n_p / 64, d_p / 64), dim3(256), 0, s, W, c->W8, c->W8t, d_p, n_p);
   ev_end(c, KID_PREP_W, s);
 
@@ -2504,6 +2521,7 @@ static int dispatch_fwd_bwd(sae_ctx* c, const void* x, int64_t M, int x_dtype, v
 
 static int dispatch_fwd_bwd_inner(sae_ctx* c, const void* x, int64_t M, int x_dtype, hipStream_t s, bool backward) {
   c->last_dtype = x_dtype;
+  c->last_fwd_e32 = false;
   if (c->topk) {
     switch (x_dtype) {
       case SAE_DTYPE_F32: return topk_fwd_bwd<float>(c, (const float*)x, M, s, backward);
@@ -2520,10 +2538,116 @@ static int dispatch_fwd_bwd_inner(sae_ctx* c, const void* x, int64_t M, int x_dt
   }
 }
 
+// ---- fp32 evaluation forward (eval_fp32.h): validate() of the reference on device='cpu' runs without autocast
+static int e32_ensure(sae_ctx* c, int64_t M) {
+  if (c->e32_rows >= M && c->e32_x) return SAE_OK;
+  for (void** p : {(void**)&c->e32_x, (void**)&c->e32_pre, (void**)&c->e32_sel, (void**)&c->e32_xhat}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  c->e32_rows = 0;
+  const int64_t rows = M;
+  HIP_TRY(hipMalloc((void**)&c->e32_x, (size_t)rows * c->d_p * 4));
+  HIP_TRY(hipMalloc((void**)&c->e32_pre, (size_t)rows * c->n_p * 4));
+  if (c->topk) HIP_TRY(hipMalloc((void**)&c->e32_sel, (size_t)rows * c->n_p * 4));
+  HIP_TRY(hipMalloc((void**)&c->e32_xhat, (size_t)rows * c->d_p * 4));
+  if (!c->e32_part) HIP_TRY(hipMalloc((void**)&c->e32_part, (size_t)E32_PART_DOUBLES * 8));
+  if (!c->e32_colmax) HIP_TRY(hipMalloc((void**)&c->e32_colmax, (size_t)c->n_p * 4));
+  c->e32_rows = rows;
+  return SAE_OK;
+}
+
+template <bool BT>
+static void e32_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(e32_gemm_kernel<BT>, dim3((N + E32_BN - 1) / E32_BN, (unsigned)((M + E32_BM - 1) / E32_BM)), dim3(256), 0, s, A, lda, B, ldb,
+                     C, ldc, (int)M, N, K);
+}
+
+template <typename T>
+static int eval_fp32_impl(sae_ctx* c, const T* x, int64_t M, hipStream_t s) {
+  const int d = c->d, n = c->n, d_p = c->d_p, n_p = c->n_p;
+  int rc = e32_ensure(c, M);
+  if (rc) return rc;
+  // partial-sum layout of e32_part (doubles): [0, E32_L1_PARTS) latent sums | 4 x E32_RES_BLOCKS residual sums | ... multi-TopK residual | total variance
+  double *l1_part = c->e32_part, *res_part = c->e32_part + E32_L1_PARTS, *res2_part = res_part + 4 * E32_RES_BLOCKS, *tv_part = res2_part + 4 * E32_RES_BLOCKS;
+  int grid_x = (int)((M * d_p + 255) / 256);
+  if (grid_x > 2048) grid_x = 2048;
+  HIP_TRY(hipMemsetAsync(c->e32_colmax, 0, (size_t)n_p * 4, s));
+  E32Final f{};
+  f.M = M; f.d = d; f.alpha = (float)c->cfg.recon_alpha; f.topk = c->topk ? 1 : 0;
+  if (!c->topk) {
+    // W <- W / max(||W[:, j]||, 1e-12) in place first, as every forward of the reference does (l1autoencoder.py:71-73); the fp32
+    // master then holds exactly the weights this forward multiplies by
+    prep_weights_l1(c, s);
+    settle_weights(c, s);
+    const float *W = c->P, *b = c->P + c->nW;
+    hipLaunchKernelGGL(e32_load_x_kernel<T>, dim3(grid_x), dim3(256), 0, s, x, c->e32_x, (const float*)nullptr, M, d, d_p);
+    e32_gemm<false>(c->e32_x, d_p, W, n_p, c->e32_pre, n_p, M, n_p, d_p, s);                       // x W: W is [d_p][n_p]
+    const dim3 gb((n_p + 255) / 256, (unsigned)((M + 63) / 64));
+    if ((int64_t)gb.x * gb.y > E32_L1_PARTS) return fail(SAE_ERR_INVALID, "fp32 evaluation: %lld rows x %d latents exceed its partial-sum buffer", (long long)M, n_p);
+    hipLaunchKernelGGL(e32_bias_relu_kernel, gb, dim3(256), 0, s, c->e32_pre, b, M, n, n_p, l1_part, c->e32_colmax);
+    e32_gemm<true>(c->e32_pre, n_p, W, n_p, c->e32_xhat, d_p, M, d_p, n_p, s);                     // c W^T: W as [N = d_p][K = n_p]
+    hipLaunchKernelGGL(e32_residual_kernel<T>, dim3(E32_RES_BLOCKS), dim3(256), 0, s, c->e32_xhat, d_p, (const float*)nullptr, x, M, d, res_part);
+    f.l1_part = l1_part; f.n_l1 = (int)(gb.x * gb.y);
+    f.res_part = res_part; f.n_res = E32_RES_BLOCKS;
+  } else {
+    const float *We = c->P, *be = c->P + c->nW, *Wd = c->P + c->nW + c->n_p, *bd = c->P + 2 * c->nW + c->n_p;
+    hipLaunchKernelGGL(e32_load_x_kernel<T>, dim3(grid_x), dim3(256), 0, s, x, c->e32_x, bd, M, d, d_p);          // sae_in = x - b_dec
+    e32_gemm<true>(c->e32_x, d_p, We, d_p, c->e32_pre, n_p, M, n_p, d_p, s);                       // sae_in W_enc^T: W_enc is [n_p][d_p]
+    const dim3 gb((n_p + 255) / 256, (unsigned)((M + 63) / 64));
+    if ((int64_t)gb.x * gb.y > E32_L1_PARTS) return fail(SAE_ERR_INVALID, "fp32 evaluation: %lld rows x %d latents exceed its partial-sum buffer", (long long)M, n_p);
+    hipLaunchKernelGGL(e32_bias_relu_kernel, gb, dim3(256), 0, s, c->e32_pre, be, M, n, n_p, l1_part, (int*)nullptr);
+    const int64_t T_rows = c->rows_per_file > 0 && M % c->rows_per_file == 0 ? c->rows_per_file : M;
+    hipLaunchKernelGGL(e32_total_variance_kernel<T>, dim3(E32_RES_BLOCKS), dim3(256), 0, s, x, M / T_rows, T_rows * d, tv_part);
+    f.tv_part = tv_part; f.n_tv = E32_RES_BLOCKS;
+    hipLaunchKernelGGL(e32_topk_select_kernel, dim3((unsigned)M), dim3(256), 0, s, c->e32_pre, c->e32_sel, n, n_p, c->k, (int*)nullptr);
+    e32_gemm<false>(c->e32_sel, n_p, Wd, d_p, c->e32_xhat, d_p, M, d_p, n_p, s);                   // dense W_dec: W_dec is [n_p][d_p]
+    hipLaunchKernelGGL(e32_residual_kernel<T>, dim3(E32_RES_BLOCKS), dim3(256), 0, s, c->e32_xhat, d_p, bd, x, M, d, res_part);
+    f.res_part = res_part; f.n_res = E32_RES_BLOCKS;
+    if (c->multi) {              // cfg.multi_topk: the returned encoding is the 4k one (topkautoencoder.py:134-136)
+      hipLaunchKernelGGL(e32_topk_select_kernel, dim3((unsigned)M), dim3(256), 0, s, c->e32_pre, c->e32_sel, n, n_p, c->k4, (int*)nullptr);
+      e32_gemm<false>(c->e32_sel, n_p, Wd, d_p, c->e32_xhat, d_p, M, d_p, n_p, s);
+      hipLaunchKernelGGL(e32_residual_kernel<T>, dim3(E32_RES_BLOCKS), dim3(256), 0, s, c->e32_xhat, d_p, bd, x, M, d, res2_part);
+      f.res2_part = res2_part; f.n_res2 = E32_RES_BLOCKS;
+    }
+    hipLaunchKernelGGL(e32_colmax_kernel, dim3((n + 255) / 256, (unsigned)((M + 63) / 64)), dim3(256), 0, s, c->e32_sel, M, n, n_p, c->e32_colmax);
+  }
+  hipLaunchKernelGGL(e32_finalize_kernel, dim3(1), dim3(256), 0, s, f, c->G + c->nparams);
+  HIP_TRY(hipGetLastError());
+  c->last_M = M;
+  c->last_M_p = round_up(M, c->row_pad);
+  c->last_fwd_e32 = true;
+  c->metrics_fresh = false;
+  return SAE_OK;
+}
+
+static int eval_fp32_dispatch(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
+  if (!c || !x) return fail(SAE_ERR_INVALID, "null argument");
+  if (M <= 0) return fail(SAE_ERR_INVALID, "M=%lld must be positive", (long long)M);
+  USE_DEVICE(c);
+  hipStream_t s = (hipStream_t)stream;
+  c->last_dtype = x_dtype;
+  switch (x_dtype) {
+    case SAE_DTYPE_F32: return eval_fp32_impl<float>(c, (const float*)x, M, s);
+    case SAE_DTYPE_F16: return eval_fp32_impl<_Float16>(c, (const _Float16*)x, M, s);
+    case SAE_DTYPE_BF16: return eval_fp32_impl<bf16_t>(c, (const bf16_t*)x, M, s);
+    default: return fail(SAE_ERR_INVALID, "unknown x_dtype %d", x_dtype);
+  }
+}
+
+extern "C" int sae_set_eval_precision(sae_ctx* c, int precision) {
+  if (!c) return fail(SAE_ERR_INVALID, "null argument");
+  if (precision != SAE_PREC_BF16 && precision != SAE_PREC_FP32)
+    return fail(SAE_ERR_INVALID, "Invalid evaluation precision: %d, must be SAE_PREC_BF16 (the training kernels) or SAE_PREC_FP32", precision);
+  c->eval_prec = precision == SAE_PREC_FP32 ? 1 : 0;
+  return SAE_OK;
+}
+
 extern "C" int sae_forward_backward(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
   return dispatch_fwd_bwd(c, x, M, x_dtype, stream, true);
 }
 extern "C" int sae_eval(sae_ctx* c, const void* x, int64_t M, int x_dtype, void* stream) {
+  if (c && c->eval_prec == 1) return eval_fp32_dispatch(c, x, M, x_dtype, stream);
   return dispatch_fwd_bwd(c, x, M, x_dtype, stream, false);
 }
 
@@ -2762,6 +2886,7 @@ extern "C" int sae_latent_buffer(sae_ctx* c, void** dev_ptr, int64_t* row_stride
   if (!c || !dev_ptr || !row_stride) return fail(SAE_ERR_INVALID, "null argument");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
   USE_DEVICE(c);
+  if (c->last_fwd_e32) return fail(SAE_ERR_STATE, "the last forward was an fp32 evaluation: it leaves no bf16 latent rows");
   {
     int rc_d = ensure_dense(c);
     if (rc_d) return rc_d;
@@ -2854,6 +2979,11 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
   if (capacity < c->n) return fail(SAE_ERR_INVALID, "capacity too small");
   if (c->last_M <= 0) return fail(SAE_ERR_STATE, "no forward has run yet");
   USE_DEVICE(c);
+  if (c->last_fwd_e32) {
+    HIP_TRY(hipMemcpyAsync(out_host, c->e32_colmax, (size_t)c->n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SAE_OK;
+  }
   {
     int rc_d = ensure_dense(c);
     if (rc_d) return rc_d;
@@ -2879,10 +3009,14 @@ extern "C" int sae_latent_colmax(sae_ctx* c, float* out_host, int64_t capacity, 
 // host reads all rows once at the end.  Everything is asynchronous on `stream`.
 extern "C" int sae_eval_into(sae_ctx* c, const void* x, int64_t M, int x_dtype, float* metrics_out, float* colmax_out, void* stream) {
   if (!c || !x || !metrics_out) return fail(SAE_ERR_INVALID, "null argument");
-  int rc = dispatch_fwd_bwd(c, x, M, x_dtype, stream, false);
+  int rc = c->eval_prec == 1 ? eval_fp32_dispatch(c, x, M, x_dtype, stream) : dispatch_fwd_bwd(c, x, M, x_dtype, stream, false);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(metrics_out, c->G + c->nparams, SAE_NUM_METRICS * 4, hipMemcpyDeviceToDevice, s));
+  if (colmax_out && c->last_fwd_e32) {      // the fp32 forward left the per-feature maxima (bit patterns of non-negative floats)
+    HIP_TRY(hipMemcpyAsync(colmax_out, c->e32_colmax, (size_t)c->n * 4, hipMemcpyDeviceToDevice, s));
+    return SAE_OK;
+  }
   if (colmax_out) {
     if (c->topk && !c->dense_valid) return fail(SAE_ERR_STATE, "the evaluation forward did not leave the dense latent rows");
     HIP_TRY(hipMemsetAsync(colmax_out, 0, (size_t)c->n * 4, s));

@@ -265,6 +265,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #pragma unroll
   for (int k = 0; k < 3; ++k) ring[k] = enc_frag(1, k);
 
+#ifdef FF2_WAITSTAMP
+  unsigned long long ws_vm = 0, ws_bar = 0, ws_gap = 0, ws_prev = 0;
+#endif
   u32x4 dr[2];
   bf16_t* const dummy_line = a.c + (int64_t)a.c_rows * a.n_p + lane * 8;
   auto body = [&](auto ph_tag, int j) {
@@ -291,10 +294,12 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     // (FF2_PACKED: static_for -- the slot index as a template constant: `#pragma unroll` gives up silently above LLVM's size
     // threshold, and with the packed form's few added lines the loop stayed rolled and indexed every register array dynamically,
     // 1.8 KB of scratch per lane.  The shipped element-wise form keeps round 4's pragma loop: bit-identical code.)
-#if FF2_PACKED
+#if FF2_PACKED || defined(FF2_WAITSTAMP)
+#define FF2_STATIC_LOOP 1
     static_for<0, 48>([&](auto slot_tag) {
       constexpr int i = decltype(slot_tag)::value;
 #else
+#define FF2_STATIC_LOOP 0
 #pragma unroll
     for (int i = 0; i < 48; ++i) {
 #endif
@@ -312,8 +317,24 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         // <= 1 VMEM operation outstanding (this iteration's first latent store): the six DMA pieces of tile j+2 are done;
         // <= 2 LDS operations outstanding (four fragment reads follow the staging write of gap 34): that write is done
         __builtin_amdgcn_sched_barrier(0);
+#ifdef FF2_WAITSTAMP
+        // diagnostic build (bench.py --dbg 65 with FREUD_FF2_WAITSTAMP=1): what the iteration's single hand-over
+        // costs THIS wave -- w0..w1: its own LDS-DMA pieces of tile j+2 and its staging write (the counted wait), w1..w2: the other
+        // three waves (the barrier).  s_memtime is a scalar-memory read: each stamp drains lgkmcnt, so the build is ~10 % slower
+        // and the split, not the total, is what it is for.
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long w2 = __builtin_amdgcn_s_memtime();
+        ws_vm += w1 - w0; ws_bar += w2 - w1;
+        if (ws_prev != 0) ws_gap += w0 - ws_prev;      // barrier exit of iteration j-1 -> arrival at this hand-over
+        ws_prev = w2;
+#else
         asm volatile("s_waitcnt vmcnt(1) lgkmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (i == 41 || i == 43 || i == 45) dma_pair((i - 41) / 2, jt, SLOT_DMA);
@@ -386,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         Snxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[(i / 2) % RING], xfrag[i / 2], Snxt, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-#if FF2_PACKED
+#if FF2_STATIC_LOOP
     });
 #else
     }
@@ -758,6 +779,9 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     // epilogue phases (bench.py --dbg 65): [0] loop end -> final half iteration + latent drain, [1] x staging, [2] residual arithmetic;
     // what is left of the epilogue = dx_hat publication + stores + sums: whole - prologue - loop - [0] - [1] - [2]
     o[0] = clk_e0 - clk_t1; o[1] = clk_e1 - clk_e0; o[2] = clk_e2 - clk_e1;
+#ifdef FF2_WAITSTAMP
+    o[0] = ws_vm; o[1] = ws_bar; o[2] = ws_gap;      // sums over the tile loop (bench.py divides by the iterations)
+#endif
   }
   if (t == 0) {
     a.cnt_part[wg] = nms;

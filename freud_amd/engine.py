@@ -109,6 +109,7 @@ def load() -> C.CDLL:
         "sae_step": (C.c_int, [vp, vp, i64, C.c_int, dbl, vp]),
         "sae_eval": (C.c_int, [vp, vp, i64, C.c_int, vp]),
         "sae_eval_into": (C.c_int, [vp, vp, i64, C.c_int, vp, vp, vp]),
+        "sae_set_eval_precision": (C.c_int, [vp, C.c_int]),
         "sae_latent_buffer": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64)]),
         "sae_topk_indices": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
         "sae_decode": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp]),
@@ -150,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "sae_dist_init", "sae_dist_world", "sae_dist_set_payload", "sae_p2p_blob_bytes", "sae_p2p_export", "sae_p2p_init", "sae_p2p_leave",
     "sae_dist_set_overlap", "sae_dist_check", "sae_dist_poll", "sae_dist_audit", "sae_grad_layout", "sae_param_checksum", "sae_set_topk_options", "sae_get_topk_state", "sae_set_topk_state",
     "sae_latent_buffer", "sae_topk_indices", "sae_decode", "sae_multi_topk_buffers",
-    "sae_step", "sae_eval", "sae_eval_into", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
+    "sae_step", "sae_eval", "sae_eval_into", "sae_set_eval_precision", "sae_read_metrics", "sae_latent_colmax", "sae_debug_read", "sae_profile", "sae_profile_period", "sae_kernel_times",
     "sae_kernel_name", "sae_dominant_kernel",
 ]
 
@@ -414,6 +415,14 @@ class SaeEngine:
         self._note_shape(x)
         x, ptr, rows, dt = self._x_args(x)
         _check(self._lib.sae_eval(self._ctx, C.c_void_p(ptr), rows, dt, self._stream(stream)))
+
+    def set_eval_precision(self, precision: str) -> None:
+        """"bf16" (default): eval() / eval_into() run the training kernels' arithmetic (CPU autocast's).  "fp32": fp32 end to end --
+        what the reference's validate() computes on device='cpu' (train_sae.py:162-166) and selects bestval.pth by."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"Invalid evaluation precision: {precision}, must be 'bf16' or 'fp32'")
+        _check(self._lib.sae_set_eval_precision(self._ctx, 3 if precision == "fp32" else PRECISION["bf16"]))
+        self.eval_precision = precision
 
     def eval_into(self, x, metrics_row, colmax_row=None, stream=None) -> None:
         """eval() of one file with its 8 loss scalars (and per-feature latent maxima) left in the given fp32 CUDA rows:

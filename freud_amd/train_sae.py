@@ -277,9 +277,15 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
           steps: int, clip_thresh: float, batch_size: int, dl_max_workers: int, log_tb_every: int, save_every: int,
           val_every: int, start_checkpoint: Optional[str], whisper_config: dict, optimizer: str, scheduler: str,
           scheduler_params: dict, from_disk: bool, autoencoder_variant: str, autoencoder_config: dict, *,
-          engine_factory: Optional[Callable] = None, dist_backend: Optional[str] = None):
-    """Same keyword arguments as the reference's train() (train_sae.py:297-320); the two trailing
+          eval_precision: Optional[str] = None, engine_factory: Optional[Callable] = None, dist_backend: Optional[str] = None):
+    """Same keyword arguments as the reference's train() (train_sae.py:297-320).  One OPTIONAL key beyond them: "eval_precision":
+    "fp32" makes validate() -- and with it the choice of bestval.pth -- compute what the reference's validate() computes on
+    device='cpu' (no autocast: fp32 end to end, train_sae.py:162-166); "bf16" (default; also FREUD_EVAL_PRECISION) keeps the training
+    kernels' arithmetic, which agrees with that to ~1e-2.  A config file without the key is a reference config file.  The two trailing
     keyword-only arguments are test hooks and are never present in a config file."""
+    eval_precision = eval_precision or os.environ.get("FREUD_EVAL_PRECISION") or "bf16"
+    if eval_precision not in ("bf16", "fp32"):
+        raise ValueError(f"Invalid eval_precision: {eval_precision}, must be 'bf16' or 'fp32'")
     device = torch.device(device)
     rank, local_rank, world = _dist_env()
     # FREUD_FORCE_DIST=1 (test hook, like bench.py --force-dist): take the data-parallel code path - process group,
@@ -375,6 +381,10 @@ def train(seed: int, train_folder: str, val_folder: str, device, run_dir: str, l
         state_dict_order = ["W_dec", "b_dec", "encoder.weight", "encoder.bias"]
         eng.set_topk_options(float(autoencoder_config["dead_feature_threshold"]), T)   # raw key (:438); T for x.mean(0)
     eng.set_params(init)
+    if eval_precision == "fp32":
+        if not hasattr(eng, "set_eval_precision"):
+            raise RuntimeError("eval_precision='fp32' needs the HIP engine (sae_set_eval_precision)")
+        eng.set_eval_precision("fp32")
 
     is_main = rank == 0
     checkpoint_out_dir = run_dir + "/checkpoints"

@@ -91,7 +91,8 @@ typedef struct sae_config {
  *                operands -- dx_hat quantised per tensor with a power-of-two scale from its own maximum, W as above; the
  *                weight-gradient GEMMs stay bf16.  Beyond BASELINE configs[4] ("fp8 enc/dec"); an option with a stated cost:
  *                raw gradients within 5e-2 (rel-Frobenius) of the bf16 arithmetic (tests/test_fp8_gpu.py). */
-enum { SAE_PREC_BF16 = 0, SAE_PREC_FP8 = 1, SAE_PREC_FP8_BWD = 2 };
+enum { SAE_PREC_BF16 = 0, SAE_PREC_FP8 = 1, SAE_PREC_FP8_BWD = 2,
+       SAE_PREC_FP32 = 3 /* evaluation only: sae_set_eval_precision */ };
 
 /* Metrics of the most recent sae_forward_backward / sae_eval (all fp32). */
 enum {
@@ -284,6 +285,15 @@ int sae_multi_topk_buffers(sae_ctx* ctx, void** dense_dev, int64_t* row_stride, 
  * maxima of |latent| (train_sae.py:176-178) to colmax_out_dev[n_dict]; both are CALLER-OWNED device rows (one pair per
  * file), so a whole validation folder is enqueued without a single synchronisation and read back once.  Asynchronous. */
 int sae_eval_into(sae_ctx* ctx, const void* x_dev, int64_t M, int x_dtype, float* metrics_out_dev, float* colmax_out_dev, void* stream);
+
+/* Arithmetic of sae_eval / sae_eval_into.  SAE_PREC_BF16 (default): the training kernels' -- bf16 operands, fp32 accumulation, i.e.
+ * CPU autocast's.  SAE_PREC_FP32: fp32 end to end, which is what the reference's validate() computes on device='cpu'
+ * (train_sae.py:162-166: nullcontext() instead of autocast; L1AutoEncoder.forward l1autoencoder.py:69-95, TopKAutoEncoder.forward
+ * topkautoencoder.py:93-151 without a dead mask) and what its bestval.pth selection (train_sae.py:585-595) rests on: fp32 matrix
+ * instructions, fp32 bias / ReLU / top-k (ties: lowest column first), loss sums in double.  The in-place column normalisation of
+ * the L1 weights happens first, exactly as in every other forward.  Training steps are not affected.  Any SAE_PREC_* other than
+ * these two: SAE_ERR_INVALID. */
+int sae_set_eval_precision(sae_ctx* ctx, int precision);
 
 /* Copy the SAE_NUM_METRICS scalars to host.  Synchronises `stream`. */
 int sae_read_metrics(sae_ctx* ctx, float out_host[SAE_NUM_METRICS], void* stream);
