@@ -390,9 +390,9 @@ def main():
     total_steps, base_lr = 100000, 4e-4
 
     def attempt(mode_override=None):
-        # (reads `use_dist` of the enclosing scope at call time: the plain reference pass of an N > 1 run switches it off)
         """engine + data-parallel set-up + spin-up + warm-up + the timed region.  Returns (engine, step function, seconds of the
-        timed region, exchange in force, healthy)."""
+        timed region, exchange in force, healthy).  (Reads `use_dist` of the enclosing scope at call time: the plain reference pass
+        of an N > 1 run switches it off.)"""
         grads, works = None, []
         args.dp_host = args.dp_host_flag or mode_override == "host"
         if args.variant == "topk":
@@ -579,9 +579,15 @@ def main():
     if args.breakdown or args.precision != "bf16" or use_dist:   # every rank runs the extra steps (they contain collectives); rank 0 reports
         n_diag = 16 if use_dist else 10
         eng.profile(2)
+        # harvested every second step: the engine keeps the last 64 event pairs per kernel id, and a configuration with several
+        # exchange launches per step (--dp-overlap > 4, the chunked exchanges of the d >= 1024 paths) would overflow that ring
+        # over 16 steps and under-report the exchange
+        kt = {}
         for i in range(n_diag):
             one_step(args.warmup + args.steps + i)
-        kt = eng.kernel_times()
+            if i % 2 == 1 or i == n_diag - 1:
+                for k, v in eng.kernel_times().items():
+                    kt[k] = (kt.get(k, (0.0, 0))[0] + v[0], kt.get(k, (0.0, 0))[1] + v[1])
         breakdown = {k: round(v[0] / max(v[1], 1), 4) for k, v in kt.items()}
         eng.profile(0)
         if use_dist:

@@ -23,8 +23,9 @@
 #include <mutex>
 #include <unistd.h>
 
-static bool g_force_gemm128 = false;   // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
-static bool g_no_stream = false;       // FREUD_GEMM_STREAM=0 / debug_flags 86: the K = d GEMMs in gemm256.h's tile form (A/B timing, tests)
+static thread_local bool g_force_gemm128 = false;   // (the CURRENT call's context: set by use_device, like g_device -- ADVICE r5)
+                                                    // sae_config.force_gemm128: keep every GEMM on the 128x128 kernel (A/B timing, tests)
+static thread_local bool g_no_stream = false;       // FREUD_GEMM_STREAM=0 / debug_flags 86: the K = d GEMMs in gemm256.h's tile form (A/B timing, tests)
 static thread_local int g_device = 0;  // device of the context the current call works on (set by use_device)
 #include "bwd_fused.h"
 #include "fwd_fused.h"
@@ -265,6 +266,7 @@ struct sae_ctx {
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
   // fp32 evaluation forward (eval_fp32.h; sae_set_eval_precision): buffers sized lazily for the largest evaluation batch seen
+  bool no_stream = false;       // this context's K = d GEMMs stay on the tile form (FREUD_GEMM_STREAM=0 / debug_flags 86 at ITS creation)
   int eval_prec = 0;            // 0 = the training kernels' arithmetic (bf16 operands, fp32 accumulate), 1 = fp32 end to end
   bool last_fwd_e32 = false;    // the last forward was an fp32 evaluation: its per-feature maxima live in e32_colmax
   int64_t e32_rows = 0;
@@ -287,6 +289,8 @@ static bool inline_stats(const sae_ctx* c) { return c->p2p && c->use_fused_fwd &
 static int use_device(const sae_ctx* c) {
   HIP_TRY(hipSetDevice(c->cfg.device_id));
   g_device = c->cfg.device_id;
+  g_force_gemm128 = c->cfg.force_gemm128 == 1;      // per-context launch choices travel with the call, not with the last sae_create
+  g_no_stream = c->no_stream;
   return SAE_OK;
 }
 #define USE_DEVICE(c)          \
@@ -390,7 +394,7 @@ static int topk_create(sae_ctx* c, int64_t Mp) {
   c->nparams = 2 * c->nW + c->n_p + c->d_p;
   const int64_t ntail = SAE_NUM_METRICS + c->n_p;       // metrics + did_fire flags ride in the all-reduced buffer
   g_force_gemm128 = c->cfg.force_gemm128 == 1;
-  g_no_stream = c->cfg.debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
+  c->no_stream = g_no_stream = c->cfg.debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
   const int splits = choose_splits(c->n_p / 128, c->d_p / 128, Mp / 64);
   c->dw_splits = splits;
 #define TALLOC(ptr, bytes)                                                                                   \
@@ -596,7 +600,7 @@ extern "C" int sae_create(const sae_config* cfg, sae_ctx** out) {
     return SAE_OK;
   }
   g_force_gemm128 = cfg->force_gemm128 == 1;
-  g_no_stream = cfg->debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
+  c->no_stream = g_no_stream = cfg->debug_flags == 86 || (getenv("FREUD_GEMM_STREAM") && atoi(getenv("FREUD_GEMM_STREAM")) == 0);
   c->dw_splits = choose_splits(c->d_p / 128, c->n_p / 128, 2 * Mp / 64);
   if (const char* ov = getenv("FREUD_DW_SPLITS")) {       // timing sweeps of the split-K factor of the weight-gradient GEMM
     const int v = atoi(ov);

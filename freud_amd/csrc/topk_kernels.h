@@ -470,7 +470,7 @@ constexpr int VEC_BITS_T_BYTES = 256 * 16;
 #define SEL_OCC 3        // waves per SIMD the compact AuxK select is compiled for
 #endif
 template <int MAXV, bool COMPACT = false>
-__global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void topk_select_reg_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ dense,
+__global__ __launch_bounds__(256, (COMPACT && MAXV <= 12) ? SEL_OCC : 1) void topk_select_reg_kernel(const bf16_t* pre, bf16_t* dense,      // (NOT restrict: the copy + select form of the compact AuxK selection runs in place, pre == dense)
                                                                int* __restrict__ top_idx, float* __restrict__ did_fire,
                                                                const unsigned char* __restrict__ dead,
                                                                const int* __restrict__ k_ptr, int k_fixed, int kcap, int n,

@@ -355,10 +355,13 @@ class MemoryMappedActivationDataLoader:
                 ready.put(e)
 
         th = threading.Thread(target=worker, name="shard-gather", daemon=True)
-        th.start()
-        copy_stream = torch.cuda.Stream(device=dev)
+        copy_stream = None
         consumed = [None] * depth   # compute-stream event: batch in hbm[slot] fully enqueued
         try:
+            # (inside the try: a failure to start the thread or to create the stream must still give the shared ring back -- with the
+            # flag stuck every later epoch pinned a fresh ring)
+            th.start()
+            copy_stream = torch.cuda.Stream(device=dev)
             while True:
                 item = ready.get()
                 if item is None:
@@ -385,9 +388,11 @@ class MemoryMappedActivationDataLoader:
                 consumed[slot] = ev
         finally:
             stop.set()
-            th.join(timeout=60)         # (the worker looks at `stop` between batches; a gather stalls at worst for one batch's page faults)
+            if th.ident is not None:
+                th.join(timeout=60)     # (the worker looks at `stop` between batches; a gather stalls at worst for one batch's page faults)
             torch.cuda.current_stream(dev).synchronize()     # the ring is reused by the next epoch: nothing of this one is in flight
-            copy_stream.synchronize()
+            if copy_stream is not None:
+                copy_stream.synchronize()
             if shared:
                 if th.is_alive():       # a straggler may still write into pinned[slot]: the ring is abandoned to it, the next epoch
                     self._ring_key = None   # allocates a fresh one (round 4 ignored the join result: silent batch corruption)
