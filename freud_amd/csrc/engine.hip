@@ -266,6 +266,7 @@ struct sae_ctx {
   int bwd_ranges = 1;           // fused d = 384 backward: column-tile ranges launched one after the other, each range reduced and
                                 // exchanged on the communication stream under the next range's backward (sae_dist_set_overlap)
   // fp32 evaluation forward (eval_fp32.h; sae_set_eval_precision): buffers sized lazily for the largest evaluation batch seen
+  bool stats_inline = true;     // fused d = 384 L1 path with the peer exchange: statistics pushed inside finalize_losses_kernel (see inline_stats)
   bool no_stream = false;       // this context's K = d GEMMs stay on the tile form (FREUD_GEMM_STREAM=0 / debug_flags 86 at ITS creation)
   int eval_prec = 0;            // 0 = the training kernels' arithmetic (bf16 operands, fp32 accumulate), 1 = fp32 end to end
   bool last_fwd_e32 = false;    // the last forward was an fp32 evaluation: its per-feature maxima live in e32_colmax
@@ -284,7 +285,10 @@ struct sae_ctx {
 };
 
 // fused d = 384 L1 path with the peer exchange: the batch statistics are exchanged inside finalize_losses_kernel (StatsPush)
-static bool inline_stats(const sae_ctx* c) { return c->p2p && c->use_fused_fwd && !c->topk; }
+// (FREUD_DP_STATS=stream: the statistics leave the critical path instead -- a pass over x and their exchange on the communication stream
+// UNDER the weight preparation and the forward, which depend on x only: the step then has ONE cross-GPU round trip in line, the gradient
+// exchange)
+static bool inline_stats(const sae_ctx* c) { return c->p2p && c->use_fused_fwd && !c->topk && c->stats_inline; }
 
 static int use_device(const sae_ctx* c) {
   HIP_TRY(hipSetDevice(c->cfg.device_id));
@@ -1316,6 +1320,7 @@ extern "C" int sae_p2p_init(sae_ctx* c, const void* blobs, int64_t bytes_per_ran
       c->p2p_fault_after = (unsigned long long)after;
     }
   }
+  if (const char* m = getenv("FREUD_DP_STATS")) c->stats_inline = strcmp(m, "stream") != 0;      // "inline" (default) | "stream"
   c->p2p = true;
   c->p2p_rank = rank;
   c->dist = true;
