@@ -98,6 +98,39 @@ __device__ __forceinline__ bf16x8 tr_frag_perm(const char* img, int col0, int s,
 #define BF_DMA_B_ 1
 #endif
 constexpr int BF_DMA_A = BF_DMA_A_, BF_DMA_B = BF_DMA_B_;
+// Round 6: the step loop unrolled over the two LDS stages (the stage a step reads is a compile-time constant).  With `cur` a run-time
+// variable every step computed its stage bases again -- by the disassembly 39 scalar instructions in ONE block at the loop head (two
+// stage offsets by multiplication, three 64-bit row pointers from the step number, fourteen LDS destinations of the DMA pieces) and 26
+// v_add_u32 (stage base + lane offset in front of the LDS reads whose immediate field cannot hold an offset into the second stage) --
+// ~65 of the ~300 instructions a wave issues per step, on the ONE issue port a single wave per SIMD has, most of them with the matrix
+// pipe idle.  Now: a second set of lane offsets for the second stage (18 registers), the row pointers advanced by their stride, the
+// LDS destination formed by the `s_add_u32 m0, ...` that writes M0 anyway.  -DBF_STATIC_STAGES=0 = round 5's loop.
+#ifndef BF_STATIC_STAGES
+#define BF_STATIC_STAGES 1
+#endif
+#ifndef BF_RING
+#define BF_RING 12           // fragment ring (divides 72); the prefetch distance is BF_RING - 1 MFMAs
+#endif
+
+// two LDS-DMA pieces whose LDS destinations are base + l0 / base + l1: the addition IS the write of M0
+__device__ __forceinline__ void glds16_x2_add(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1, unsigned base,
+                                              unsigned l0, unsigned l1) {
+  asm volatile(
+      "s_add_u32 m0, %4, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\t"
+      "s_add_u32 m0, %4, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1"
+      :
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(base), "s"(l0), "s"(l1)
+      : "memory", "m0", "scc");
+}
+__device__ __forceinline__ void glds16_x2_add_nt(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1, unsigned base,
+                                                 unsigned l0, unsigned l1) {
+  asm volatile(
+      "s_add_u32 m0, %4, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0 nt\n\t"
+      "s_add_u32 m0, %4, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt"
+      :
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(base), "s"(l0), "s"(l1)
+      : "memory", "m0", "scc");
+}
 
 __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   // epilogue multiplies the dW slab and db by scale = alpha/count.
   float scal1, scal2;
   if (a.cnt_part) {
-    double* redc = reinterpret_cast<double*>(smem + BF_STAGE_BYTES);      // stage 1 is idle until the loop's first hand-over
+    double* redc = reinterpret_cast<double*>(smem + BF_DXH_BYTES);        // the second stage's dx_hat image (either layout): idle until the loop's first hand-over
     double m = wave_sum_d(cnt_m);
     if (lane == 0) redc[w] = m;
     __syncthreads();
@@ -171,6 +204,25 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   }
   typedef __attribute__((address_space(3))) char* lptr_t;
   const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
+#if BF_STATIC_STAGES
+  // LDS layout of this form: [dx_hat stage 0 | dx_hat stage 1 | x stage 0 | x stage 1 | c stage 0 | c stage 1] (24 + 24 + 24 + 24 + 8 + 8
+  // KiB) instead of two contiguous stages: the 16-bit immediate offset of an LDS read then reaches BOTH stages of an image family from
+  // one set of lane offsets (row reads and transposed reads of dx_hat: 0 ... 48 KiB; x: 48 ... 96 KiB from a second set of eight; c: from
+  // its own two) -- two whole sets for a contiguous second stage did not fit the 256 vector registers (596 bytes of scratch).
+  // The same pair from RUNNING row pointers (pd / px: dx_hat and x rows of the step being fetched, pcl: its latent rows at this
+  // workgroup's columns) into stage `stage`: the LDS destination is formed by the s_add that writes M0.
+  unsigned loff_x[6], loff_cs[2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) loff_x[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(loff_d[i] + 2 * BF_DXH_BYTES));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) loff_cs[i] = (unsigned)__builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
+  const unsigned stage_base_d[2] = {smem_base, smem_base + BF_DXH_BYTES};
+  const unsigned stage_base_c[2] = {smem_base + 4 * BF_DXH_BYTES, smem_base + 4 * BF_DXH_BYTES + BF_C_BYTES};
+  auto dma_pair_at = [&](int p, const bf16_t* pd, const bf16_t* px, const bf16_t* pcl, int stage) {
+    if (p < 6) glds16_x2_add(pd, px, voff_d[p], voff_d[p], stage_base_d[stage], loff_d[p], loff_x[p]);
+    else glds16_x2_add_nt(pcl, pcl, voff_c[0], voff_c[1], stage_base_c[stage], loff_cs[0], loff_cs[1]);
+  };
+#endif
   // piece pair p (0..6) of the step whose first row is row0, into stage `stage`
   auto dma_pair = [&](int p, int64_t row0, int stage) {
     const unsigned buf = smem_base + stage * BF_STAGE_BYTES;
@@ -212,6 +264,17 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     const int col = 32 * w + 16 * g + 4 * p;
     return dual_off(4 * ah + q + 8, col >> 3) + (col & 7) * 2;
   }();
+#if BF_STATIC_STAGES
+  // lane offsets of the x images (transposed reads) and of the c images in the layout above; opaque, or they are folded back into
+  // `toff + constant` and rebuilt by a v_add_u32 in front of every read
+  int toffX[8], coffC0 = coff0 + 4 * BF_DXH_BYTES, coffC1 = coff1 + 4 * BF_DXH_BYTES;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    toffX[i] = toff[i] + 2 * BF_DXH_BYTES;
+    asm volatile("" : "+v"(toffX[i]));
+  }
+  asm volatile("" : "+v"(coffC0), "+v"(coffC1));
+#endif
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   auto tr_pair = [&](const char* p0, const char* p1) -> bf16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p0));
@@ -223,7 +286,8 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   // The step loop is rotated: the barrier that hands over the next stage sits DIST MFMAs before the end of a step,
   // and the gaps after it already request the first fragments (and the c fragments) of the NEXT step from the other
   // stage, so no step starts with an exposed LDS round trip.  RING divides 72, which keeps every ring slot static.
-  constexpr int RING = 12, DIST = RING - 1;
+  constexpr int RING = BF_RING, DIST = RING - 1;
+  static_assert(72 % RING == 0, "ring slots must be static across steps");
   auto load_frag = [&](const char* img_d, int i) -> bf16x8 {
     // A-operand fragment of MFMA i (0..71) of the step whose stage image starts at img_d:
     //   i in [ 0,24): dc += dx_hat(rows; ds_read_b128)      . W^T fragment i (registers)
@@ -238,6 +302,23 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       return tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]);
     }
   };
+#if BF_STATIC_STAGES
+  auto load_frag_s = [&](auto stage_tag, int i) -> bf16x8 {      // load_frag of stage ST (a constant) in the interleaved layout
+    constexpr int ST = decltype(stage_tag)::value;
+    if (i < 24) {
+      return *reinterpret_cast<const bf16x8*>(smem + ST * BF_DXH_BYTES + (i >> 3) * 8192 + roff[i & 7]);
+    } else {
+      const int tt = i < 48 ? i - 24 : i - 48, dt = tt >> 1, sk = tt & 1;
+      const char* b = smem + ST * BF_DXH_BYTES + (dt >> 2) * 8192 + sk * 4096;
+      return i < 48 ? tr_pair(b + toff[2 * (dt & 3)], b + toff[2 * (dt & 3) + 1]) : tr_pair(b + toffX[2 * (dt & 3)], b + toffX[2 * (dt & 3) + 1]);
+    }
+  };
+  auto load_c_s = [&](auto stage_tag, int half) -> bf16x8 {
+    constexpr int ST = decltype(stage_tag)::value;
+    const char* b = smem + ST * BF_C_BYTES + half * 4096;
+    return tr_pair(b + coffC0, b + coffC1);
+  };
+#endif
   // dc starts at (1/M)/scale: the L1 term sign(c)/M of d loss / d c, so the gate needs no add.  The dc chain is issued
   // as VGPR-form MFMAs (inline asm): the gate reads dc with plain VALU, and hipcc no longer parks a dW accumulator in
   // VGPRs to make room for it (that cost 48 v_accvgpr moves per step).
@@ -292,8 +373,14 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   db_acc = 0.f;
   if (step_begin < step_end) {
+#if BF_STATIC_STAGES
+    const int64_t r0 = (int64_t)step_begin * BF_BM;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) dma_pair_at(p, a.dxh + r0 * BF_D, a.xb + r0 * BF_D, a.c + r0 * a.n_p + n0, 0);
+#else
 #pragma unroll
     for (int p = 0; p < 7; ++p) dma_pair(p, (int64_t)step_begin * BF_BM, 0);
+#endif
   }
   // make hipcc retire the W^T fragment loads HERE: otherwise it places its vmcnt waits for them inside the loop,
   // where they would also wait for the (untracked) LDS-DMA of the next step and serialise copy and compute
@@ -301,11 +388,32 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   for (int kk = 0; kk < 24; ++kk) asm volatile("" : "+v"(wfrag[kk]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#if BF_STATIC_STAGES
+#pragma unroll
+  for (int i = 0; i <= DIST; ++i) ring[i] = load_frag_s(std::integral_constant<int, 0>{}, i);     // includes gap 0 of the first step
+  cf[0] = load_c_s(std::integral_constant<int, 0>{}, 0);
+  cf[1] = load_c_s(std::integral_constant<int, 0>{}, 1);
+#else
 #pragma unroll
   for (int i = 0; i <= DIST; ++i) ring[i] = load_frag(smem, i);     // includes gap 0 of the first step
   cf[0] = tr_pair(smem + 2 * BF_DXH_BYTES + coff0, smem + 2 * BF_DXH_BYTES + coff1);
   cf[1] = tr_pair(smem + 2 * BF_DXH_BYTES + 4096 + coff0, smem + 2 * BF_DXH_BYTES + 4096 + coff1);
+#endif
   if (a.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#if BF_STATIC_STAGES
+  // rows fetched during a step: those of the step after it (the last step re-copies its own rows into the idle stage instead of
+  // branching around the DMA) -- as running pointers, advanced by one step's stride while a later step exists
+  const int64_t nrow_first = (int64_t)(step_begin + 1 < step_end ? step_begin + 1 : step_begin) * BF_BM;
+  const bf16_t* nd = a.dxh + nrow_first * BF_D;
+  const bf16_t* nx = a.xb + nrow_first * BF_D;
+  const bf16_t* nc = a.c + nrow_first * a.n_p + n0;
+  const int64_t c_stride = (int64_t)BF_BM * a.n_p;
+  auto step_body = [&](auto cur_tag, int step) {
+    constexpr int CUR = decltype(cur_tag)::value;
+    using CurT = std::integral_constant<int, CUR>;
+    using NxtT = std::integral_constant<int, CUR ^ 1>;
+    f32x16 dc;
+#else
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
     // the last step re-copies its own rows into the idle stage instead of branching around the DMA
@@ -313,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     const char* img_d = smem + cur * BF_STAGE_BYTES;
     const char* nxt_d = smem + (cur ^ 1) * BF_STAGE_BYTES;
     f32x16 dc;
+#endif
 
 #pragma unroll
     for (int i = 0; i < 72; ++i) {
@@ -357,6 +466,19 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       __builtin_amdgcn_sched_barrier(0);
       // ---- gap g = i + 1 (issues while MFMA i occupies the matrix pipe); gap 72 is gap 0 of the next step
       const int g = i + 1;
+#if BF_STATIC_STAGES
+      if (g == 72 - DIST) {
+        // every read of this stage has been issued and returned, this wave's DMA pieces of the next step have landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... and everybody's
+        cf[0] = load_c_s(NxtT{}, 0);
+      }
+      if (g == 72 - DIST + 1) cf[1] = load_c_s(NxtT{}, 1);
+      if (g + DIST < 72) ring[(g + DIST) % RING] = load_frag_s(CurT{}, g + DIST);
+      else ring[(g + DIST) % RING] = load_frag_s(NxtT{}, g + DIST - 72);
+      if (g >= BF_DMA_B && (g - BF_DMA_B) % BF_DMA_A == 0 && (g - BF_DMA_B) / BF_DMA_A < 7)
+        dma_pair_at((g - BF_DMA_B) / BF_DMA_A, nd, nx, nc, CUR ^ 1);
+#else
       if (g == 72 - DIST) {
         // every read of this stage has been issued and returned, this wave's DMA pieces of the next step have landed
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -368,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       else ring[(g + DIST) % RING] = load_frag(nxt_d, g + DIST - 72);
       if (g >= BF_DMA_B && (g - BF_DMA_B) % BF_DMA_A == 0 && (g - BF_DMA_B) / BF_DMA_A < 7)
         dma_pair((g - BF_DMA_B) / BF_DMA_A, next_row0, cur ^ 1);
+#endif
       if (g >= 30 && g < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = g - 30, s2 = e >> 3, j = e & 7;
         const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed
@@ -376,8 +499,27 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#if BF_STATIC_STAGES
+    if (step + 2 < step_end) {      // (wave-uniform: scalar pointer arithmetic)
+      nd += BF_BM * BF_D;
+      nx += BF_BM * BF_D;
+      nc += c_stride;
+    }
+  };
+  // pairs of steps (stage 0, stage 1) in a branch-free loop body, then the odd step if there is one (a conditional second half inside
+  // the loop merges 300 live registers at the back edge: the allocator answered with 680 bytes of scratch)
+  {
+    int step = step_begin;
+    for (; step + 1 < step_end; step += 2) {
+      step_body(std::integral_constant<int, 0>{}, step);
+      step_body(std::integral_constant<int, 1>{}, step + 1);
+    }
+    if (step < step_end) step_body(std::integral_constant<int, 0>{}, step);
+  }
+#else
     cur ^= 1;
   }
+#endif
   if (a.clk) {
     clk_loop += __builtin_amdgcn_s_memtime() - clk_t0;
     clk_real += __builtin_amdgcn_s_memrealtime() - clk_r0;

@@ -77,6 +77,10 @@ __device__ __forceinline__ float block_sum_256_lds(float v, float* red) {
 // read, and a copy can never overlap the MFMAs that follow it): the caller waits with its own s_waitcnt vmcnt + barrier.
 // M0 carries the wave-uniform LDS byte address.  Two pieces per statement (one M0 save/restore): piece k copies
 // 64 x 16 B from sbase_k + voff_k (per lane) to LDS [dst_k, dst_k + 1024).
+// (Round 6: M0 is declared CLOBBERED instead of being saved and restored around every statement -- nothing else in these kernels lives in
+// M0 (gfx9 LDS instructions do not read it), so the save / restore pair was two scalar instructions per statement on the one issue
+// port a single-wave-per-SIMD kernel has: 6 of the fused forward's ~28 scalar instructions per iteration.  -DGLDS_KEEP_M0 = the old form.)
+#ifdef GLDS_KEEP_M0
 __device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
                                           unsigned dst0, unsigned dst1) {
   unsigned keep;
@@ -89,8 +93,6 @@ __device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1
       : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
       : "memory");
 }
-
-// Same, with the non-temporal cache policy: for streams that are read exactly once (the latent in the backward)
 __device__ __forceinline__ void glds16_x2_nt(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
                                              unsigned dst0, unsigned dst1) {
   unsigned keep;
@@ -103,8 +105,6 @@ __device__ __forceinline__ void glds16_x2_nt(const void* sbase0, const void* sba
       : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
       : "memory");
 }
-
-// One 256-byte piece: lane l copies 4 B from sbase + voff (per lane) to LDS [dst + 4 l, dst + 4 l + 4).
 __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned dst) {
   unsigned keep;
   asm volatile(
@@ -115,6 +115,33 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
       : "s"(sbase), "v"(voff), "s"(dst)
       : "memory");
 }
+#else
+__device__ __forceinline__ void glds16_x2(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
+                                          unsigned dst0, unsigned dst1) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1"
+      :
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
+      : "memory", "m0");
+}
+
+// Same, with the non-temporal cache policy: for streams that are read exactly once (the latent in the backward)
+__device__ __forceinline__ void glds16_x2_nt(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1,
+                                             unsigned dst0, unsigned dst1) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0 nt\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt"
+      :
+      : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(dst0), "s"(dst1)
+      : "memory", "m0");
+}
+
+// One 256-byte piece: lane l copies 4 B from sbase + voff (per lane) to LDS [dst + 4 l, dst + 4 l + 4).
+__device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(sbase), "v"(voff), "s"(dst) : "memory", "m0");
+}
+#endif
 
 // A loop whose index is a TEMPLATE constant.  `#pragma unroll` gives up silently above LLVM's size threshold; the loop then stays
 // rolled and every register array it indexes goes to the stack (fwd_fused2.h's slot loop in round 5: 1.8 KB of scratch per lane after

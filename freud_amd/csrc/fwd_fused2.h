@@ -37,6 +37,15 @@
 #ifndef FF2_EPI_PACKED
 #define FF2_EPI_PACKED 1     // 1 = the packed residual arithmetic of the no-mask path (v_pk_add / v_pk_fma on pairs)
 #endif
+#ifndef FF2_L1_SUNK
+#define FF2_L1_SUNK 0        // 1 = round 5's plain `l1_it += cv` (A/B: tools/build_variant.sh l1sunk -DFF2_L1_SUNK=1)
+#endif
+#ifndef FF2_PAIR_ROUND
+#define FF2_PAIR_ROUND 1     // round 6: the rounding of S to bf16 (CPU autocast's GEMM output) for TWO elements by one v_cvt_pk_bf16_f32, brought back
+#endif                       // to fp32 by a shift / a mask: 3 vector instructions per pair instead of 4, the same bits (0 = one cvt + shift per element)
+#ifndef FF2_PAIR_FRAGS
+#define FF2_PAIR_FRAGS 1     // round 6: encoder fragments requested two at a time, every fourth slot: the second MFMA of a pair needs no s_waitcnt of
+#endif                       // its own (LDS reads return in order) -- 12 waits per iteration less on the wave's one issue port (0 = one per even slot)
 #ifndef FF2_PACKED
 #define FF2_PACKED 0         // 1 = the packed form below: 91 instead of 111 vector instructions per iteration and NOT faster (profiles/r05_ab_fwd_packed_valu.txt)
 #endif
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     // (FF2_PACKED: static_for -- the slot index as a template constant: `#pragma unroll` gives up silently above LLVM's size
     // threshold, and with the packed form's few added lines the loop stayed rolled and indexed every register array dynamically,
     // 1.8 KB of scratch per lane.  The shipped element-wise form keeps round 4's pragma loop: bit-identical code.)
-#if FF2_PACKED || defined(FF2_WAITSTAMP)
+#if FF2_PACKED || defined(FF2_WAITSTAMP) || !FF2_L1_SUNK
 #define FF2_STATIC_LOOP 1
     static_for<0, 48>([&](auto slot_tag) {
       constexpr int i = decltype(slot_tag)::value;
@@ -304,7 +313,16 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     for (int i = 0; i < 48; ++i) {
 #endif
       // ---- fragment prefetch
+#if FF2_PAIR_FRAGS
+      // encoder fragments k = i/2 + 3 and i/2 + 4 together, every fourth slot (consumed at slots i + 7 and i + 9; the ring holds 8)
+      // -- the LATER one first: the wait in front of the earlier MFMA (its fragment is the younger request) then covers both
+      if ((i & 3) == 0 && i <= 40) {
+        if (i / 2 + 4 <= 23) ring[(i / 2 + 4) % RING] = enc_frag(SLOT_E, i / 2 + 4);
+        ring[(i / 2 + 3) % RING] = enc_frag(SLOT_E, i / 2 + 3);
+      }
+#else
       if ((i & 1) == 0 && i <= 40) ring[(i / 2 + 3) % RING] = enc_frag(SLOT_E, i / 2 + 3);         // encoder k = i/2 + 3 (slot i + 7)
+#endif
       if (i == 42 || i == 44 || i == 46) ring[(i - 42) / 2] = enc_frag(SLOT_EN, (i - 42) / 2);      // k = 0..2 of the NEXT iteration
       if (i == 15 || i == 16 || i == 17) Afr[i - 12] = dec_a(SLOT_D, i - 12);                       // k-step 1 (decoder MFMAs 12..23)
       if (i == 45 || i == 46 || i == 47) Afr[i - 45] = dec_a(SLOT_DN, i - 45);                      // k-step 0 of the next phase
@@ -375,9 +393,25 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
       // latent element e at gap 4 + 2 e
       if (i >= 4 && i <= 34 && (i & 1) == 0) {
         const int e = (i - 4) >> 1;                      // S register e <-> column n = (e&3) + 8 (e>>2) + 4 h
+#if FF2_PAIR_ROUND
+        if ((e & 1) == 0) {      // both elements of the pair rounded by ONE conversion (round to nearest even, like bf16_round)
+          const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{S[e], S[e + 1]}, bf16x2));
+          pr = f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+        }
+        float cv = fmaxf(pr[e & 1] + bq[e >> 2][e & 3], 0.f);           // rounded to bf16 BEFORE the fp32 bias add (CPU autocast)
+#else
         float cv = fmaxf(bf16_round(S[e]) + bq[e >> 2][e & 3], 0.f);    // rounded to bf16 BEFORE the fp32 bias add (CPU autocast)
+#endif
         if (PAD) cv = row_ok ? cv : 0.f;
+#if FF2_L1_SUNK
         l1_it += cv;
+#else
+        // Round 6 (the disassembly): written as `l1_it += cv`, LLVM SANK the sixteen additions of three of the four unrolled bodies to
+        // the loop latch -- the values stay live in sixteen registers each and 51 dependent v_add_f32 run back to back at the back edge
+        // with no MFMA between them (~200 cycles per four iterations with the matrix pipe idle).  As an opaque instruction the addition
+        // stays in its MFMA gap; same operands, same order, same sum.
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(l1_it) : "v"(cv));
+#endif
         cw[e & 7] = (bf16_t)cv;
         if ((e & 7) == 7)      // the eight values of k-step e >> 3: one 16-byte chunk of this lane's row
           *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e >> 3)]) = cw;

@@ -27,6 +27,11 @@ KERNELS = {
     "p2p2": "_Z20p2p_allreduce_kernelILi2EEv7P2PArgs",
     "finalize": "_Z22finalize_losses_kernelPKfiS0_iPfS1_lifS0_iPKd9StatsPush",
     "push_selftest": "_Z24p2p_selftest_push_kernel9StatsPushiPj",
+    # fused forward, the shipped instantiations (T = bf16 / fp16 / fp32 activations; PAD = false / true; STAMP = false)
+    "ff2_bf16": "_Z22fwd_fused2_d384_kernelIDF16bLb0ELb0EEv12FwdFusedArgs",
+    "ff2_bf16_pad": "_Z22fwd_fused2_d384_kernelIDF16bLb1ELb0EEv12FwdFusedArgs",
+    "ff2_f16": "_Z22fwd_fused2_d384_kernelIDF16_Lb0ELb0EEv12FwdFusedArgs",
+    "ff2_f32": "_Z22fwd_fused2_d384_kernelIfLb0ELb0EEv12FwdFusedArgs",
 }
 
 
@@ -177,3 +182,24 @@ def test_no_kernel_spills_to_scratch():
         assert not bad, f"kernels with scratch (spill) instructions: {bad}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.parametrize("key", ["ff2_bf16", "ff2_bf16_pad", "ff2_f16", "ff2_f32"])
+def test_fused_forward_tail_wait_counts_exactly_its_four_latent_stores(disasm, key):
+    """fwd_fused2.h's epilogue overlays its staging image on the W^T ring while the loop's last LDS-DMA pieces may still be landing
+    there; the hand-over is `s_waitcnt vmcnt(4)` + s_barrier: everything but the wave's FOUR youngest vector-memory operations.
+    That is right only while exactly four latent stores -- and no load, no further DMA piece -- sit between the last
+    global_load_lds of the kernel and that wait: an edit that adds a store or a load there would let DMA writes land
+    in memory the epilogue already uses, silently.  Asserted in the built code object."""
+    ins = disasm[key]
+    dma = [k for k, i in enumerate(ins) if i.startswith("global_load_lds")]
+    assert dma, "no LDS-DMA in the fused forward?"
+    last = dma[-1]
+    waits = [k for k in range(last + 1, len(ins)) if ins[k].startswith("s_waitcnt") and "vmcnt(4)" in ins[k]]
+    assert waits, "the counted tail wait (vmcnt(4)) is gone: FF2_TAIL_V1's full drain, or a changed drain loop -- re-derive the count"
+    w = waits[0]
+    between = ins[last + 1:w]
+    vm = [i for i in between if i.startswith(("global_", "buffer_", "flat_", "scratch_"))]
+    stores = [i for i in vm if i.startswith("global_store")]
+    assert len(stores) == 4 and len(vm) == 4, f"{len(stores)} stores / {len(vm)} vector-memory operations between the last DMA piece and the tail wait: {vm}"
+    assert any(i.startswith("s_barrier") for i in ins[w:w + 4]), "the tail wait is not followed by the workgroup barrier"
