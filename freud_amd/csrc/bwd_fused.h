@@ -108,6 +108,9 @@ constexpr int BF_DMA_A = BF_DMA_A_, BF_DMA_B = BF_DMA_B_;
 #ifndef BF_STATIC_STAGES
 #define BF_STATIC_STAGES 1
 #endif
+#ifndef BF_GATE_AHEAD
+#define BF_GATE_AHEAD 1      // the ReLU gate's compare one MFMA gap ahead of its select (see the gate below); 0 = both in one gap
+#endif
 #ifndef BF_RING
 #define BF_RING 12           // fragment ring (divides 72); the prefetch distance is BF_RING - 1 MFMAs
 #endif
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     using CurT = std::integral_constant<int, CUR>;
     using NxtT = std::integral_constant<int, CUR ^ 1>;
     f32x16 dc;
+    bool gate_cur = false, gate_next = false;
 #else
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
     const char* img_d = smem + cur * BF_STAGE_BYTES;
     const char* nxt_d = smem + (cur ^ 1) * BF_STAGE_BYTES;
     f32x16 dc;
+    bool gate_cur = false, gate_next = false;
 #endif
 
 #pragma unroll
@@ -491,12 +496,29 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       if (g >= BF_DMA_B && (g - BF_DMA_B) % BF_DMA_A == 0 && (g - BF_DMA_B) / BF_DMA_A < 7)
         dma_pair((g - BF_DMA_B) / BF_DMA_A, next_row0, cur ^ 1);
 #endif
+#if BF_GATE_AHEAD
+      // Round 6: the gate's COMPARE one gap ahead of its select.  `v_cmp` writes a scalar register and gfx950 wants two wait states before
+      // a vector instruction reads it; with compare and select in the same gap (nothing else may move in between: the gaps are fenced)
+      // hipcc filled them with `s_nop 1` -- sixteen per step on the wave's one issue port.  One gap apart the distance is there for free.
+      if (g >= 29 && g < 45) {
+        const int e1 = g - 29;
+        gate_next = (float)cf[e1 >> 3][e1 & 7] > 0.f;
+      }
+      if (g >= 30 && g < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
+        const int e = g - 30, s2 = e >> 3, j = e & 7;
+        const float gv = gate_cur ? dc[e] : 0.f;                    // (1/M term rides in the accumulator) bf16 once, when packed
+        db_acc += gv;
+        pf[s2][j] = (bf16_t)gv;
+      }
+      if (g >= 29 && g < 45) gate_cur = gate_next;
+#else
       if (g >= 30 && g < 46) {      // one dpre element per gap: dc register e, gated by c at the same (row, col)
         const int e = g - 30, s2 = e >> 3, j = e & 7;
         const float gv = ((float)cf[s2][j] > 0.f) ? dc[e] : 0.f;    // (1/M term rides in the accumulator) bf16 once, when packed
         db_acc += gv;
         pf[s2][j] = (bf16_t)gv;
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #if BF_STATIC_STAGES

@@ -5,15 +5,15 @@
 #                        loop (static stages, interleaved LDS layout, running row pointers)
 #   fwdold / bwdold    = one of the two loops as in round 5
 #   r5loop             = both as in round 5
-mkdir -p gpurun_out/r06_loops
-O=gpurun_out/r06_loops
+mkdir -p gpurun_out/r06_loops2
+O=gpurun_out/r06_loops2
 export FREUD_SAE_ALLOW_OLD_LIB=1
 timeout 1500 python -m pytest tests/test_engine_gpu.py tests/test_resume_gpu.py tests/test_trajectory_gpu.py -q -x -m gpu > $O/tests.txt 2>&1
 echo "tests rc $?" >> $O/tests.txt
 tail -3 $O/tests.txt
 B="python3 bench.py --no-cpu-baseline --no-pcie-sample"
 for i in 1 2 3; do
-  for lib in "" build/ab/libfreud_sae_fwdold.so build/ab/libfreud_sae_bwdold.so build/ab/libfreud_sae_r5loop.so; do
+  for lib in "" build/ab/libfreud_sae_gatesame.so build/ab/libfreud_sae_r5loop.so; do
     for args in "" "--rotate 4" "--data normal"; do
       echo -n "${lib:-current} [$args] " >> $O/ab.txt
       FREUD_SAE_LIB=$lib $B --steps 200 --warmup 20 --breakdown $args 2>&1 | grep -E "per-kernel|ms_per_step" | tr '\n' ' ' | sed -e 's/.*"fwd_fused_gemm": \([0-9.]*\).*"bwd_fused_gemm": \([0-9.]*\).*"reduce_grads": \([0-9.]*\).*"ms_per_step": \([0-9.]*\).*/fwd \1 bwd \2 reduce \3 step \4/' >> $O/ab.txt
@@ -23,8 +23,8 @@ for i in 1 2 3; do
 done
 cat $O/ab.txt
 for lib in "" build/ab/libfreud_sae_r5loop.so; do
-  FREUD_SAE_LIB=$lib $B --dbg 65 --steps 100 --warmup 20 2>&1 | grep -E "^fwd" >> $O/stamps_${lib:+r5}${lib:-current}.txt
-  FREUD_SAE_LIB=$lib $B --dbg 66 --steps 100 --warmup 20 2>&1 | grep -E "^bwd" >> $O/stamps_${lib:+r5}${lib:-current}.txt
+  FREUD_SAE_LIB=$lib $B --dbg 65 --steps 100 --warmup 20 2>&1 | grep -E "^fwd" >> $O/stamps_$(basename ${lib:-current}).txt
+  FREUD_SAE_LIB=$lib $B --dbg 66 --steps 100 --warmup 20 2>&1 | grep -E "^bwd" >> $O/stamps_$(basename ${lib:-current}).txt
 done
 cat $O/stamps_*.txt
 for i in 1 2; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie-sample > $O/driver_style_$i.json 2>/dev/null; done
