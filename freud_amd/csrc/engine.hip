@@ -1534,6 +1534,7 @@ template <int AM, int BM_, class Epi>
 static bool gemm_streams(const GemmArgs& g) {
   if constexpr (!(G2_STREAM && epi_stream<Epi>::value && AM == OP_ROW && BM_ == OP_ROW)) return false;
   if (g_no_stream || g_force_gemm128 || g.nbm % 2 != 0 || g.nbn % 2 != 0) return false;
+  if (G2S_STATIC && g.ktiles % 2 != 0) return false;       // (the static-stage K loop walks the K tiles in pairs: gemm256s.h)
   return !g.dyn && g.splits == 1 && g.tail_tiles == 0 && g.ktiles == g.ktiles0 && g.ktiles >= 2 && g.seg1_gate == nullptr && g.lda == g.ldb &&
          (g.nbm / 2) * (g.nbn / 2) >= 4 * G2_PERSIST_STATIC;
 }

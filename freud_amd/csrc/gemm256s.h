@@ -42,6 +42,9 @@ struct epi_stream<E, std::void_t<decltype(E::STREAM)>> { static constexpr bool v
 #ifndef G2S_PRIO
 #define G2S_PRIO 0           // tools/kbench experiment (see the K loop)
 #endif
+#ifndef G2S_STATIC
+#define G2S_STATIC 1         // round 6: the K loop unrolled over the two LDS stages (compile-time stage; K tiles per output tile must be EVEN:
+#endif                       // the host launches the streaming form only then).  0 = round 5's loop with a run-time stage
 #ifndef G2_STREAM
 #define G2_STREAM 1          // tools/build_variant.sh A/B switch: 0 = the K = d GEMMs through gemm256.h's persistent tile form
 #endif
@@ -157,10 +160,33 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
     typedef __attribute__((address_space(3))) char* lptr_t;
     const unsigned smem_base = (unsigned)(uintptr_t)(lptr_t)smem;
     const unsigned piece0 = (unsigned)__builtin_amdgcn_readfirstlane(4 * w * 1024);
+#if G2S_STATIC
+    // Round 6 (the same finding as in bwd_fused.h): with the stage a run-time variable every K tile rebuilt its LDS addresses -- 32 vector
+    // additions (stage base + lane offset in front of the fragment reads, whose 16-bit immediate cannot reach the second stage) and ~35
+    // scalar instructions (stage bases, DMA destinations) per wave, 2 waves per SIMD.  LDS layout of this form: [A stage 0 | A stage 1 |
+    // B stage 0 | B stage 1] (4 x 32 KiB): both stages of an operand are within the immediate's reach of ONE set of four lane offsets
+    // (one per K step: the chunk swizzle XORs the K step into the lane's row bits, so it is not an additive constant).
+    auto issue = [&](const bf16_t* pa, const bf16_t* pb, int stage, int q) {
+      const unsigned dst = smem_base + stage * G2_OPER_BYTES + piece0 + q * 1024;
+      glds16_x2(pa, pb, voff[q], voff[q], dst, dst + 2 * G2_OPER_BYTES);
+    };
+    int offA[4], offB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r = lane & 31, c = 2 * ks + (lane >> 5);
+      const int o = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);            // frag_read<OP_ROW>'s offset for base32 = 0
+      offA[ks] = o + (128 * wm) * 128;
+      offB[ks] = o + (64 * wn) * 128 + 2 * G2_OPER_BYTES;
+      asm volatile("" : "+v"(offA[ks]), "+v"(offB[ks]));             // opaque: kept as registers, not re-derived per read
+    }
+    auto fragA = [&](int stage, int i, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (32 * i) * 128 + offA[ks]); };
+    auto fragB = [&](int stage, int j, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (32 * j) * 128 + offB[ks]); };
+#else
     auto issue = [&](const bf16_t* pa, const bf16_t* pb, int stage, int q) {
       const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
       glds16_x2(pa, pb, voff[q], voff[q], dst, dst + G2_OPER_BYTES);
     };
+#endif
     char* eb = smem + 2 * G2_STAGE_BYTES + w * 4096;
     const int rr = lane >> 3, c8 = 8 * (lane & 7);
 
@@ -172,10 +198,17 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
     bf16x8 fa[2][4], fb[2][2];
+#if G2S_STATIC
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = fragA(0, i, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[0][j] = fragB(0, j, 0);
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = frag_read<OP_ROW>(smem, 128 * wm + 32 * i, 0, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) fb[0][j] = frag_read<OP_ROW>(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
+#endif
 
     // (no zeroing: the first K step of every tile multiplies into a ZERO source -- an inline constant of the MFMA -- instead of into
     // the accumulators: 128 vector moves per wave and tile less in an epilogue that is bound by its vector instructions)
@@ -203,6 +236,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
 #endif
 
       // one K tile of the stream; FIRST: the tile's K tile 0 (its first K step starts the accumulators from zero)
+#if G2S_STATIC
+      auto ktile = [&](auto first_tag, auto cur_tag, int kt) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int cur = decltype(cur_tag)::value;        // (shadows the run-time `cur`, which this form does not use)
+        constexpr int sa = cur, sb = cur, na = cur ^ 1, nb = cur ^ 1;      // "images" are stage numbers here
+        auto ldfrag = [&](int ia, int ib, int ks, int f) {
+          if (f < 4) fa[ks & 1][f] = fragA(ia, f, ks);
+          else fb[ks & 1][f - 4] = fragB(ib, f - 4, ks);
+        };
+#else
       auto ktile = [&](auto first_tag, int kt) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const char* sa = smem + cur * G2_STAGE_BYTES;
@@ -213,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
           if (f < 4) fa[ks & 1][f] = frag_read<OP_ROW>(ia, 128 * wm + 32 * f, ks, lane);
           else fb[ks & 1][f - 4] = frag_read<OP_ROW>(ib, 64 * wn + 32 * (f - 4), ks, lane);
         };
+#endif
         if (!FIRST && kt == nk - 1) {      // the functor's loads for this tile: a memory latency under the last K tile's MFMAs
 #if G2S_PRIO
           // experiment: waves 0-3 run the last K tile's MFMAs ahead of their SIMD partners (waves 4-7), so that each half's
@@ -273,10 +317,25 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#if !G2S_STATIC
         cur ^= 1;
+#endif
       };
+#if G2S_STATIC
+      {   // nk is even (host-side condition of this form): every output tile starts in stage 0
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        ktile(std::true_type{}, S0{}, 0);
+        ktile(std::false_type{}, S1{}, 1);
+        for (int kt = 2; kt < nk; kt += 2) {
+          ktile(std::false_type{}, S0{}, kt);
+          ktile(std::false_type{}, S1{}, kt + 1);
+        }
+      }
+#else
       ktile(std::true_type{}, 0);
       for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{}, kt);
+#endif
 #if G2S_PRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
