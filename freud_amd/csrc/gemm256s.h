@@ -45,6 +45,9 @@ struct epi_stream<E, std::void_t<decltype(E::STREAM)>> { static constexpr bool v
 #ifndef G2S_STATIC
 #define G2S_STATIC 1         // round 6: the K loop unrolled over the two LDS stages (compile-time stage; K tiles per output tile must be EVEN:
 #endif                       // the host launches the streaming form only then).  0 = round 5's loop with a run-time stage
+#ifndef G2S_M16
+#define G2S_M16 (G2S_STATIC)  // round 6: the K loop on v_mfma_f32_16x16x32_bf16 (needs the static-stage form).  The chip is power-managed and holds a higher
+#endif                        // clock on this shape: stand-alone, random operands, K = 1280: 5.50 -> 4.97 ms as a timing proxy (profiles/r06_kbench_proxy16.txt)
 #ifndef G2_STREAM
 #define G2_STREAM 1          // tools/build_variant.sh A/B switch: 0 = the K = d GEMMs through gemm256.h's persistent tile form
 #endif
@@ -135,6 +138,90 @@ __device__ __forceinline__ void g2s_epilogue_f32(f32x16 (&acc)[4][2], char* eb, 
   epi.s_tile_end(row_w, col_w);
 }
 
+// ---- the same two epilogues for the accumulators of the 16x16x32 K loop (G2S_M16): acc[i16][j16] = one 16x16 tile as f32x4 -- lane
+// (r16 = lane % 16, q = lane / 16) holds columns 16 j16 + 4 q .. + 3 of row 16 i16 + r16 (operands swapped as in the 32x32 loop: a lane
+// owns consecutive COLUMNS).  The LDS images the functor-side reads expect are the same; only who writes which 8 (16) bytes changes:
+//   bf16 form: row rr = 16 (i16 & 1) + r16 of the 32-row block, 16-byte chunk 2 j16 + (q >> 1), 8-byte half q & 1;
+//   fp32 form: row rr of the 32x32 tile, 16-byte chunk 4 (j16 & 1) + q.
+typedef __attribute__((ext_vector_type(4))) float g2s_f32x4;
+template <bool PARTIAL, class Epi>
+__device__ __forceinline__ void g2s_epilogue16(g2s_f32x4 (&acc)[8][4], char* eb, int row_w, int col_l, typename Epi::SPre (&pre0)[4], Epi& epi) {
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q4 = lane >> 4, rr = lane >> 3, c = lane & 7;
+  const char* rbase = eb + rr * 128 + ((c ^ rr) << 4);
+  auto write_block = [&](int I) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = 16 * a + r16;
+      char* wb = eb + row * 128 + (((q4 & 1) ^ ((row >> 3) & 1)) << 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const g2s_f32x4 v = acc[2 * I + a][j];
+        *reinterpret_cast<bf16x4*>(wb + (((2 * j + (q4 >> 1)) ^ (row & 7)) << 4)) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      }
+    }
+  };
+  typename Epi::SPre pre[2][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pre[0][q] = pre0[q];
+  write_block(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x8 raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[q] = *reinterpret_cast<const bf16x8*>(rbase + q * 1024);
+    if (i + 1 < 4) {
+      write_block(i + 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[(i + 1) & 1][q] = epi.s_prefetch(row_w + 32 * (i + 1) + 8 * q + rr, col_l);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16x8 v = raw[q];
+      const int lo = (q & 1) ? 4 : 0, hi = 4 - lo;
+      const f32x4 v0 = {(float)v[lo], (float)v[lo + 1], (float)v[lo + 2], (float)v[lo + 3]};
+      const f32x4 v1 = {(float)v[hi], (float)v[hi + 1], (float)v[hi + 2], (float)v[hi + 3]};
+      epi.template s_apply<PARTIAL>(row_w + 32 * i + 8 * q + rr, col_l, v0, v1, pre[i & 1][q]);
+    }
+  }
+  epi.s_tile_end(row_w, col_l);
+}
+
+template <class Epi>
+__device__ __forceinline__ void g2s_epilogue16_f32(g2s_f32x4 (&acc)[8][4], char* eb, int row_w, int col_w, Epi& epi) {
+  const int lane = threadIdx.x & 63, r16 = lane & 15, q4 = lane >> 4, rq = lane >> 2, cp = lane & 3;
+  auto fsw = [](int row) { return (row & 7) ^ ((row >> 2) & 1); };
+  const char* rbase = eb + rq * 128;
+  const int rsw = fsw(rq);           // (row rq + 16: the same low bits)
+  auto write_block = [&](int b) {
+    const int i = b >> 1, j = b & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = 16 * a + r16;
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        const g2s_f32x4 v = acc[2 * i + a][2 * j + bq];
+        *reinterpret_cast<f32x4*>(eb + row * 128 + (((4 * bq + q4) ^ fsw(row)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+  };
+  write_block(0);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    f32x4 raw[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      raw[q][0] = *reinterpret_cast<const f32x4*>(rbase + q * 2048 + (((2 * cp) ^ rsw) << 4));
+      raw[q][1] = *reinterpret_cast<const f32x4*>(rbase + q * 2048 + (((2 * cp + 1) ^ rsw) << 4));
+    }
+    if (b + 1 < 8) write_block(b + 1);
+    const int i = b >> 1, j = b & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      epi.s_apply(4 * i + 2 * j + q, row_w + 32 * i + 16 * q + rq, col_w + 32 * j + 8 * cp, raw[q][0], raw[q][1]);
+  }
+  epi.s_tile_end(row_w, col_w);
+}
+
 template <class E, class = void>
 struct epi_stream_f32 { static constexpr bool value = false; };
 template <class E>
@@ -181,6 +268,23 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
     }
     auto fragA = [&](int stage, int i, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (32 * i) * 128 + offA[ks]); };
     auto fragB = [&](int stage, int j, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (32 * j) * 128 + offB[ks]); };
+#if G2S_M16
+    // fragments of v_mfma_f32_16x16x32_bf16: 16 rows x 32 k -- lane (r16 = lane % 16, q = lane / 16) reads the 16-byte chunk q + 4 ks of row
+    // r16 of its row block.  The images and their chunk swizzle (chunk ^ (row >> 1 & 7)) are the 32x32 loop's; tools/lds_bank_check.py-style
+    // count for the four 16-lane service groups of ds_read_b128: rows {0-3, 12-15} with chunk c and rows 4-11 with chunk c + 1 hit 16
+    // distinct (row parity, chunk) slots for c = 0 and c = 4 -- conflict-free as it stands.
+    int offA16[2], offB16[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r16 = lane & 15, c = (lane >> 4) + 4 * ks;
+      const int o = r16 * 128 + ((c ^ ((r16 >> 1) & 7)) << 4);
+      offA16[ks] = o + (128 * wm) * 128;
+      offB16[ks] = o + (64 * wn) * 128 + 2 * G2_OPER_BYTES;
+      asm volatile("" : "+v"(offA16[ks]), "+v"(offB16[ks]));
+    }
+    auto fragA16 = [&](int stage, int i16, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (16 * i16) * 128 + offA16[ks]); };
+    auto fragB16 = [&](int stage, int j16, int ks) { return *reinterpret_cast<const bf16x8*>(smem + stage * G2_OPER_BYTES + (16 * j16) * 128 + offB16[ks]); };
+#endif
 #else
     auto issue = [&](const bf16_t* pa, const bf16_t* pb, int stage, int q) {
       const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
@@ -198,7 +302,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
     bf16x8 fa[2][4], fb[2][2];
-#if G2S_STATIC
+#if G2S_M16
+    // A fragments: a ring of four (row block t = 8 ks + i16 of the K tile in slot t % 4, requested three row blocks ahead); B fragments:
+    // the four column blocks of a K step, double-buffered by K step
+    bf16x8 fa16[4], fb16[2][4];
+    g2s_f32x4 acc16[8][4];
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) fa16[t3] = fragA16(0, t3, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb16[0][j] = fragB16(0, j, 0);
+#elif G2S_STATIC
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = fragA(0, i, 0);
 #pragma unroll
@@ -236,6 +349,56 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
 #endif
 
       // one K tile of the stream; FIRST: the tile's K tile 0 (its first K step starts the accumulators from zero)
+#if G2S_M16
+      // one K tile on the 16x16x32 shape: 64 MFMAs n = 4 t + j (t = 8 ks + i16: K step and 16-row block, j: 16-column block), one piece of
+      // other work behind each -- the A fragment of row block t + 3 at j == 0 (blocks 13-15 request the NEXT tile's blocks 0-2 from the
+      // other stage: after the hand-over), K step 1's B fragments at n = 5..17, the second half of tile kt+1's DMA pieces at n = 1 / 10,
+      // the hand-over at n = 50 (every read of this stage is issued by then: row block 15 was requested at n = 48), behind it the first half
+      // of tile kt+2's pieces and the next tile's K-step-0 B fragments.
+      auto ktile16 = [&](auto first_tag, auto cur_tag, int kt) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int CUR = decltype(cur_tag)::value;
+        if (!FIRST && kt == nk - 1) {      // the functor's loads for this tile: a memory latency under the last K tile's MFMAs
+          if constexpr (epi_stream_f32<Epi>::value) {
+            epi.s_tile(row_w, bn * G2_BN + 64 * wn + 8 * (lane & 3));
+          } else {
+            epi.s_tile(row_w, col_l);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre0[q] = epi.s_prefetch(row_w + 8 * q + rr, col_l);
+          }
+        }
+        static_for<0, 64>([&](auto n_tag) {
+          constexpr int n = decltype(n_tag)::value, t = n >> 2, ks = t >> 3, i16 = t & 7, j = n & 3;
+          // (inline asm with the accumulator TIED to the destination: through the builtin, whose destination may differ from its source,
+          // the allocator renamed the accumulators between the two peeled K tiles of an output tile and the loop -- both copies live across
+          // the transition, 250 registers instead of ~200, and the real functors spilled their prefetched operands.  No MFMA of this loop
+          // depends on an MFMA closer than 31 instructions before it, and the epilogue reads a block's accumulators hundreds of cycles
+          // after their last update: the hazards the compiler no longer sees cannot occur.)
+          if constexpr (FIRST && ks == 0) {
+            asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc16[i16][j]) : "v"(fb16[0][j]), "v"(fa16[t & 3]));
+          } else {
+            asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[i16][j]) : "v"(fb16[ks][j]), "v"(fa16[t & 3]));   // D^T = B A^T
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (j == 0) {
+            constexpr int tt = t + 3;
+            if constexpr (tt < 16) fa16[tt & 3] = fragA16(CUR, tt & 7, tt >> 3);
+            else fa16[tt & 3] = fragA16(CUR ^ 1, tt - 16, 0);
+          }
+          if constexpr (n == 5 || n == 9 || n == 13 || n == 17) fb16[1][(n - 5) >> 2] = fragB16(CUR, (n - 5) >> 2, 1);
+          if constexpr (n == 1) issue(pa(kt + 1), pb(kt + 1), CUR ^ 1, 2);
+          if constexpr (n == 10) issue(pa(kt + 1), pb(kt + 1), CUR ^ 1, 3);
+          if constexpr (n == 50) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+          }
+          if constexpr (n == 51) issue(pa(kt + 2), pb(kt + 2), CUR, 0);
+          if constexpr (n == 53 || n == 54 || n == 57 || n == 58) fb16[0][n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3] = fragB16(CUR ^ 1, n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3, 0);
+          if constexpr (n == 59) issue(pa(kt + 2), pb(kt + 2), CUR, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+#endif
 #if G2S_STATIC
       auto ktile = [&](auto first_tag, auto cur_tag, int kt) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -276,6 +439,27 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
+#ifdef G2S_PROXY16
+            // TIMING PROXY ONLY (tools/build_variant.sh g2sproxy16 -DG2S_PROXY16; results are WRONG): every 32x32x16 MFMA replaced by two
+            // 16x16x32 MFMAs on the same operand registers and a quarter each of the same accumulator -- the same FLOPs, LDS and register
+            // traffic, the other MFMA shape: what would a 16x16x32 K loop get under the chip's power limit with two waves per SIMD?
+            {
+              typedef __attribute__((ext_vector_type(4))) float f32x4_;
+              f32x16& C = acc[m >> 1][m & 1];
+              f32x4_ q0 = (kk & 1) ? f32x4_{C[4], C[5], C[6], C[7]} : f32x4_{C[0], C[1], C[2], C[3]};
+              f32x4_ q1 = (kk & 1) ? f32x4_{C[12], C[13], C[14], C[15]} : f32x4_{C[8], C[9], C[10], C[11]};
+              if (FIRST && kk == 0) { q0 = f32x4_{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+              q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], q0, 0, 0, 0);
+              q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], q1, 0, 0, 0);
+              if (kk & 1) { C[4] = q0[0]; C[5] = q0[1]; C[6] = q0[2]; C[7] = q0[3]; C[12] = q1[0]; C[13] = q1[1]; C[14] = q1[2]; C[15] = q1[3]; }
+              else { C[0] = q0[0]; C[1] = q0[1]; C[2] = q0[2]; C[3] = q0[3]; C[8] = q1[0]; C[9] = q1[1]; C[10] = q1[2]; C[11] = q1[3]; }
+            }
+            if constexpr (false) {
+              if (kk == 0) {
+              } else {
+              }
+            }
+#else
             if constexpr (FIRST) {
               if (kk == 0) {
                 f32x16 zero;
@@ -288,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
             } else {
               acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], acc[m >> 1][m & 1], 0, 0, 0);   // D^T = B A^T
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (kk == 0) {            // second half of stream tile kt+1's pieces + the fragments of K step 1
               if (m == 0) issue(pa(kt + 1), pb(kt + 1), cur ^ 1, 2);
@@ -325,12 +510,21 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
       {   // nk is even (host-side condition of this form): every output tile starts in stage 0
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
+#if G2S_M16
+        ktile16(std::true_type{}, S0{}, 0);
+        ktile16(std::false_type{}, S1{}, 1);
+        for (int kt = 2; kt < nk; kt += 2) {
+          ktile16(std::false_type{}, S0{}, kt);
+          ktile16(std::false_type{}, S1{}, kt + 1);
+        }
+#else
         ktile(std::true_type{}, S0{}, 0);
         ktile(std::false_type{}, S1{}, 1);
         for (int kt = 2; kt < nk; kt += 2) {
           ktile(std::false_type{}, S0{}, kt);
           ktile(std::false_type{}, S1{}, kt + 1);
         }
+#endif
       }
 #else
       ktile(std::true_type{}, 0);
@@ -344,9 +538,15 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
 #endif
 
       const bool partial = row_w + 128 > epi.s_rows();       // (wave-uniform) rows beyond M in this wave's block: the masking form
+#if G2S_M16
+      if constexpr (epi_stream_f32<Epi>::value) g2s_epilogue16_f32(acc16, eb, row_w, bn * G2_BN + 64 * wn, epi);
+      else if (partial) g2s_epilogue16<true>(acc16, eb, row_w, col_l, pre0, epi);
+      else g2s_epilogue16<false>(acc16, eb, row_w, col_l, pre0, epi);
+#else
       if constexpr (epi_stream_f32<Epi>::value) g2s_epilogue_f32(acc, eb, row_w, bn * G2_BN + 64 * wn, epi);
       else if (partial) g2s_epilogue<true>(acc, eb, row_w, col_l, pre0, epi);
       else g2s_epilogue<false>(acc, eb, row_w, col_l, pre0, epi);
+#endif
 #ifdef G2X_STAMP
       st_loop += st1 - st0; st_epi += __builtin_readcyclecounter() - st1; ++st_tiles;
 #endif
