@@ -258,6 +258,26 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
           for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+#ifdef G8S_PROXY16
+              // TIMING PROXY ONLY (tools/build_variant.sh g8sproxy16 -DG8S_PROXY16; results WRONG): each 32x32x64 MFMA as two 16x16x128 on
+              // the same operand registers and a quarter each of the accumulator -- would the smaller shape lift the clock for e4m3 too?
+              {
+                typedef __attribute__((ext_vector_type(4))) float f32x4_;
+                f32x16& C = acc[i][j];
+                f32x4_ q0 = s ? f32x4_{C[4], C[5], C[6], C[7]} : f32x4_{C[0], C[1], C[2], C[3]};
+                f32x4_ q1 = s ? f32x4_{C[12], C[13], C[14], C[15]} : f32x4_{C[8], C[9], C[10], C[11]};
+                q0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[s][j], fa[i], q0, 0, 0, 0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[s][j], fa[i], q1, 0, 0, 0, 0, 0, 0);
+                if (s) { C[4] = q0[0]; C[5] = q0[1]; C[6] = q0[2]; C[7] = q0[3]; C[12] = q1[0]; C[13] = q1[1]; C[14] = q1[2]; C[15] = q1[3]; }
+                else { C[0] = q0[0]; C[1] = q0[1]; C[2] = q0[2]; C[3] = q0[3]; C[8] = q1[0]; C[9] = q1[1]; C[10] = q1[2]; C[11] = q1[3]; }
+              }
+              if constexpr (false) {
+                if (s == 0) {
+                } else {
+                }
+              } else if constexpr (false) {
+              }
+#else
               if constexpr (FIRST) {
                 if (s == 0) {
                   f32x16 zero;
@@ -270,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
               } else {
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
               }
+#endif
             }
             fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);
             __builtin_amdgcn_sched_barrier(0);
