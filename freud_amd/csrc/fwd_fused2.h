@@ -40,6 +40,9 @@
 #ifndef FF2_L1_SUNK
 #define FF2_L1_SUNK 0        // 1 = round 5's plain `l1_it += cv` (A/B: tools/build_variant.sh l1sunk -DFF2_L1_SUNK=1)
 #endif
+#ifndef FF2_EEDD
+#define FF2_EEDD 0
+#endif
 #ifndef FF2_PAIR_ROUND
 #define FF2_PAIR_ROUND 1     // round 6: the rounding of S to bf16 (CPU autocast's GEMM output) for TWO elements by one v_cvt_pk_bf16_f32, brought back
 #endif                       // to fp32 by a shift / a mask: 3 vector instructions per pair instead of 4, the same bits (0 = one cvt + shift per element)
@@ -429,7 +432,13 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         __builtin_nontemporal_store(dr[i == 42], reinterpret_cast<u32x4*>(dst_pair + (int64_t)(8 * p) * dst_rstride));
       }
       __builtin_amdgcn_sched_barrier(0);
+#if FF2_EEDD
+      // (experiment, round 6: the two MFMAs of slots 4 q + 2 and 4 q + 3 exchanged -- D E E D D E E D ... -- so that every second encoder MFMA
+      // follows its predecessor in the accumulation chain directly; same operands, same chain order, bit-identical)
+      if ((i & 3) == 0 || (i & 3) == 3) {
+#else
       if ((i & 1) == 0) {
+#endif
         const int m = i / 2, ks = m / 12, mb = (m % 12) / 3, dtl = m % 3;
         acc[4 * dtl + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Afr[3 * ks + dtl], Bq[(4 * ks + mb) & 3], acc[4 * dtl + mb], 0, 0, 0);
       } else if (i == 1) {
