@@ -430,7 +430,22 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
+#ifdef G2_PROXY16
+        // TIMING PROXY ONLY (kbench -DG2_PROXY16; results WRONG): each 32x32x16 MFMA as two 16x16x32 on the same operand registers and a
+        // quarter each of the accumulator -- what would the tile-form K loops (weight gradient, decoder) gain from the other shape?
+        {
+          typedef __attribute__((ext_vector_type(4))) float f32x4_;
+          f32x16& C = acc[m >> 1][m & 1];
+          f32x4_ q0 = (kk & 1) ? f32x4_{C[4], C[5], C[6], C[7]} : f32x4_{C[0], C[1], C[2], C[3]};
+          f32x4_ q1 = (kk & 1) ? f32x4_{C[12], C[13], C[14], C[15]} : f32x4_{C[8], C[9], C[10], C[11]};
+          q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], q0, 0, 0, 0);
+          q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], q1, 0, 0, 0);
+          if (kk & 1) { C[4] = q0[0]; C[5] = q0[1]; C[6] = q0[2]; C[7] = q0[3]; C[12] = q1[0]; C[13] = q1[1]; C[14] = q1[2]; C[15] = q1[3]; }
+          else { C[0] = q0[0]; C[1] = q0[1]; C[2] = q0[2]; C[3] = q0[3]; C[8] = q1[0]; C[9] = q1[1]; C[10] = q1[2]; C[11] = q1[3]; }
+        }
+#else
         acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][m & 1], fa[kk & 1][m >> 1], acc[m >> 1][m & 1], 0, 0, 0);   // D^T = B A^T
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF) {
           // half u = (kt, kk / 2).  Even K step: the fragments of the odd one.  Odd K step: hand-over H_u -- half u + 1 has
