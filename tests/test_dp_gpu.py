@@ -332,6 +332,15 @@ def test_two_processes_coarse_grained_buffers(tmp_path):
     _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=2, extra_env={"FREUD_P2P_FINEGRAINED": "0"})
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_statistics_on_the_communication_stream_train_the_same(tmp_path, world):
+    """FREUD_DP_STATS=stream (round 6): the fused path's batch statistics -- a pass over x and their exchange -- on the communication
+    stream under the weight preparation and the forward, instead of pushed from inside the loss finalisation between forward and
+    backward: one cross-GPU round trip less on the critical path, the same sums, so R ranks must still train like one process on R
+    times the batch (planted -1.0 entries make the exchanged count matter)."""
+    _ranks_vs_single_process(tmp_path, "l1_fused", "float32", 1, world=world, extra_env={"FREUD_DP_STATS": "stream"})
+
+
 def _ranks_vs_single_process(tmp_path, case, payload, overlap, world, extra_env=None):
     """R x B == 1 x RB on REAL kernels with the REAL exchange: two freshly spawned processes (ranks 0 and 1, both on GPU 0)
     run train() with the in-engine protocol over hipIpc peer mappings -- handles through a gloo group, batch statistics
