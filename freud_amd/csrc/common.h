@@ -143,6 +143,11 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
 }
 #endif
 
+// One 1 KiB piece (the single form of glds16_x2)
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(sbase), "v"(voff), "s"(dst) : "memory", "m0");
+}
+
 // A loop whose index is a TEMPLATE constant.  `#pragma unroll` gives up silently above LLVM's size threshold; the loop then stays
 // rolled and every register array it indexes goes to the stack (fwd_fused2.h's slot loop in round 5: 1.8 KB of scratch per lane after
 // a few added lines; topk_select_reg_kernel<44>: its key arrays, 1 KB per lane).

@@ -43,6 +43,12 @@
 #ifndef FF2_EEDD
 #define FF2_EEDD 0
 #endif
+#ifndef FF2_SPLIT_ELEM
+#define FF2_SPLIT_ELEM 1     // round 6: a pair's latent arithmetic over four gaps, three vector instructions each (see the slot loop): -4.6 % loop cycles
+#endif
+#ifndef FF2_DMA_SPREAD
+#define FF2_DMA_SPREAD 0
+#endif
 #ifndef FF2_PAIR_ROUND
 #define FF2_PAIR_ROUND 1     // round 6: the rounding of S to bf16 (CPU autocast's GEMM output) for TWO elements by one v_cvt_pk_bf16_f32, brought back
 #endif                       // to fp32 by a shift / a mask: 3 vector instructions per pair instead of 4, the same bits (0 = one cvt + shift per element)
@@ -99,6 +105,10 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     const unsigned dst = smem_base + st * FF_WT_BYTES;
     glds16_x2(src, src, voff_t[2 * p], voff_t[2 * p + 1], (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p])),
               (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + loff_t[2 * p + 1])));
+  };
+  auto dma_one = [&](int k, int jt, int st) {       // piece k (0..5) of this wave's share of W^T tile jt into ring slot st
+    const bf16_t* src = a.Wt + (int64_t)jt * FF_BN * FF_D;
+    glds16(src, voff_t[k], (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_base + st * FF_WT_BYTES + loff_t[k])));
   };
   const int last = a.ntiles - 1;
 #pragma unroll
@@ -297,6 +307,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
     f32x4 bq[4];
     float l1_it = 0.f;
     f32x2_t l1_pk = {0.f, 0.f}, pr = {0.f, 0.f};
+    unsigned se_u = 0u;
+    float se_t0 = 0.f, se_t1 = 0.f;
     bf16x8 cw;
     const f32x16 S = Scur;
 
@@ -358,7 +370,20 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
+#if FF2_DMA_SPREAD
+      // Round 6: the six LDS-DMA pieces of tile j+3 ONE per gap and four gaps apart -- two right behind this iteration's hand-over, four
+      // in the first gaps of the NEXT iteration (that body issues its predecessor's pieces 2..5: slot and source of phase PH - 1) --
+      // instead of three pairs in gaps 41 / 43 / 45.  A piece issued right behind another waits for the address path (the backward's
+      // placement sweep, bwd_fused.h: back-to-back pieces cost more each), and a gap with two of them is ~150 cycles of issue behind a
+      // 32-cycle MFMA.  The slot is free for all of them (every wave has passed the hand-over behind which tile j-1 was last read);
+      // they land a thousand cycles before the next hand-over's vmcnt wait, which still counts them (they are older than the latent
+      // store it lets pass).  First iteration: the early pieces re-copy tile 2 into slot 2 (as the prologue did); after the last one
+      // the pieces not issued are redundant copies of the last tile.
+      if (i == 41 || i == 45) dma_one((i - 41) / 4, jt, SLOT_DMA);
+      if (i == 1 || i == 5 || i == 9 || i == 13) dma_one(2 + (i - 1) / 4, j + 2 <= last ? j + 2 : last, (PH + 2) & 3);
+#else
       if (i == 41 || i == 43 || i == 45) dma_pair((i - 41) / 2, jt, SLOT_DMA);
+#endif
       if ((PH & 1) == 0 && i == 46 && w == 0) {
         const int jb = j + 2 <= a.ntiles - 2 ? j + 2 : a.ntiles - 2;
         glds4(a.bias + (int64_t)jb * FF_BN, (unsigned)(lane * 4),
@@ -391,6 +416,32 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
         cw[(e & 7) + 1] = (bf16_t)sv[1];
         if ((e & 7) == 6)      // the eight values of k-step e >> 3: one 16-byte chunk of this lane's row
           *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e >> 3)]) = cw;
+      }
+#elif FF2_SPLIT_ELEM
+      // Round 6: the latent arithmetic of a PAIR of elements spread over FOUR consecutive gaps, three vector instructions each, instead of
+      // six in each of two even gaps and none in the odd ones.  One wave per SIMD issues in order: a gap with six vector instructions,
+      // a fragment read and a wait is ~44 cycles of issue behind a 32-cycle MFMA, and the light gap next to it cannot give the time back.
+      // Same operations on the same values in the same order (the L1 additions stay e = 0, 1, 2, ...).
+      if (i >= 4 && i <= 35) {
+        const int p = (i - 4) >> 2, ph = (i - 4) & 3, e0 = 2 * p;       // pair p = elements e0, e0 + 1 (S register e <-> column n = (e&3) + 8 (e>>2) + 4 h)
+        if (ph == 0) {
+          se_u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{S[e0], S[e0 + 1]}, bf16x2));      // rounded to bf16 BEFORE the fp32 bias add (CPU autocast)
+        } else if (ph == 1) {
+          se_t0 = __uint_as_float(se_u << 16) + bq[e0 >> 2][e0 & 3];
+          se_t1 = __uint_as_float(se_u & 0xFFFF0000u);
+        } else if (ph == 2) {
+          se_t1 = se_t1 + bq[e0 >> 2][(e0 & 3) + 1];
+          se_t0 = fmaxf(se_t0, 0.f);
+          se_t1 = fmaxf(se_t1, 0.f);
+          if (PAD) { se_t0 = row_ok ? se_t0 : 0.f; se_t1 = row_ok ? se_t1 : 0.f; }
+        } else {
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(l1_it) : "v"(se_t0));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(l1_it) : "v"(se_t1));
+          cw[e0 & 7] = (bf16_t)se_t0;
+          cw[(e0 & 7) + 1] = (bf16_t)se_t1;
+          if ((e0 & 7) == 6)      // the eight values of k-step e0 >> 3: one 16-byte chunk of this lane's row
+            *reinterpret_cast<bf16x8*>(cst + PB_W * 16384 + wrow + boff[2 * HF_W + (e0 >> 3)]) = cw;
+        }
       }
 #else
       // latent element e at gap 4 + 2 e
