@@ -47,7 +47,7 @@
 #define FF2_SPLIT_ELEM 1     // round 6: a pair's latent arithmetic over four gaps, three vector instructions each (see the slot loop): -4.6 % loop cycles
 #endif
 #ifndef FF2_DMA_SPREAD
-#define FF2_DMA_SPREAD 0
+#define FF2_DMA_SPREAD 1     // round 6: the six LDS-DMA pieces one per gap, four gaps apart (see the slot loop): loop 1969 -> 1892 cycles
 #endif
 #ifndef FF2_PAIR_ROUND
 #define FF2_PAIR_ROUND 1     // round 6: the rounding of S to bf16 (CPU autocast's GEMM output) for TWO elements by one v_cvt_pk_bf16_f32, brought back
