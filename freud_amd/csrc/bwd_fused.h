@@ -111,6 +111,9 @@ constexpr int BF_DMA_A = BF_DMA_A_, BF_DMA_B = BF_DMA_B_;
 #ifndef BF_GATE_AHEAD
 #define BF_GATE_AHEAD 1      // the ReLU gate's compare one MFMA gap ahead of its select (see the gate below); 0 = both in one gap
 #endif
+#ifndef BF_DMA_SINGLE
+#define BF_DMA_SINGLE 1      // round 6: the 14 LDS-DMA pieces of a step one per second gap (1, 3, ..., 27) instead of 7 pairs in gaps 1, 5, ..., 25: 2620 -> 2581 cycles per step
+#endif
 #ifndef BF_RING
 #define BF_RING 12           // fragment ring (divides 72); the prefetch distance is BF_RING - 1 MFMAs
 #endif
@@ -124,6 +127,13 @@ __device__ __forceinline__ void glds16_x2_add(const void* sbase0, const void* sb
       :
       : "s"(sbase0), "s"(sbase1), "v"(voff0), "v"(voff1), "s"(base), "s"(l0), "s"(l1)
       : "memory", "m0", "scc");
+}
+// single pieces of the same (BF_DMA_SINGLE)
+__device__ __forceinline__ void glds16_add(const void* sbase, unsigned voff, unsigned base, unsigned l0) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(sbase), "v"(voff), "s"(base), "s"(l0) : "memory", "m0", "scc");
+}
+__device__ __forceinline__ void glds16_add_nt(const void* sbase, unsigned voff, unsigned base, unsigned l0) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" : : "s"(sbase), "v"(voff), "s"(base), "s"(l0) : "memory", "m0", "scc");
 }
 __device__ __forceinline__ void glds16_x2_add_nt(const void* sbase0, const void* sbase1, unsigned voff0, unsigned voff1, unsigned base,
                                                  unsigned l0, unsigned l1) {
@@ -221,6 +231,14 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
   for (int i = 0; i < 2; ++i) loff_cs[i] = (unsigned)__builtin_amdgcn_readfirstlane((w + 4 * i) * 1024);
   const unsigned stage_base_d[2] = {smem_base, smem_base + BF_DXH_BYTES};
   const unsigned stage_base_c[2] = {smem_base + 4 * BF_DXH_BYTES, smem_base + 4 * BF_DXH_BYTES + BF_C_BYTES};
+  auto dma_one_at = [&](int k, const bf16_t* pd, const bf16_t* px, const bf16_t* pcl, int stage) {      // piece k of 14: dx_hat / x alternating, then c
+    if (k < 12) {
+      if ((k & 1) == 0) glds16_add(pd, voff_d[k >> 1], stage_base_d[stage], loff_d[k >> 1]);
+      else glds16_add(px, voff_d[k >> 1], stage_base_d[stage], loff_x[k >> 1]);
+    } else {
+      glds16_add_nt(pcl, voff_c[k - 12], stage_base_c[stage], loff_cs[k - 12]);
+    }
+  };
   auto dma_pair_at = [&](int p, const bf16_t* pd, const bf16_t* px, const bf16_t* pcl, int stage) {
     if (p < 6) glds16_x2_add(pd, px, voff_d[p], voff_d[p], stage_base_d[stage], loff_d[p], loff_x[p]);
     else glds16_x2_add_nt(pcl, pcl, voff_c[0], voff_c[1], stage_base_c[stage], loff_cs[0], loff_cs[1]);
@@ -481,8 +499,12 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_d384_kernel(BwdFusedArgs a) 
       if (g == 72 - DIST + 1) cf[1] = load_c_s(NxtT{}, 1);
       if (g + DIST < 72) ring[(g + DIST) % RING] = load_frag_s(CurT{}, g + DIST);
       else ring[(g + DIST) % RING] = load_frag_s(NxtT{}, g + DIST - 72);
+#if BF_DMA_SINGLE
+      if (g >= 1 && (g - 1) % 2 == 0 && (g - 1) / 2 < 14) dma_one_at((g - 1) / 2, nd, nx, nc, CUR ^ 1);      // experiment: one piece per second gap
+#else
       if (g >= BF_DMA_B && (g - BF_DMA_B) % BF_DMA_A == 0 && (g - BF_DMA_B) / BF_DMA_A < 7)
         dma_pair_at((g - BF_DMA_B) / BF_DMA_A, nd, nx, nc, CUR ^ 1);
+#endif
 #else
       if (g == 72 - DIST) {
         // every read of this stage has been issued and returned, this wave's DMA pieces of the next step have landed
