@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256, 1) void fwd_fused2_d384_kernel(FwdFusedArgs a)
           se_t1 = fmaxf(se_t1, 0.f);
           if (PAD) { se_t0 = row_ok ? se_t0 : 0.f; se_t1 = row_ok ? se_t1 : 0.f; }
         } else {
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(l1_it) : "v"(se_t0));
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(l1_it) : "v"(se_t1));
+          // (one statement: between two asm statements hipcc puts an s_nop of its own)
+          asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l1_it) : "v"(se_t0), "v"(se_t1));
           cw[e0 & 7] = (bf16_t)se_t0;
           cw[(e0 & 7) + 1] = (bf16_t)se_t1;
           if ((e0 & 7) == 6)      // the eight values of k-step e0 >> 3: one 16-byte chunk of this lane's row
