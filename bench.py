@@ -800,7 +800,8 @@ def main():
     # N > 1: the OTHER carrier's number next to the headline's (north_star names RCCL; the peer exchange is auto's first choice): a short
     # leg on a fresh context after everything else is in `out`.  It runs under a watchdog thread: a carrier that hangs (RCCL can; the
     # engine's own exchange times out by itself) costs this leg, never the line -- rank 0 prints the line without it and every rank leaves.
-    other = {"p2p": "rccl", "rccl": "p2p"}.get(dp_mode) if (use_dist and world > 1 and dp_timing is not None) else None
+    # (--force-dist runs the leg with one rank as well: the only way this code path executes on a one-GPU box with the nccl backend)
+    other = {"p2p": "rccl", "rccl": "p2p"}.get(dp_mode) if (use_dist and (world > 1 or args.force_dist) and dp_timing is not None) else None
     if (other and dp_fallback is None and os.environ.get("FREUD_BENCH_OTHER_CARRIER", "1") != "0"
             and (other != "rccl" or dist.get_backend() == "nccl")):
         import threading

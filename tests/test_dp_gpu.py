@@ -733,3 +733,23 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     t = d["dp_timing"]
     assert t["ranks_counted_by_collective"] == 2 and t["collective_backend"] == "gloo", t
     assert d["value"] == pytest.approx(8192 * 2 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_bench_reports_the_other_carrier_next_to_the_headline():
+    """Every data-parallel bench line carries a short leg on the OTHER in-engine carrier (north_star names RCCL; the peer exchange is
+    auto's first choice), run on a fresh context under a watchdog after everything else is in the line.  With the nccl backend the
+    leg needs real RCCL, which two ranks cannot share on one device -- `--force-dist` runs the same code path with ONE rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FREUD_BENCH_SHARE_GPU")}
+    env["MASTER_PORT"] = str(_free_port())
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "6", "--warmup", "3", "--rows", "8192",
+                         "--no-cpu-baseline", "--spinup", "0"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    d = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    t = d["dp_timing"]
+    assert t["carrier"] == "p2p" and t["other_carrier"]["carrier"] == "rccl", t
+    assert t["other_carrier"]["healthy"] and t["other_carrier"]["ms_per_step"] > 0 and t["other_carrier"]["ranks_in_engine_communicator"] == 1, t
