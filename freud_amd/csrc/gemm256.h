@@ -51,27 +51,64 @@ __device__ __forceinline__ bf16x8 g2_frag(const char* img, int base32, int kk, i
 // row-major shape 8 % slower -- tools/kbench/gemm256_half_row.patch -- so those GEMMs hand their stages over whole.)
 __device__ __forceinline__ int g2h_piece(int w, int h, int q) { return (w >> 2) * 16 + 8 * h + 2 * (w & 3) + q; }
 
+// ---- accumulators -> the epilogues' LDS images, for both K-loop forms ------------------------------------------------------------
+// 32x32x16 loop: acc[i][j] = one 32x32 tile as f32x16.  The K loops feed the MFMA with the operands swapped -- D^T = B A^T -- so a lane holds
+// output row 32 i + lane % 32 and, per group of four accumulator registers, FOUR CONSECUTIVE COLUMNS 32 j + 8 g + 4 (lane / 32).
+// 16x16x32 loop (G2_M16): acc[i16][j16] = one 16x16 tile as f32x4 -- lane (r16 = lane % 16, q = lane / 16) holds columns 16 j16 + 4 q .. + 3
+// of row 16 i16 + r16.  Either way a lane writes 4 consecutive columns per store; the functor-side reads do not change.
+typedef __attribute__((ext_vector_type(4))) float g2_f32x4;
+__device__ __forceinline__ void g2_put_f32(const f32x16 (&acc)[4][2], float* dst0, int lane) {
+  float* dst = dst0 + (lane & 31) * GEMM_EPI_PITCH + 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<f32x4*>(dst + 32 * i * GEMM_EPI_PITCH + 32 * j + 8 * gq) =
+            f32x4{acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+}
+__device__ __forceinline__ void g2_put_f32(const g2_f32x4 (&acc)[8][4], float* dst0, int lane) {
+  float* dst = dst0 + (lane & 15) * GEMM_EPI_PITCH + 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(dst + 16 * i * GEMM_EPI_PITCH + 16 * j) = f32x4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+}
+template <int PITCH>
+__device__ __forceinline__ void g2_put_bf16(const f32x16 (&acc)[4][2], bf16_t* dst0, int lane) {
+  bf16_t* dst = dst0 + (lane & 31) * PITCH + 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<bf16x4*>(dst + 32 * i * PITCH + 32 * j + 8 * gq) =
+            bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
+}
+template <int PITCH>
+__device__ __forceinline__ void g2_put_bf16(const g2_f32x4 (&acc)[8][4], bf16_t* dst0, int lane) {
+  bf16_t* dst = dst0 + (lane & 15) * PITCH + 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<bf16x4*>(dst + 16 * i * PITCH + 16 * j) = bf16x4{(bf16_t)acc[i][j][0], (bf16_t)acc[i][j][1], (bf16_t)acc[i][j][2], (bf16_t)acc[i][j][3]};
+}
+
 // Epilogue shared by the bf16 and fp8 256x256 kernels: the tile leaves as two passes (sub-tile columns), each pass two
 // 128x128 sub-tiles (rows), one per 256-thread half, through fp32 LDS and the row-major functor.
-template <class Epi>
-__device__ __forceinline__ void g2_epilogue(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+template <class Epi, class Acc>
+__device__ __forceinline__ void g2_epilogue(Acc& acc, char* smem, int bm, int bn, int split, Epi& epi) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   float* tile = reinterpret_cast<float*>(smem);
   const int half = t >> 8, tl = t & 255;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if ((wn >> 1) == pass) {
-      // (the K loops feed the MFMA with the operands swapped -- D^T = B A^T -- so a lane holds output row 32 i + lane % 32 and,
-      // per group of four accumulator registers, FOUR CONSECUTIVE COLUMNS 32 j + 8 g + 4 (lane / 32): 16-byte LDS writes)
-      float* dst = tile + wm * G2_SUB_FLOATS + (lane & 31) * GEMM_EPI_PITCH + 64 * (wn & 1) + 4 * (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq)
-            *reinterpret_cast<f32x4*>(dst + 32 * i * GEMM_EPI_PITCH + 32 * j + 8 * gq) =
-                f32x4{acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+      g2_put_f32(acc, tile + wm * G2_SUB_FLOATS + 64 * (wn & 1), lane);
     }
     lds_barrier();
     const float* src = tile + half * G2_SUB_FLOATS;
@@ -116,8 +153,8 @@ struct epi_rounds_first { static constexpr bool value = false; };
 template <class E>
 struct epi_rounds_first<E, std::void_t<decltype(E::ROUNDS_BF16_FIRST)>> { static constexpr bool value = E::ROUNDS_BF16_FIRST; };
 
-template <bool FINAL_BARRIER, class Epi>
-__device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+template <bool FINAL_BARRIER, class Epi, class Acc>
+__device__ __forceinline__ void g2_epilogue_bf16(Acc& acc, char* smem, int bm, int bn, int split, Epi& epi) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
   const int half = t >> 8, tl = t & 255, c4 = (tl & 31) * 4;
@@ -134,17 +171,7 @@ __device__ __forceinline__ void g2_epilogue_bf16(f32x16 (&acc)[4][2], char* smem
     for (int it = 0; it < NB; ++it) dst[it] = epi.prefetch(row0 + (tl >> 5) + 8 * (b0 + it), bn * G2_BN + 128 * pass + c4);
   };
   prefetch_batch(0, pre[0]);
-  {
-    bf16_t* dst = tile + (128 * wm + (lane & 31)) * G2_BF16_PITCH + 64 * wn + 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          *reinterpret_cast<bf16x4*>(dst + 32 * i * G2_BF16_PITCH + 32 * j + 8 * gq) =
-              bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
-  }
+  g2_put_bf16<G2_BF16_PITCH>(acc, tile + (128 * wm) * G2_BF16_PITCH + 64 * wn, lane);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -179,8 +206,8 @@ struct epi_wide8 { static constexpr bool value = false; };
 template <class E>
 struct epi_wide8<E, std::void_t<decltype(E::WIDE8)>> { static constexpr bool value = G2_WIDE8 && E::WIDE8; };
 
-template <bool FINAL_BARRIER, class Epi>
-__device__ __forceinline__ void g2_epilogue_bf16_w8(f32x16 (&acc)[4][2], char* smem, int bm, int bn, int split, Epi& epi) {
+template <bool FINAL_BARRIER, class Epi, class Acc>
+__device__ __forceinline__ void g2_epilogue_bf16_w8(Acc& acc, char* smem, int bm, int bn, int split, Epi& epi) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
   const int half = t >> 8, tl = t & 255, c8 = (tl & 15) * 8;
@@ -198,17 +225,7 @@ __device__ __forceinline__ void g2_epilogue_bf16_w8(f32x16 (&acc)[4][2], char* s
     }
   };
   prefetch_batch(0, pre[0]);
-  {
-    bf16_t* dst = tile + (128 * wm + (lane & 31)) * G2_BF16_PITCH + 64 * wn + 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          *reinterpret_cast<bf16x4*>(dst + 32 * i * G2_BF16_PITCH + 32 * j + 8 * gq) =
-              bf16x4{(bf16_t)acc[i][j][4 * gq], (bf16_t)acc[i][j][4 * gq + 1], (bf16_t)acc[i][j][4 * gq + 2], (bf16_t)acc[i][j][4 * gq + 3]};
-  }
+  g2_put_bf16<G2_BF16_PITCH>(acc, tile + (128 * wm) * G2_BF16_PITCH + 64 * wn, lane);
   lds_barrier();
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -243,6 +260,9 @@ constexpr int G2_A3_LDS_BYTES = 5 * G2_OPER_BYTES;      // 3 A slots + 2 B slots
 
 #ifndef G2_A3
 #define G2_A3 1              // tools/kbench A/B switch: 0 = no three-deep A ring (Epi::DEEP_A_RING ignored)
+#endif
+#ifndef G2_M16
+#define G2_M16 1             // tools/kbench A/B switch: 0 = the row x row K loop on v_mfma_f32_32x32x16_bf16 like the other operand modes
 #endif
 #ifndef G2_HALF_KMAJOR
 #define G2_HALF_KMAJOR 1     // tools/kbench A/B switch: 0 = the k-major GEMMs hand their stages over whole, like the others
@@ -299,6 +319,17 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // Row-major x row-major (the decoder and every other GEMM whose operands both have K contiguous): the K loop runs on
+  // v_mfma_f32_16x16x32_bf16 -- 64 MFMAs of 16 cycles per K tile instead of 32 of 32, with the fragment reads and DMA pieces spread one per
+  // MFMA as in the streaming form (gemm256s.h, where the shape is described): same images, same swizzle, same ring, bit-identical output.
+  constexpr bool M16 = G2_M16 && AMODE == OP_ROW && BMODE == OP_ROW;
+  g2_f32x4 acc16[8][4];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[i][j] = g2_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   auto a_ptr = [&](int kt) -> const bf16_t* {
     const bool s1 = kt >= ktiles0;
@@ -400,11 +431,35 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
   __syncthreads();
+  // (M16) fragments of the 16x16x32 MFMA: 16 rows x 32 k -- lane (r16 = lane % 16, q = lane / 16) reads the 16-byte chunk q + 4 ks of row
+  // r16 of its row block; the chunk swizzle (chunk ^ (row >> 1 & 7)) does not depend on the block.  A fragments in a ring of four (block
+  // t + 3 requested behind block t's first MFMA), B fragments double-buffered per K step.
+  bf16x8 fa16[4], fb16[2][4];
+  int offA16[2] = {0, 0}, offB16[2] = {0, 0};
+  if constexpr (M16) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r16 = lane & 15, c = (lane >> 4) + 4 * ks;
+      const int o = r16 * 128 + ((c ^ ((r16 >> 1) & 7)) << 4);
+      offA16[ks] = o + (128 * wm) * 128;
+      offB16[ks] = o + (64 * wn) * 128;
+      asm volatile("" : "+v"(offA16[ks]), "+v"(offB16[ks]));
+    }
+  }
+  auto fragA16 = [&](const char* img, int i16, int ks) { return *reinterpret_cast<const bf16x8*>(img + (16 * i16) * 128 + offA16[ks]); };
+  auto fragB16 = [&](const char* img, int j16, int ks) { return *reinterpret_cast<const bf16x8*>(img + (16 * j16) * 128 + offB16[ks]); };
   if (kt_begin < kt_end) {
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = frag_a(smem, 128 * wm + 32 * i, 0);
+      for (int t3 = 0; t3 < 3; ++t3) fa16[t3] = fragA16(smem, t3, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[0][j] = frag_b(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, 64 * wn + 32 * j, 0);
+      for (int j = 0; j < 4; ++j) fb16[0][j] = fragB16(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, j, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[0][i] = frag_a(smem, 128 * wm + 32 * i, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[0][j] = frag_b(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, 64 * wn + 32 * j, 0);
+    }
   }
 
 #ifdef G2X_STAMP
@@ -426,6 +481,38 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       if (f < 4) fa[ks & 1][f] = frag_a(ia, 128 * wm + 32 * f, ks);
       else fb[ks & 1][f - 4] = frag_b(ib, 64 * wn + 32 * (f - 4), ks);
     };
+    if constexpr (M16) {
+      // MFMA n = 4 t + j: row block t % 8 of K step t / 8 against column block j.  Side work, one piece per MFMA: A block t + 3 at j = 0
+      // (t + 3 >= 16: the next tile's, behind the hand-over), K step 1's B fragments at n = 5..17, DMA pieces at n = 1 / 10 (A3: A tile
+      // kt + 2 into the slot tile kt - 1 left; else the second half of tile kt + 1), the hand-over at n = 50 (row block 15 was requested at
+      // n = 48: every read of this tile's images is issued), behind it tile kt + 2's other pieces and the next tile's K-step-0 B fragments.
+      static_for<0, 64>([&](auto n_tag) {
+        constexpr int n = decltype(n_tag)::value, t16 = n >> 2, ks = t16 >> 3, i16 = t16 & 7, j = n & 3;
+        // (the accumulator TIED to the destination: see gemm256s.h -- no MFMA here depends on one closer than 31 instructions before it)
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[i16][j]) : "v"(fb16[ks][j]), "v"(fa16[t16 & 3]));   // D^T = B A^T
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j == 0) {
+          constexpr int tt = t16 + 3;
+          if constexpr (tt < 16) fa16[tt & 3] = fragA16(sa, tt & 7, tt >> 3);
+          else fa16[tt & 3] = fragA16(na, tt - 16, 0);
+        }
+        if constexpr (n == 5 || n == 9 || n == 13 || n == 17) fb16[1][(n - 5) >> 2] = fragB16(sb, (n - 5) >> 2, 1);
+        if constexpr (n == 1) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 0); else issue(clampk(kt + 1), cur ^ 1, 2); }
+        if constexpr (n == 10) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 1); else issue(clampk(kt + 1), cur ^ 1, 3); }
+        if constexpr (n == 50) {
+          if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but A tile kt+2 (this wave's 4 youngest DMA instructions)
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+        if constexpr (n == 51) { if constexpr (A3) issue_bb(clampk(kt + 2), cur, 0); else issue(clampk(kt + 2), cur, 0); }
+        if constexpr (n == 53 || n == 54 || n == 57 || n == 58) {
+          constexpr int jb = n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3;
+          fb16[0][jb] = fragB16(nb, jb, 0);
+        }
+        if constexpr (n == 59) { if constexpr (A3) issue_bb(clampk(kt + 2), cur, 1); else issue(clampk(kt + 2), cur, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -520,6 +607,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    }      // (!M16)
     cur ^= 1;
     aslot = anext;
   }
@@ -529,9 +617,15 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #ifdef G2X_STAMP
   st2 = __builtin_readcyclecounter();
 #endif
-  if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<PERSIST>(acc, smem, bm, bn, split, epi);
-  else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc, smem, bm, bn, split, epi);
-  else g2_epilogue(acc, smem, bm, bn, split, epi);      // (both end with a barrier: LDS is free again)
+  if constexpr (M16) {
+    if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<PERSIST>(acc16, smem, bm, bn, split, epi);
+    else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc16, smem, bm, bn, split, epi);
+    else g2_epilogue(acc16, smem, bm, bn, split, epi);
+  } else {
+    if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<PERSIST>(acc, smem, bm, bn, split, epi);
+    else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc, smem, bm, bn, split, epi);
+    else g2_epilogue(acc, smem, bm, bn, split, epi);      // (both end with a barrier: LDS is free again)
+  }
 #ifdef G2X_STAMP
   if (threadIdx.x == 0 && g2x_stamps) {
     unsigned long long st3 = __builtin_readcyclecounter();
