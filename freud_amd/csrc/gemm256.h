@@ -264,6 +264,9 @@ constexpr int G2_A3_LDS_BYTES = 5 * G2_OPER_BYTES;      // 3 A slots + 2 B slots
 #ifndef G2_M16
 #define G2_M16 1             // tools/kbench A/B switch: 0 = the row x row K loop on v_mfma_f32_32x32x16_bf16 like the other operand modes
 #endif
+#ifndef G2_M16K
+#define G2_M16K 0            // 1 = the k-major x k-major K loop (weight gradient, half ring) on v_mfma_f32_16x16x32_bf16 as well (see the loop)
+#endif
 #ifndef G2_HALF_KMAJOR
 #define G2_HALF_KMAJOR 1     // tools/kbench A/B switch: 0 = the k-major GEMMs hand their stages over whole, like the others
 #endif
@@ -324,7 +327,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   // MFMA as in the streaming form (gemm256s.h, where the shape is described): same images, same swizzle, same ring, bit-identical output.
   constexpr bool M16 = G2_M16 && AMODE == OP_ROW && BMODE == OP_ROW;
   g2_f32x4 acc16[8][4];
-  if constexpr (M16) {
+  if constexpr (M16 || (G2_M16K && G2_HALF_KMAJOR && AMODE == OP_KMAJOR && BMODE == OP_KMAJOR)) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -386,6 +389,32 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       voff_b[q] = g2_src_off<BMODE>(g2h_piece(w, q >> 1, q & 1), lane, g.ldb);
     }
   }
+  // (M16K) the half ring's K loop on v_mfma_f32_16x16x32_bf16: one 32-deep K step = one half.  Transposed fragment reads of a 16-column block
+  // `blk` of a k-major image: the 16-lane group G = lane / 16 reads k rows 32 h + 8 G + q (q = lane % 16 / 4) and + 4, columns 16 blk + 4 p ..
+  // + 3 (p = lane % 4), and receives column lane % 16 with k = 8 G .. 8 G + 7 -- the operand layout of the instruction.  In the image's chunk
+  // swizzle (chunk ^ ((row & 3) << 2 | (row >> 2 & 3))) the block enters as an XOR of address bits 5-7 and the second read is the first's
+  // address ^ 16, + 1024: two lane offsets per operand serve every read; the half is an immediate (8192 h).  Conflict-free: the two groups of a
+  // 32-lane service half sit 8 rows apart, their swizzles differ in chunk bit 1, each covers eight distinct 16-byte chunks.
+  constexpr bool M16K = G2_M16K && HALF;
+  unsigned ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
+  if constexpr (M16K) {
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int swz = (q << 2) | ((2 * G) & 3);
+    const int rowb = (8 * G + q) * 256 + 8 * (p & 1);
+    ka0 = (unsigned)(rowb + (((p >> 1) ^ swz) << 4) + wm * 16384);
+    kb0 = (unsigned)(rowb + ((((p >> 1) ^ swz) ^ (8 * (wn & 1))) << 4) + (wn >> 1) * 16384 + G2_OPER_BYTES);
+    ka1 = ka0 ^ 16u;
+    kb1 = kb0 ^ 16u;
+    asm volatile("" : "+v"(ka0), "+v"(ka1), "+v"(kb0), "+v"(kb1));
+  }
+  auto tr16 = [&](unsigned o0, unsigned o1, int blk, int h) -> bf16x8 {
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const unsigned x = (unsigned)blk << 5;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(uintptr_t)((o0 ^ x) + 8192u * h));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(uintptr_t)((o1 ^ x) + 8192u * h + 1024u));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
   auto issue_h = [&](int kt, int stage, int h, int q) {
     const unsigned dst = smem_base + stage * G2_STAGE_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(g2h_piece(w, h, q) * 1024);
     glds16_x2(a_ptr(kt), b_ptr(kt), voff_a[2 * h + q], voff_b[2 * h + q], dst, dst + G2_OPER_BYTES);
@@ -449,7 +478,12 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   auto fragA16 = [&](const char* img, int i16, int ks) { return *reinterpret_cast<const bf16x8*>(img + (16 * i16) * 128 + offA16[ks]); };
   auto fragB16 = [&](const char* img, int j16, int ks) { return *reinterpret_cast<const bf16x8*>(img + (16 * j16) * 128 + offB16[ks]); };
   if (kt_begin < kt_end) {
-    if constexpr (M16) {
+    if constexpr (M16K) {
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3) fa16[t3] = tr16(smem_base + ka0, smem_base + ka1, t3, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb16[0][j] = tr16(smem_base + kb0, smem_base + kb1, j, 0);
+    } else if constexpr (M16) {
 #pragma unroll
       for (int t3 = 0; t3 < 3; ++t3) fa16[t3] = fragA16(smem, t3, 0);
 #pragma unroll
@@ -481,7 +515,37 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       if (f < 4) fa[ks & 1][f] = frag_a(ia, 128 * wm + 32 * f, ks);
       else fb[ks & 1][f - 4] = frag_b(ib, 64 * wn + 32 * (f - 4), ks);
     };
-    if constexpr (M16) {
+    if constexpr (M16K) {
+      // half h of the tile = MFMAs 32 h .. 32 h + 31: m = 4 t + j, A block t against B block j.  A block t + 3 behind block t's first MFMA (t + 3 >= 8:
+      // the next half's, behind the hand-over); the hand-over H_u at m = 18 (block 7 was requested at m = 16; half u + 1 has landed: all but this
+      // wave's 8 youngest DMA instructions); behind it the next half's four B fragments and half u + 4's two DMA pairs into the freed slot.
+      const unsigned cb = smem_base + (unsigned)cur * G2_STAGE_BYTES, nx = smem_base + (unsigned)(cur ^ 1) * G2_STAGE_BYTES;
+      const unsigned a0c = cb + ka0, a1c = cb + ka1, b0c = cb + kb0, b1c = cb + kb1;
+      const unsigned a0n = nx + ka0, a1n = nx + ka1, b0n = nx + kb0, b1n = nx + kb1;
+      static_for<0, 64>([&](auto n_tag) {
+        constexpr int n = decltype(n_tag)::value, h = n >> 5, m = n & 31, t16 = m >> 2, j = m & 3;
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[t16][j]) : "v"(fb16[h][j]), "v"(fa16[t16 & 3]));   // D^T = B A^T
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j == 0) {
+          constexpr int tt = t16 + 3;
+          if constexpr (tt < 8) fa16[tt & 3] = tr16(a0c, a1c, tt, h);
+          else if constexpr (h == 0) fa16[tt & 3] = tr16(a0c, a1c, tt - 8, 1);
+          else fa16[tt & 3] = tr16(a0n, a1n, tt - 8, 0);
+        }
+        if constexpr (m == 18) {
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          __syncthreads();
+        }
+        if constexpr (m == 19 || m == 21 || m == 22 || m == 23) {
+          constexpr int jb = m == 19 ? 0 : m - 20;
+          if constexpr (h == 0) fb16[1][jb] = tr16(b0c, b1c, jb, 1);
+          else fb16[0][jb] = tr16(b0n, b1n, jb, 0);
+        }
+        if constexpr (m == 26) issue_h(clampk(kt + 2), cur, h, 0);
+        if constexpr (m == 30) issue_h(clampk(kt + 2), cur, h, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else if constexpr (M16) {
       // MFMA n = 4 t + j: row block t % 8 of K step t / 8 against column block j.  Side work, one piece per MFMA: A block t + 3 at j = 0
       // (t + 3 >= 16: the next tile's, behind the hand-over), K step 1's B fragments at n = 5..17, DMA pieces at n = 1 / 10 (A3: A tile
       // kt + 2 into the slot tile kt - 1 left; else the second half of tile kt + 1), the hand-over at n = 50 (row block 15 was requested at
@@ -617,7 +681,7 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
 #ifdef G2X_STAMP
   st2 = __builtin_readcyclecounter();
 #endif
-  if constexpr (M16) {
+  if constexpr (M16 || M16K) {
     if constexpr (epi_rounds_first<Epi>::value && epi_wide8<Epi>::value) g2_epilogue_bf16_w8<PERSIST>(acc16, smem, bm, bn, split, epi);
     else if constexpr (epi_rounds_first<Epi>::value) g2_epilogue_bf16<PERSIST>(acc16, smem, bm, bn, split, epi);
     else g2_epilogue(acc16, smem, bm, bn, split, epi);
