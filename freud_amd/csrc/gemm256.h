@@ -264,8 +264,11 @@ constexpr int G2_A3_LDS_BYTES = 5 * G2_OPER_BYTES;      // 3 A slots + 2 B slots
 #ifndef G2_M16
 #define G2_M16 1             // tools/kbench A/B switch: 0 = the row x row K loop on v_mfma_f32_32x32x16_bf16 like the other operand modes
 #endif
+#ifndef G2_RUNPTR
+#define G2_RUNPTR 1          // tools/kbench A/B switch: 0 = the 16x16x32 loops form tile kt + 2's source pointers anew per K tile
+#endif
 #ifndef G2_M16K
-#define G2_M16K 0            // 1 = the k-major x k-major K loop (weight gradient, half ring) on v_mfma_f32_16x16x32_bf16 as well (see the loop)
+#define G2_M16K 1            // tools/kbench A/B switch: 0 = the k-major x k-major K loop (weight gradient, half ring) on v_mfma_f32_32x32x16_bf16
 #endif
 #ifndef G2_HALF_KMAJOR
 #define G2_HALF_KMAJOR 1     // tools/kbench A/B switch: 0 = the k-major GEMMs hand their stages over whole, like the others
@@ -430,6 +433,37 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
   // and the last group ran its barrier + 4 DMA pieces + 6 reads before its first MFMA.
   const int kt_last = kt_end - 1;
   auto clampk = [&](int kt) { return kt < kt_last ? kt : kt_last; };   // past-the-end tiles re-copy the last one (harmless)
+  // (16x16x32 loops) the source tile origins of K tile min(kt + 2, last) as RUNNING pointers: a_ptr() / b_ptr() are a segment select and a
+  // 64-bit multiply by the leading dimension each -- 43 scalar instructions in one MFMA gap per K tile, at the same moment in both waves of a
+  // SIMD (they leave the same barrier): here a compare, a select and a 64-bit add
+  constexpr bool RUN2 = G2_RUNPTR && ((M16 && A3) || M16K);
+  const bf16_t* pa2 = nullptr;
+  const bf16_t* pb2 = nullptr;
+  const bf16_t* pa2_seg1 = nullptr;
+  const bf16_t* pb2_seg1 = nullptr;
+  int64_t pa2_step = 0, pb2_step = 0;
+  if constexpr (RUN2) {
+    if (kt_begin < kt_end) {
+      pa2 = a_ptr(clampk(kt_begin + 2));
+      pb2 = b_ptr(clampk(kt_begin + 2));
+    }
+    pa2_seg1 = AMODE == OP_ROW ? g.A1 + (int64_t)(bm * G2_BM) * g.lda : g.A1 + bm * G2_BM;
+    pb2_seg1 = BMODE == OP_ROW ? g.B1 + (int64_t)(bn * G2_BN) * g.ldb : g.B1 + bn * G2_BN;
+    pa2_step = AMODE == OP_ROW ? (int64_t)GEMM_BK : (int64_t)GEMM_BK * g.lda;
+    pb2_step = BMODE == OP_ROW ? (int64_t)GEMM_BK : (int64_t)GEMM_BK * g.ldb;
+  }
+  auto issue_aa2 = [&](int slot, int qp) {
+    const unsigned dst = smem_base + slot * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(pa2, pa2, voff_a[2 * qp], voff_a[2 * qp + 1], dst, dst + 1024);
+  };
+  auto issue_bb2 = [&](int slot, int qp) {
+    const unsigned dst = smem_base + (3 + slot) * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(pb2, pb2, voff_b[2 * qp], voff_b[2 * qp + 1], dst, dst + 1024);
+  };
+  auto issue_h2 = [&](int stage, int h, int q) {
+    const unsigned dst = smem_base + stage * G2_STAGE_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(g2h_piece(w, h, q) * 1024);
+    glds16_x2(pa2, pb2, voff_a[2 * h + q], voff_b[2 * h + q], dst, dst + G2_OPER_BYTES);
+  };
   bf16x8 fa[2][4], fb[2][2];
   auto frag_a = [&](const char* img, int base32, int ks) { return g2_frag<AMODE>(img, base32, ks, lane); };
   auto frag_b = [&](const char* img, int base32, int ks) { return g2_frag<BMODE>(img, base32, ks, lane); };
@@ -541,8 +575,8 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
           if constexpr (h == 0) fb16[1][jb] = tr16(b0c, b1c, jb, 1);
           else fb16[0][jb] = tr16(b0n, b1n, jb, 0);
         }
-        if constexpr (m == 26) issue_h(clampk(kt + 2), cur, h, 0);
-        if constexpr (m == 30) issue_h(clampk(kt + 2), cur, h, 1);
+        if constexpr (m == 26) { if constexpr (RUN2) issue_h2(cur, h, 0); else issue_h(clampk(kt + 2), cur, h, 0); }
+        if constexpr (m == 30) { if constexpr (RUN2) issue_h2(cur, h, 1); else issue_h(clampk(kt + 2), cur, h, 1); }
         __builtin_amdgcn_sched_barrier(0);
       });
     } else if constexpr (M16) {
@@ -561,19 +595,19 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
           else fa16[tt & 3] = fragA16(na, tt - 16, 0);
         }
         if constexpr (n == 5 || n == 9 || n == 13 || n == 17) fb16[1][(n - 5) >> 2] = fragB16(sb, (n - 5) >> 2, 1);
-        if constexpr (n == 1) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 0); else issue(clampk(kt + 1), cur ^ 1, 2); }
-        if constexpr (n == 10) { if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 1); else issue(clampk(kt + 1), cur ^ 1, 3); }
+        if constexpr (n == 1) { if constexpr (RUN2) issue_aa2(aprev, 0); else if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 0); else issue(clampk(kt + 1), cur ^ 1, 2); }
+        if constexpr (n == 10) { if constexpr (RUN2) issue_aa2(aprev, 1); else if constexpr (A3) issue_aa(clampk(kt + 2), aprev, 1); else issue(clampk(kt + 1), cur ^ 1, 3); }
         if constexpr (n == 50) {
           if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but A tile kt+2 (this wave's 4 youngest DMA instructions)
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         }
-        if constexpr (n == 51) { if constexpr (A3) issue_bb(clampk(kt + 2), cur, 0); else issue(clampk(kt + 2), cur, 0); }
+        if constexpr (n == 51) { if constexpr (RUN2) issue_bb2(cur, 0); else if constexpr (A3) issue_bb(clampk(kt + 2), cur, 0); else issue(clampk(kt + 2), cur, 0); }
         if constexpr (n == 53 || n == 54 || n == 57 || n == 58) {
           constexpr int jb = n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3;
           fb16[0][jb] = fragB16(nb, jb, 0);
         }
-        if constexpr (n == 59) { if constexpr (A3) issue_bb(clampk(kt + 2), cur, 1); else issue(clampk(kt + 2), cur, 1); }
+        if constexpr (n == 59) { if constexpr (RUN2) issue_bb2(cur, 1); else if constexpr (A3) issue_bb(clampk(kt + 2), cur, 1); else issue(clampk(kt + 2), cur, 1); }
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -672,6 +706,14 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       }
     }
     }      // (!M16)
+    if constexpr (RUN2) {      // -> the origins of tile min(kt + 3, last)
+      const int kn = kt + 3;
+      if (kn <= kt_last) {
+        const bool seg = kn == ktiles0;
+        pa2 = seg ? pa2_seg1 : pa2 + pa2_step;
+        pb2 = seg ? pb2_seg1 : pb2 + pb2_step;
+      }
+    }
     cur ^= 1;
     aslot = anext;
   }
