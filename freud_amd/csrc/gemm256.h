@@ -11,6 +11,9 @@
 //   barrier (see the loop) so that tile t+1's first fragments and tile t+2's DMA are in flight under tile t's last MFMAs.
 //   Epilogue: the tile leaves as four 128x128 sub-tiles through fp32 LDS, two at a time, one per 256-thread half,
 //   through the same functors as gemm.h (their block reductions are 256-thread-group local).
+//   Round 6: when both operands have the same layout the K loop runs on v_mfma_f32_16x16x32_bf16 instead -- 8x4 tiles of 16x16 per wave, 64
+//   MFMAs of 16 cycles per K tile, one piece of side work per MFMA (G2_M16: row x row, the decoder; G2_M16K: k-major x k-major through the
+//   half ring, the weight gradient) -- with the same images, swizzles, rings and epilogues, bit-identical output; the mixed forms keep 32x32x16.
 #pragma once
 #include "gemm.h"
 
