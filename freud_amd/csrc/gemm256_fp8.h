@@ -21,6 +21,10 @@
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+#ifndef G8_SPREAD
+#define G8_SPREAD 1          // tools/build_variant.sh A/B switch: 0 = the K loops' side work clustered in front of each 8-MFMA group (rounds 2-5)
+#endif
+
 struct Gemm8Args {
   const unsigned char* A;   // [rows_a][lda] fp8, K contiguous
   const unsigned char* B;   // [rows_b][ldb] fp8, K contiguous
@@ -115,6 +119,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
   for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + (A3 ? 3 : 1) * G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
 
   int cur = 0, aslot = 0;
+#if G8_SPREAD
+  // source origins of K tiles min(kt + 1, last) and min(kt + 2, last), carried (an add per K tile instead of a clamp + multiply per DMA call)
+  const unsigned char* r1a = a_base + (int64_t)clampk(1) * 128;
+  const unsigned char* r1b = b_base + (int64_t)clampk(1) * 128;
+  const unsigned char* r2a = a_base + (int64_t)clampk(2) * 128;
+  const unsigned char* r2b = b_base + (int64_t)clampk(2) * 128;
+  auto issue_p = [&](const unsigned char* pa, const unsigned char* pb, int stage, int q) {
+    const unsigned dst = smem_base + stage * G2_STAGE_BYTES + piece0 + q * 1024;
+    glds16_x2(pa, pb, voff_a[q], voff_b[q], dst, dst + G2_OPER_BYTES);
+  };
+  auto issue_aa_p = [&](const unsigned char* src, int slot, int qp) {
+    const unsigned dst = smem_base + slot * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(src, src, voff_a[2 * qp], voff_a[2 * qp + 1], dst, dst + 1024);
+  };
+  auto issue_bb_p = [&](const unsigned char* src, int slot, int qp) {
+    const unsigned dst = smem_base + (3 + slot) * G2_OPER_BYTES + piece0 + 2 * qp * 1024;
+    glds16_x2(src, src, voff_b[2 * qp], voff_b[2 * qp + 1], dst, dst + 1024);
+  };
+#endif
   for (int kt = 0; kt < g.ktiles; ++kt) {
     const int anext = aslot == 2 ? 0 : aslot + 1, aprev = anext == 2 ? 0 : anext + 1;
     const char* sa = A3 ? smem + aslot * G2_OPER_BYTES : smem + cur * G2_STAGE_BYTES;
@@ -127,6 +150,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
       const char* xa = s == 0 ? sa : na;
       const char* xb = s == 0 ? sb : nb;
       const int xs = s == 0 ? 1 : 0;
+#if G8_SPREAD
+      // Side work one piece per MFMA gap (round 6: clustered in front of the group -- two DMA calls with their address arithmetic, the hand-over
+      // and two fragment reads, ~45 instructions -- it sat in BOTH waves of a SIMD at the same moment, right behind the barrier they share, and a
+      // 64-cycle MFMA covers 16 issue slots, not 45).  MFMA m = 2 i + j; behind it: m odd -> A fragment i of the next step (its registers are
+      // free); m = 4 / 6 -> the next step's B fragments (the other buffer); step 0: m = 0 / 2 -> the DMA calls of tile kt + 1's second half
+      // (A3: A tile kt + 2); step 1: m = 0 -> the hand-over (every read of this stage was issued in step 0; the first read of the next stage
+      // follows at m = 1), m = 2 / 4 -> tile kt + 2's first half (A3: B tile kt + 2) into the freed stage.
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int i = m >> 1, j = m & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);   // D^T = B A^T (g2_epilogue)
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 1) fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);
+        if (m == 4) fb[xs][0] = g8_frag(xb, 64 * wn, xs, lane);
+        if (m == 6) fb[xs][1] = g8_frag(xb, 64 * wn + 32, xs, lane);
+        if (s == 0) {
+          if (m == 0) { if constexpr (A3) issue_aa_p(r2a, aprev, 0); else issue_p(r1a, r1b, cur ^ 1, 2); }
+          if (m == 2) { if constexpr (A3) issue_aa_p(r2a, aprev, 1); else issue_p(r1a, r1b, cur ^ 1, 3); }
+        } else {
+          if (m == 0) {
+            if constexpr (A3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but A tile kt+2 (this wave's 4 youngest DMA instructions)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+            __syncthreads();                                    // ... and everybody's; every read of this stage has returned
+          }
+          if (m == 2) { if constexpr (A3) issue_bb_p(r2b, cur, 0); else issue_p(r2a, r2b, cur, 0); }
+          if (m == 4) { if constexpr (A3) issue_bb_p(r2b, cur, 1); else issue_p(r2a, r2b, cur, 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       if (s == 0) {            // second half of tile kt+1's pieces (its first half left right after the last hand-over)
         if constexpr (A3) {    // ... A3: A tile kt+2 into the slot tile kt-1 left
           issue_aa(clampk(kt + 2), aprev, 0);
@@ -158,7 +211,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(Gemm8Args g, Epi ep
         fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);     // its registers are free: next step's fragment i
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
+#if G8_SPREAD
+    {
+      const int64_t step = kt + 3 <= kt_last ? 128 : 0;
+      r1a = r2a; r1b = r2b;
+      r2a += step; r2b += step;
+    }
+#endif
     cur ^= 1;
     aslot = anext;
   }
@@ -220,6 +281,13 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
     for (int j = 0; j < 2; ++j) fb[0][j] = g8_frag(smem + G2_OPER_BYTES, 64 * wn + 32 * j, 0, lane);
     f32x16 acc[4][2];        // (started from a zero MFMA source by the first K step of every tile: gemm256s.h)
     int cur = 0;
+#if G8_SPREAD
+    // origins of the stream's K tiles kt + 1 and kt + 2 (carried: a select and an add per K tile instead of two per DMA group)
+    const unsigned char* q1a = a_cur + 128;
+    const unsigned char* q1b = b_cur + 128;
+    const unsigned char* q2a = a_cur + 256;
+    const unsigned char* q2b = b_cur + 256;
+#endif
     for (;;) {
       const int nblk = blk + gridDim.x;
       const bool more = nblk < ntiles;
@@ -229,6 +297,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
       const unsigned char* b_nxt = more ? g.B + (int64_t)(bn2 * G2_BN) * g.ldb : b_cur + (int64_t)(nk - 2) * 128;
       auto pa = [&](int j) { return j < nk ? a_cur + (int64_t)j * 128 : a_nxt + (int64_t)(j - nk) * 128; };
       auto pb = [&](int j) { return j < nk ? b_cur + (int64_t)j * 128 : b_nxt + (int64_t)(j - nk) * 128; };
+#if G8_SPREAD
+      if (nk == 2) { q2a = a_nxt; q2b = b_nxt; }      // (two K tiles per output tile: stream tile 2 is the NEXT output tile's first, known only now)
+#endif
       const int row_w = bm * G2_BM + 128 * wm, col_l = bn * G2_BN + 64 * wn + c8;
       typename Epi::SPre pre0[4];
       auto ktile = [&](auto first_tag, int kt) {
@@ -242,6 +313,41 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
           const char* xa = s == 0 ? sa : na;
           const char* xb = s == 0 ? sb : nb;
           const int xs = s == 0 ? 1 : 0;
+#if G8_SPREAD
+          // (one piece of side work per MFMA gap and carried source origins: see gemm256_fp8_kernel and gemm256s.h)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const int i = m >> 1, j = m & 1;
+            if constexpr (FIRST) {
+              if (s == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], zero, 0, 0, 0, 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+              }
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[s][j], fa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 1) fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);
+            if (m == 4) fb[xs][0] = g8_frag(xb, 64 * wn, xs, lane);
+            if (m == 6) fb[xs][1] = g8_frag(xb, 64 * wn + 32, xs, lane);
+            if (s == 0) {
+              if (m == 0) issue(q1a, q1b, cur ^ 1, 2);
+              if (m == 2) issue(q1a, q1b, cur ^ 1, 3);
+            } else {
+              if (m == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+              }
+              if (m == 2) issue(q2a, q2b, cur, 0);
+              if (m == 4) issue(q2a, q2b, cur, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
           if (s == 0) {
             issue(pa(kt + 1), pb(kt + 1), cur ^ 1, 2);
             issue(pa(kt + 1), pb(kt + 1), cur ^ 1, 3);
@@ -295,7 +401,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_fp8_kernel(Gemm8Args g, Epi e
             fa[i] = g8_frag(xa, 128 * wm + 32 * i, xs, lane);
             __builtin_amdgcn_sched_barrier(0);
           }
+#endif
         }
+#if G8_SPREAD
+        {   // the stream's tile kt + 3: this output tile's, or the first of the next one's (gemm256s.h)
+          const bool wrap = kt + 3 == nk;
+          q1a = q2a; q1b = q2b;
+          q2a = wrap ? a_nxt : q2a + 128;
+          q2b = wrap ? b_nxt : q2b + 128;
+        }
+#endif
         cur ^= 1;
       };
       ktile(std::true_type{}, 0);

@@ -45,6 +45,10 @@ struct epi_stream<E, std::void_t<decltype(E::STREAM)>> { static constexpr bool v
 #ifndef G2S_STATIC
 #define G2S_STATIC 1         // round 6: the K loop unrolled over the two LDS stages (compile-time stage; K tiles per output tile must be EVEN:
 #endif                       // the host launches the streaming form only then).  0 = round 5's loop with a run-time stage
+#ifndef G2S_RUNPTR
+#define G2S_RUNPTR 1          // the 16x16x32 loop carries the source origins of the stream's K tiles kt + 1 / kt + 2 instead of forming them (a select and
+                              // a 64-bit add per operand and DMA gap, twice per K tile, in both waves of a SIMD at once)
+#endif
 #ifndef G2S_M16
 #define G2S_M16 (G2S_STATIC)  // round 6: the K loop on v_mfma_f32_16x16x32_bf16 (needs the static-stage form).  The chip is power-managed and holds a higher
 #endif                        // clock on this shape: stand-alone, random operands, K = 1280: 5.50 -> 4.97 ms as a timing proxy (profiles/r06_kbench_proxy16.txt)
@@ -331,6 +335,13 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
     unsigned long long st_loop = 0, st_epi = 0, st_tiles = 0;
     const unsigned long long st_k0 = __builtin_readcyclecounter();
 #endif
+#if G2S_M16 && G2S_RUNPTR
+    // origins of the stream's K tiles kt + 1 and kt + 2 (nk == 2: tile 2 is the next output tile's first -- set at the top of the tile loop)
+    const bf16_t* q1a = a_cur + GEMM_BK;
+    const bf16_t* q1b = b_cur + GEMM_BK;
+    const bf16_t* q2a = a_cur + 2 * GEMM_BK;
+    const bf16_t* q2b = b_cur + 2 * GEMM_BK;
+#endif
     for (;;) {
       // the tile behind this one in the workgroup's walk (none: the stream ends by re-copying this tile's last K tile, harmless)
       const int nblk = blk + gridDim.x;
@@ -342,6 +353,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
       // K tile j of the stream as seen from this tile: j < nk this tile's, j >= nk the next tile's j - nk
       auto pa = [&](int j) { return j < nk ? a_cur + (int64_t)j * GEMM_BK : a_nxt + (int64_t)(j - nk) * GEMM_BK; };
       auto pb = [&](int j) { return j < nk ? b_cur + (int64_t)j * GEMM_BK : b_nxt + (int64_t)(j - nk) * GEMM_BK; };
+#if G2S_M16 && G2S_RUNPTR
+      if (nk == 2) { q2a = a_nxt; q2b = b_nxt; }      // (two K tiles per output tile: stream tile 2 is the NEXT output tile's first, known only now)
+#endif
       const int row_w = bm * G2_BM + 128 * wm, col_l = bn * G2_BN + 64 * wn + c8;
       typename Epi::SPre pre0[4];
 #ifdef G2X_STAMP
@@ -386,17 +400,38 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_kernel(GemmArgs g, Epi e
             else fa16[tt & 3] = fragA16(CUR ^ 1, tt - 16, 0);
           }
           if constexpr (n == 5 || n == 9 || n == 13 || n == 17) fb16[1][(n - 5) >> 2] = fragB16(CUR, (n - 5) >> 2, 1);
+#if G2S_RUNPTR
+          if constexpr (n == 1) issue(q1a, q1b, CUR ^ 1, 2);
+          if constexpr (n == 10) issue(q1a, q1b, CUR ^ 1, 3);
+#else
           if constexpr (n == 1) issue(pa(kt + 1), pb(kt + 1), CUR ^ 1, 2);
           if constexpr (n == 10) issue(pa(kt + 1), pb(kt + 1), CUR ^ 1, 3);
+#endif
           if constexpr (n == 50) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
           }
+#if G2S_RUNPTR
+          if constexpr (n == 51) issue(q2a, q2b, CUR, 0);
+#else
           if constexpr (n == 51) issue(pa(kt + 2), pb(kt + 2), CUR, 0);
+#endif
           if constexpr (n == 53 || n == 54 || n == 57 || n == 58) fb16[0][n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3] = fragB16(CUR ^ 1, n == 53 ? 0 : n == 54 ? 1 : n == 57 ? 2 : 3, 0);
+#if G2S_RUNPTR
+          if constexpr (n == 59) issue(q2a, q2b, CUR, 1);
+#else
           if constexpr (n == 59) issue(pa(kt + 2), pb(kt + 2), CUR, 1);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         });
+#if G2S_RUNPTR
+        {   // the stream's tile kt + 3: this output tile's, or the first of the next one's (its second and third follow by + GEMM_BK)
+          const bool wrap = kt + 3 == nk;
+          q1a = q2a; q1b = q2b;
+          q2a = wrap ? a_nxt : q2a + GEMM_BK;
+          q2b = wrap ? b_nxt : q2b + GEMM_BK;
+        }
+#endif
       };
 #endif
 #if G2S_STATIC
