@@ -230,41 +230,47 @@ struct EpiEnc8 {
   // bf16-rounded accumulator) and the second, e4m3 copy of the latent
   static constexpr bool STREAM = true;
   struct SPre {};
-  f32x4 sb0, sb1;
-  __device__ void s_begin() { l1 = 0.f; }
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 sbp[4], invp, scp, l1p;      // bias pairs, 1 / (s_x s_w), s_c, the L1 sum as a pair of partial sums
+  __device__ void s_begin() { l1 = 0.f; l1p = f32x2{0.f, 0.f}; }
   __device__ int64_t s_rows() const { return M; }
   __device__ void s_tile(int, int col) {
-    sb0 = *reinterpret_cast<const f32x4*>(bias + col);
-    sb1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+    sbp[0] = f32x2{b0[0], b0[1]}; sbp[1] = f32x2{b0[2], b0[3]}; sbp[2] = f32x2{b1[0], b1[1]}; sbp[3] = f32x2{b1[2], b1[3]};
     inv = scal8[S8_INV_ENC];
     sc = scal8[S8_SC];
+    invp = f32x2{inv, inv};
+    scp = f32x2{sc, sc};
   }
   __device__ SPre s_prefetch(int, int) const { return SPre{}; }
+  // Round 6: packed arithmetic, 28 vector instructions per 8 latents (the element-wise form, with its bf16 re-rounding of v / (s_x s_w) spelled
+  // out as convert + shift, was ~70 -- in a kernel whose K loop is only ten K tiles long, so that the epilogue was a fifth of a tile).  v is the
+  // accumulator ALREADY rounded to bf16 and 1 / (s_x s_w) a power of two: v inv is exact, so fma(v, inv, b) IS bf16(v inv) + b, bit for bit.
   template <bool PARTIAL>
   __device__ void s_apply(int row, int col, f32x4 v0, f32x4 v1, const SPre&) {
-    bf16x8 o;
-    float cv[8];
+    f32x2 sv[4] = {__builtin_elementwise_fma(f32x2{v0[0], v0[1]}, invp, sbp[0]), __builtin_elementwise_fma(f32x2{v0[2], v0[3]}, invp, sbp[1]),
+                   __builtin_elementwise_fma(f32x2{v1[0], v1[1]}, invp, sbp[2]), __builtin_elementwise_fma(f32x2{v1[2], v1[3]}, invp, sbp[3])};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      cv[j] = fmaxf(bf16_round(v0[j] * inv) + sb0[j], 0.f);
-      cv[4 + j] = fmaxf(bf16_round(v1[j] * inv) + sb1[j], 0.f);
-      if (PARTIAL && row >= M) cv[j] = cv[4 + j] = 0.f;
-      l1 += cv[j] + cv[4 + j];
-      o[j] = (bf16_t)cv[j];
-      o[4 + j] = (bf16_t)cv[4 + j];
+    for (int k = 0; k < 4; ++k) {
+      sv[k] = f32x2{fmaxf(sv[k][0], 0.f), fmaxf(sv[k][1], 0.f)};
+      if (PARTIAL && row >= M) sv[k] = f32x2{0.f, 0.f};
+      l1p += sv[k];
     }
     // (timing experiment of round 5, `-DFP8_SKIP_BF16`: no bf16 copy of the latent -- the upper bound of what a single latent store buys:
     // encoder 7.38 -> 6.64 ms at C5, profiles/r05_fp8_single_store_bound.txt; as a run-time flag it cost this kernel 6 spill instructions)
 #ifndef FP8_SKIP_BF16
+    const bf16x8 o = {(bf16_t)sv[0][0], (bf16_t)sv[0][1], (bf16_t)sv[1][0], (bf16_t)sv[1][1],
+                      (bf16_t)sv[2][0], (bf16_t)sv[2][1], (bf16_t)sv[3][0], (bf16_t)sv[3][1]};
     EPI_STORE(reinterpret_cast<bf16x8*>(c + (int64_t)row * n_p + col), o);
 #endif
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-    const u32x2 q = {pack4_fp8(cv[0] * sc, cv[1] * sc, cv[2] * sc, cv[3] * sc), pack4_fp8(cv[4] * sc, cv[5] * sc, cv[6] * sc, cv[7] * sc)};
+    const f32x2 q0 = sv[0] * scp, q1 = sv[1] * scp, q2 = sv[2] * scp, q3 = sv[3] * scp;
+    const u32x2 q = {pack4_fp8(q0[0], q0[1], q1[0], q1[1]), pack4_fp8(q2[0], q2[1], q3[0], q3[1])};
     EPI_STORE(reinterpret_cast<u32x2*>(c8 + (int64_t)row * n_p + col), q);
   }
   __device__ void s_tile_end(int, int) {}
   __device__ void s_end(float* scratch) {
-    const float v = wave_sum(l1);
+    const float v = wave_sum(l1p[0] + l1p[1]);
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     lds_barrier();
     if (threadIdx.x == 0) {
