@@ -450,8 +450,10 @@ __device__ __forceinline__ void gemm256_tile(const GemmArgs& g, Epi& epi, char* 
       pa2 = a_ptr(clampk(kt_begin + 2));
       pb2 = b_ptr(clampk(kt_begin + 2));
     }
-    pa2_seg1 = AMODE == OP_ROW ? g.A1 + (int64_t)(bm * G2_BM) * g.lda : g.A1 + bm * G2_BM;
-    pb2_seg1 = BMODE == OP_ROW ? g.B1 + (int64_t)(bn * G2_BN) * g.ldb : g.B1 + bn * G2_BN;
+    if (g.A1 != nullptr) {      // (one K segment: kn == ktiles0 never holds inside the walk, the origins stay unused)
+      pa2_seg1 = AMODE == OP_ROW ? g.A1 + (int64_t)(bm * G2_BM) * g.lda : g.A1 + bm * G2_BM;
+      pb2_seg1 = BMODE == OP_ROW ? g.B1 + (int64_t)(bn * G2_BN) * g.ldb : g.B1 + bn * G2_BN;
+    }
     pa2_step = AMODE == OP_ROW ? (int64_t)GEMM_BK : (int64_t)GEMM_BK * g.lda;
     pb2_step = BMODE == OP_ROW ? (int64_t)GEMM_BK : (int64_t)GEMM_BK * g.ldb;
   }
