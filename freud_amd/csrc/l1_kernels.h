@@ -382,7 +382,11 @@ struct EpiDpre {
 #pragma unroll
     for (int k = 0; k < 4; ++k) scp[k] = f32x2{0.f, 0.f};
   }
+#ifdef DPRE_KO_GATE      // TIMING EXPERIMENT ONLY (results WRONG): no read of the latent -- what would a 1-bit gate mask from the encoder buy this GEMM at most?
+  __device__ SPre s_prefetch(int row, int col) const { return SPre{u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}}; }
+#else
   __device__ SPre s_prefetch(int row, int col) const { return SPre{EPI_LOAD(reinterpret_cast<const u32x4*>(c + (int64_t)row * n_p + col))}; }
+#endif
   // the gate c > 0 on the bf16 BITS: the upper element of a pair is positive iff the dword, as a signed integer, exceeds 0xFFFF; the
   // lower one iff the dword shifted left by 16 is positive (-0.0, which a max(x, 0) may leave, is negative as an integer)
   template <bool PARTIAL>
