@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the engine side of this experiment (EpiEncG / EpiDpreG, the FREUD_GATE_MASK switch) was measured and REMOVED -- DESIGN.md section 7 item 5,
+# profiles/r06_gate_mask_experiment.txt; the script is kept as the record of what was run.
 # round 6: the L1 backward's ReLU gate as a bit mask from the streaming encoder (EpiEncG -> EpiDpreG) against the latent read (FREUD_GATE_MASK=0),
 # same library, same box, interleaved: tests through both, then C4 / C5 bf16 step + kernel times
 O=gpurun_out/r06_gatemask; mkdir -p $O
